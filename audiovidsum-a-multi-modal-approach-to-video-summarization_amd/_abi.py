@@ -1,0 +1,112 @@
+"""ctypes binding of libavsum_hip.so (the C-ABI declared in include/avsum_hip.h).
+
+The product path has no CPU fallback: if the library is missing, or a call
+returns a non-zero status, this module raises.  Build with
+``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C csrc``.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_uint, c_void_p
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "lib", "libavsum_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "avsum_hip.h")
+
+AVS_F32, AVS_BF16 = 0, 1
+ACT_NONE, ACT_RELU = 0, 1
+BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
+
+
+class AvsError(RuntimeError):
+    pass
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [
+        ("dtype", c_int),
+        ("n", c_int), ("h", c_int), ("w", c_int),
+        ("cin", c_int), ("kh", c_int), ("kw", c_int),
+        ("sh", c_int), ("sw", c_int), ("ph", c_int), ("pw", c_int),
+        ("ho", c_int), ("wo", c_int), ("cout", c_int),
+        ("x_img_stride", c_int64), ("x_row_stride", c_int64), ("x_px_stride", c_int64),
+        ("w_row_stride", c_int64), ("y_px_stride", c_int64),
+        ("act", c_int), ("alpha", c_float),
+    ]
+
+
+P = c_void_p  # device pointer
+_SIGNATURES = {
+    "avs_abi_version": (c_int, []),
+    "avs_last_error": (c_char_p, []),
+    "avs_device_info": (c_int, [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int64), c_char_p, c_int]),
+    "avs_conv2d_nhwc": (c_int, [POINTER(ConvDesc), P, P, P, P, P]),
+    "avs_gemm_nt": (c_int, [c_int, c_int, c_int, c_int, P, c_int64, c_int64, P, c_int64, c_int64, P, c_int64,
+                            c_int64, P, c_int, c_int64, c_float, c_int, c_int, P]),
+    "avs_frames_normalize_u8": (c_int, [c_int, P, c_int, c_int, c_int, c_float, POINTER(c_float), POINTER(c_float),
+                                        POINTER(c_float), P, c_int, c_int, c_int, c_int, P]),
+    "avs_resize_bilinear_u8": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, P]),
+    "avs_bn_batch_stats": (c_int, [c_int, P, c_int64, c_int, c_int64, P, c_int, P, P, c_float, P, P, P]),
+    "avs_bn_apply": (c_int, [c_int, P, c_int64, c_int, c_int64, P, c_int, c_int64, P, P, P, c_int64, c_int, P,
+                             c_int64, P]),
+    "avs_pool2d_nhwc": (c_int, [c_int, c_int, P, c_int, c_int, c_int, c_int, c_int64, c_int, c_int, c_int, P, c_int,
+                                c_int, c_int64, P]),
+    "avs_global_avgpool_nhwc": (c_int, [c_int, P, c_int, c_int, c_int, P, c_int64, P]),
+    "avs_segment_mean_f32": (c_int, [P, c_int64, c_int, P, c_int, P, c_int64, P]),
+    "avs_reflect_pad_f32": (c_int, [P, c_int64, c_int, P, c_int64, P]),
+    "avs_power_mel_f32": (c_int, [P, c_int64, c_int, P, P, P, c_int, c_int, P, P, P]),
+    "avs_clamp_topdb_f32": (c_int, [P, c_int64, P, c_float, P]),
+    "avs_fill_f32": (c_int, [P, c_int64, c_float, P]),
+    "avs_lstm_f32": (c_int, [P, P, c_int, c_int, c_uint, P, c_int, P, c_int64, c_int, P]),
+    "avs_mha_batchaxis_f32": (c_int, [P, c_int, c_int, c_int, c_int, P, P]),
+    "avs_score_head_f32": (c_int, [P, c_int64, c_int, c_int64, P, P, P, P]),
+    "avs_softmax_rows_f32": (c_int, [P, c_int64, c_int, c_int64, P]),
+    "avs_cdist_f64": (c_int, [P, c_int, P, c_int, c_int, P, P]),
+    "avs_dtw_workspace_bytes": (c_int64, [c_int, c_int]),
+    "avs_dtw_path_f64": (c_int, [P, c_int, c_int, P, c_int64, P, P, P, P]),
+    "avs_gather_scale_f32": (c_int, [P, c_int64, c_int, P, P, c_int, P, P]),
+}
+
+_lib = None
+
+
+def declared_symbols():
+    """Names of every function include/avsum_hip.h declares (parsed from the header)."""
+    import re
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(avs_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib():
+    """Load libavsum_hip.so once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AvsError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run __graft_entry__.build() or `make -C <package>/csrc`). There is no CPU fallback."
+        )
+    handle = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(handle, name)
+        fn.restype = res
+        fn.argtypes = args
+    if handle.avs_abi_version() != 1:
+        raise AvsError(f"ABI version mismatch: library reports {handle.avs_abi_version()}, binding expects 1")
+    _lib = handle
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().avs_last_error()
+        raise AvsError(f"{what} failed with status {status}: {msg.decode() if msg else ''}")
+
+
+def device_info(dev=0):
+    cu, clk, mem = c_int(), c_int(), c_int64()
+    arch = ctypes.create_string_buffer(64)
+    check(lib().avs_device_info(dev, ctypes.byref(cu), ctypes.byref(clk), ctypes.byref(mem), arch, 64),
+          "avs_device_info")
+    return {"cu_count": cu.value, "clock_khz": clk.value, "hbm_bytes": mem.value, "arch": arch.value.decode()}

@@ -1,0 +1,117 @@
+"""Mel-spectrogram / MFCC front end on the MI355X.
+
+Replaces torchaudio.transforms.MelSpectrogram / MFCC as called from
+features/extractors.py:236-246 (torchaudio is a third-party dependency that is
+not in the reference tree; its defaults are restated in SURVEY Appendix A.1-A.4:
+n_fft = win = 400, periodic Hann, hop 200, center/reflect, power 2, HTK mel
+scale 0..sr/2, norm None, DCT-II ortho, AmplitudeToDB('power', top_db=80)).
+
+Constants are built once per (sample_rate, device) in float64 and rounded to
+fp32; the Hann window is folded into the DFT basis so the STFT is one NT GEMM
+whose A rows are the overlapping frames of the reflect-padded waveform
+(row stride = hop).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+from ._abi import BIAS_NONE
+
+N_FFT = 400
+HOP = 200
+N_BINS = N_FFT // 2 + 1  # 201
+
+
+def _hz_to_mel(f):
+    return 2595.0 * math.log10(1.0 + f / 700.0)
+
+
+def mel_filterbank(sample_rate, n_mels, n_freqs=N_BINS, f_min=0.0, f_max=None):
+    """[n_freqs, n_mels] triangular HTK filters, norm=None (float64)."""
+    f_max = float(sample_rate // 2) if f_max is None else f_max
+    all_freqs = np.linspace(0.0, sample_rate // 2, n_freqs)
+    m_pts = np.linspace(_hz_to_mel(f_min), _hz_to_mel(f_max), n_mels + 2)
+    f_pts = 700.0 * (10.0 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts[None, :] - all_freqs[:, None]
+    down = -slopes[:, :-2] / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    return np.maximum(0.0, np.minimum(down, up))
+
+
+def dct_matrix(n_mfcc, n_mels):
+    """[n_mfcc, n_mels] DCT-II with ortho normalisation (rows = coefficients)."""
+    n = np.arange(n_mels, dtype=np.float64)
+    k = np.arange(n_mfcc, dtype=np.float64)[:, None]
+    d = np.cos(math.pi / n_mels * (n + 0.5) * k)
+    d[0] *= 1.0 / math.sqrt(2.0)
+    d *= math.sqrt(2.0 / n_mels)
+    return d
+
+
+def windowed_dft_basis():
+    """[2*N_BINS, N_FFT]: rows 0..200 = w[n] cos(2 pi k n / N), rows 201..401 = -w[n] sin(...)."""
+    n = np.arange(N_FFT)
+    window = 0.5 * (1.0 - np.cos(2.0 * math.pi * n / N_FFT))  # periodic Hann
+    k = np.arange(N_BINS)[:, None]
+    ang = 2.0 * math.pi * ((k * n[None, :]) % N_FFT) / N_FFT
+    return np.concatenate([np.cos(ang) * window, -np.sin(ang) * window], 0)
+
+
+class MelPlan:
+    """Device-resident constants + the launch sequence for log2-mel and MFCC."""
+
+    _cache = {}
+
+    def __init__(self, sample_rate, n_mels, n_mfcc, device):
+        self.sample_rate, self.n_mels, self.n_mfcc, self.device = sample_rate, n_mels, n_mfcc, device
+        self.basis = torch.from_numpy(windowed_dft_basis().astype(np.float32)).to(device)
+        fb = mel_filterbank(sample_rate, n_mels).astype(np.float32)
+        nz = fb > 0
+        lo = np.where(nz.any(0), nz.argmax(0), 0).astype(np.int32)
+        hi = np.where(nz.any(0), N_BINS - nz[::-1].argmax(0), 0).astype(np.int32)
+        self.fb = torch.from_numpy(fb).to(device)
+        self.fb_lo = torch.from_numpy(lo).to(device)
+        self.fb_hi = torch.from_numpy(hi).to(device)
+        self.dct = torch.from_numpy(dct_matrix(n_mfcc, n_mels).astype(np.float32)).to(device)
+
+    @classmethod
+    def get(cls, sample_rate, n_mels, n_mfcc, device):
+        key = (sample_rate, n_mels, n_mfcc, str(device))
+        if key not in cls._cache:
+            cls._cache[key] = cls(sample_rate, n_mels, n_mfcc, device)
+        return cls._cache[key]
+
+    @staticmethod
+    def num_frames(t):
+        return 1 + t // HOP
+
+    def spectrum(self, wave):
+        """wave fp32 [T] on device, T > 200 -> (re | im) [frames, 402] of the Hann-windowed STFT."""
+        t = wave.numel()
+        if t <= N_FFT // 2:
+            # torch.stft(center=True, pad_mode="reflect") raises for T <= pad as well
+            raise RuntimeError(f"Argument #4: Padding size should be less than the corresponding input dimension, "
+                               f"but got: padding ({N_FFT // 2}, {N_FFT // 2}) at dimension 1 of input [1, {t}]")
+        frames = self.num_frames(t)
+        padded = ops.reflect_pad(wave.contiguous(), N_FFT // 2, t + N_FFT)
+        spec = torch.empty((frames, 2 * N_BINS), dtype=torch.float32, device=wave.device)
+        ops.gemm_nt_batched(ops.dtype_code(torch.float32), frames, 2 * N_BINS, N_FFT, padded, 0, HOP, 0, self.basis, 0,
+                            N_FFT, 0, spec, 0, 2 * N_BINS, 0, None, BIAS_NONE, 0, 1.0, ops.ACT_NONE, 1)
+        return spec
+
+    def log2_mel(self, wave):
+        """[frames, n_mels] = log2(mel + 1e-6)  (features/extractors.py:241-246)."""
+        return ops.power_mel(self.spectrum(wave), N_BINS, self.fb, self.fb_lo, self.fb_hi, 0)
+
+    def mel_power(self, wave):
+        return ops.power_mel(self.spectrum(wave), N_BINS, self.fb, self.fb_lo, self.fb_hi, 2)
+
+    def mfcc(self, wave, top_db=80.0):
+        """[frames, n_mfcc] (torchaudio MFCC, log_mels=False)."""
+        gmax = torch.zeros(1, dtype=torch.float32, device=wave.device)
+        db = ops.power_mel(self.spectrum(wave), N_BINS, self.fb, self.fb_lo, self.fb_hi, 1, gmax)
+        ops.clamp_topdb(db, gmax, top_db)
+        return ops.linear(db, self.dct)

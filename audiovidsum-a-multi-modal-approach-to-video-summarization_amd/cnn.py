@@ -1,0 +1,465 @@
+"""CNN trunks of the visual extractor on the MI355X.
+
+The reference builds ``torchvision.models.resnet50(pretrained=True)`` minus its
+``fc`` as an ``nn.Sequential`` (features/extractors.py:25,29) and
+``inception_v3(pretrained=True, aux_logits=True)`` with ``fc = Identity``
+(:26,32-36).  torchvision and its weight files are not available offline, so
+this module supplies
+
+  * parameter containers with torchvision's module structure and state-dict
+    keys (weights come from ``load_state_dict`` or a seeded init), and
+  * runners that execute the trunks through libavsum_hip.so on NHWC tensors:
+    every convolution is the implicit-GEMM kernel (fp32 MFMA = parity mode,
+    bf16 MFMA = throughput mode); ResNet BatchNorm runs in BATCH-STATISTICS
+    mode per micro-batch group, because the reference never puts that trunk in
+    eval mode; Inception BatchNorm (eval mode, eps 1e-3) is folded
+    into the convolution weights.
+
+The containers deliberately have no torch forward: the product path is HIP only.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+RESNET_MEAN = (0.485, 0.456, 0.406)
+RESNET_STD = (0.229, 0.224, 0.225)
+
+
+class _NoTorchForward(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover - guard
+        raise RuntimeError("this module only holds parameters; the trunk runs through the HIP runner")
+
+
+# ============================================================================ ResNet-50 container
+class Bottleneck(_NoTorchForward):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)  # v1.5: stride on the 3x3
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+
+def _make_layer(inplanes, planes, blocks, stride):
+    downsample = None
+    if stride != 1 or inplanes != planes * 4:
+        downsample = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride, bias=False), nn.BatchNorm2d(planes * 4))
+    layers = [Bottleneck(inplanes, planes, stride, downsample)]
+    for _ in range(1, blocks):
+        layers.append(Bottleneck(planes * 4, planes))
+    return nn.Sequential(*layers)
+
+
+def resnet50_trunk():
+    """``nn.Sequential(*list(resnet50().children())[:-1])`` with torchvision's init (kaiming fan_out, BN 1/0)."""
+    trunk = nn.Sequential(
+        nn.Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True), nn.MaxPool2d(3, 2, 1),
+        _make_layer(64, 64, 3, 1), _make_layer(256, 128, 4, 2), _make_layer(512, 256, 6, 2),
+        _make_layer(1024, 512, 3, 2), nn.AdaptiveAvgPool2d((1, 1)),
+    )
+    for m in trunk.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        elif isinstance(m, nn.BatchNorm2d):
+            nn.init.constant_(m.weight, 1)
+            nn.init.constant_(m.bias, 0)
+    return trunk
+
+
+# ============================================================================ helpers
+def _ohwi(weight, dtype):
+    """OIHW conv weight -> [O, kh*kw*I] in the kernel's reduction order."""
+    o, i, kh, kw = weight.shape
+    return weight.detach().permute(0, 2, 3, 1).reshape(o, kh * kw * i).to(dtype).contiguous()
+
+
+def _stem_weight(weight, px, dtype):
+    """Stem conv [O,3,kh,kw] on the 4-channel pre-padded image: each kernel row becomes ``px`` pixels x 4
+    channels (zero beyond kw and in channel 3) so that one reduction step is a contiguous run of pixels."""
+    o, i, kh, kw = weight.shape
+    w = torch.zeros((o, kh, px, 4), dtype=torch.float32, device=weight.device)
+    w[:, :, :kw, :i] = weight.detach().permute(0, 2, 3, 1)
+    return w.reshape(o, kh * px * 4).to(dtype).contiguous()
+
+
+class ResNet50Runner:
+    """Runs the container's parameters on uint8 frames [N,224,224,3] -> fp32 [N,2048]."""
+
+    def __init__(self, trunk, dtype=torch.float32, bn_mode="batch"):
+        if bn_mode not in ("batch", "folded"):
+            raise ValueError("bn_mode must be 'batch' (reference-faithful) or 'folded'")
+        self.trunk, self.dtype, self.bn_mode = trunk, dtype, bn_mode
+        self._key = None
+        self._w = None
+
+    # weights in kernel layout, rebuilt when the parameters change / move
+    def _prepare(self):
+        key = tuple((p.data_ptr(), p._version) for p in self.trunk.parameters()) + (self.dtype,)
+        if self._w is not None and key == self._key:
+            return self._w
+        t, dt = self.trunk, self.dtype
+        w = {"stem": _stem_weight(t[0].weight, 8, dt), "blocks": []}
+
+        def bn(m):
+            return (m.weight.detach().float().contiguous(), m.bias.detach().float().contiguous(), float(m.eps),
+                    m.running_mean.detach().float(), m.running_var.detach().float())
+
+        w["bn1"] = bn(t[1])
+        for li in range(4, 8):
+            for blk in t[li]:
+                d = {"c1": _ohwi(blk.conv1.weight, dt), "b1": bn(blk.bn1), "c2": _ohwi(blk.conv2.weight, dt),
+                     "b2": bn(blk.bn2), "c3": _ohwi(blk.conv3.weight, dt), "b3": bn(blk.bn3),
+                     "stride": blk.stride, "planes": blk.conv1.out_channels}
+                if blk.downsample is not None:
+                    d["cd"] = _ohwi(blk.downsample[0].weight, dt)
+                    d["bd"] = bn(blk.downsample[1])
+                w["blocks"].append(d)
+        self._w, self._key = w, key
+        return w
+
+    def _bn(self, raw2d, bnp, groups, hw, residual=None, relu=True, out=None):
+        gamma, beta, eps, rmean, rvar = bnp
+        act = ops.ACT_RELU if relu else ops.ACT_NONE
+        if self.bn_mode == "batch":
+            grows, gmax = groups[hw]
+            scale, shift = ops.bn_batch_stats(raw2d, grows, gamma, beta, eps)
+            return ops.bn_apply(raw2d, scale, shift, grows, gmax, residual, act, raw2d if out is None else out)
+        scale = (gamma / torch.sqrt(rvar + eps)).contiguous()
+        shift = (beta - rmean * scale).contiguous()
+        return ops.bn_apply(raw2d, scale.view(1, -1), shift.view(1, -1), None, 0, residual, act,
+                            raw2d if out is None else out)
+
+    def forward(self, frames_u8, group_frames=None):
+        """frames_u8: device uint8 [N,224,224,3] (already 224x224, extractors.py:132).
+        group_frames: int64 CPU tensor / list [G+1] of frame offsets of the BatchNorm micro-batch groups
+        (extractors.py:48-56); default = one group per frame."""
+        n, h, w_, _ = frames_u8.shape
+        if (h, w_) != (224, 224):
+            raise ValueError("ResNet50Runner expects 224x224 frames (resize first)")
+        if n == 0:
+            return torch.zeros((0, 2048), dtype=torch.float32, device=frames_u8.device)
+        w = self._prepare()
+        dev, dt = frames_u8.device, self.dtype
+        if group_frames is None:
+            group_frames = torch.arange(n + 1, dtype=torch.int64)
+        group_frames = torch.as_tensor(group_frames, dtype=torch.int64)
+        if int(group_frames[0]) != 0 or int(group_frames[-1]) != n:
+            raise ValueError("group_frames must start at 0 and end at N")
+        gsz = int((group_frames[1:] - group_frames[:-1]).max())
+        groups = {hw: ((group_frames * hw).to(dev), gsz * hw) for hw in (112 * 112, 56 * 56, 28 * 28, 14 * 14, 7 * 7)}
+
+        # stem: (x - mean)/std without /255 (extractors.py:133-139), zero padded by 3 (conv1 pad) into
+        # [N,230,232,4]; conv1 7x7/2 reads 8-pixel (32-element) runs: kh=7 rows x 32 elements.
+        x0 = ops.frames_normalize(frames_u8, dt, 1.0, RESNET_MEAN, RESNET_STD, 230, 232, 3, 3)
+        c1 = torch.empty((n, 112, 112, 64), dtype=dt, device=dev)
+        ops.conv2d_raw(ops.dtype_code(dt), n, 230, 112, 32, 7, 1, 2, 1, 0, 0, 112, 112, 64, x0, 230 * 232 * 4, 232 * 4,
+                       8, w["stem"], w["stem"].stride(0), c1, 64)
+        del x0
+        a1 = self._bn(c1.view(-1, 64), w["bn1"], groups, 112 * 112).view(n, 112, 112, 64)
+        del c1
+        x = torch.empty((n, 56, 56, 64), dtype=dt, device=dev)
+        ops.pool2d(a1, "max", 3, 2, 1, x)
+        del a1
+        hcur = 56
+        for blk in w["blocks"]:
+            s, planes = blk["stride"], blk["planes"]
+            cin = x.shape[3]
+            hout = hcur // s
+            t1 = torch.empty((n, hcur, hcur, planes), dtype=dt, device=dev)
+            ops.conv2d(x, blk["c1"], 1, 1, 1, 0, t1)
+            t1 = self._bn(t1.view(-1, planes), blk["b1"], groups, hcur * hcur).view(n, hcur, hcur, planes)
+            t2 = torch.empty((n, hout, hout, planes), dtype=dt, device=dev)
+            ops.conv2d(t1, blk["c2"], 3, 3, s, 1, t2)
+            del t1
+            t2 = self._bn(t2.view(-1, planes), blk["b2"], groups, hout * hout).view(n, hout, hout, planes)
+            t3 = torch.empty((n, hout, hout, planes * 4), dtype=dt, device=dev)
+            ops.conv2d(t2, blk["c3"], 1, 1, 1, 0, t3)
+            del t2
+            if "cd" in blk:
+                idn = torch.empty((n, hout, hout, planes * 4), dtype=dt, device=dev)
+                ops.conv2d(x, blk["cd"], 1, 1, s, 0, idn)
+                idn = self._bn(idn.view(-1, planes * 4), blk["bd"], groups, hout * hout, relu=False)
+            else:
+                idn = x.view(-1, cin)
+            x = self._bn(t3.view(-1, planes * 4), blk["b3"], groups, hout * hout, residual=idn, relu=True)
+            x = x.view(n, hout, hout, planes * 4)
+            del t3, idn
+            hcur = hout
+        return ops.global_avgpool(x)
+
+
+# ============================================================================ Inception-v3 container
+class BasicConv2d(_NoTorchForward):
+    def __init__(self, cin, cout, **kw):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, bias=False, **kw)
+        self.bn = nn.BatchNorm2d(cout, eps=0.001)
+
+
+class InceptionA(_NoTorchForward):
+    def __init__(self, cin, pool_features):
+        super().__init__()
+        self.branch1x1 = BasicConv2d(cin, 64, kernel_size=1)
+        self.branch5x5_1 = BasicConv2d(cin, 48, kernel_size=1)
+        self.branch5x5_2 = BasicConv2d(48, 64, kernel_size=5, padding=2)
+        self.branch3x3dbl_1 = BasicConv2d(cin, 64, kernel_size=1)
+        self.branch3x3dbl_2 = BasicConv2d(64, 96, kernel_size=3, padding=1)
+        self.branch3x3dbl_3 = BasicConv2d(96, 96, kernel_size=3, padding=1)
+        self.branch_pool = BasicConv2d(cin, pool_features, kernel_size=1)
+
+
+class InceptionB(_NoTorchForward):
+    def __init__(self, cin):
+        super().__init__()
+        self.branch3x3 = BasicConv2d(cin, 384, kernel_size=3, stride=2)
+        self.branch3x3dbl_1 = BasicConv2d(cin, 64, kernel_size=1)
+        self.branch3x3dbl_2 = BasicConv2d(64, 96, kernel_size=3, padding=1)
+        self.branch3x3dbl_3 = BasicConv2d(96, 96, kernel_size=3, stride=2)
+
+
+class InceptionC(_NoTorchForward):
+    def __init__(self, cin, c7):
+        super().__init__()
+        self.branch1x1 = BasicConv2d(cin, 192, kernel_size=1)
+        self.branch7x7_1 = BasicConv2d(cin, c7, kernel_size=1)
+        self.branch7x7_2 = BasicConv2d(c7, c7, kernel_size=(1, 7), padding=(0, 3))
+        self.branch7x7_3 = BasicConv2d(c7, 192, kernel_size=(7, 1), padding=(3, 0))
+        self.branch7x7dbl_1 = BasicConv2d(cin, c7, kernel_size=1)
+        self.branch7x7dbl_2 = BasicConv2d(c7, c7, kernel_size=(7, 1), padding=(3, 0))
+        self.branch7x7dbl_3 = BasicConv2d(c7, c7, kernel_size=(1, 7), padding=(0, 3))
+        self.branch7x7dbl_4 = BasicConv2d(c7, c7, kernel_size=(7, 1), padding=(3, 0))
+        self.branch7x7dbl_5 = BasicConv2d(c7, 192, kernel_size=(1, 7), padding=(0, 3))
+        self.branch_pool = BasicConv2d(cin, 192, kernel_size=1)
+
+
+class InceptionD(_NoTorchForward):
+    def __init__(self, cin):
+        super().__init__()
+        self.branch3x3_1 = BasicConv2d(cin, 192, kernel_size=1)
+        self.branch3x3_2 = BasicConv2d(192, 320, kernel_size=3, stride=2)
+        self.branch7x7x3_1 = BasicConv2d(cin, 192, kernel_size=1)
+        self.branch7x7x3_2 = BasicConv2d(192, 192, kernel_size=(1, 7), padding=(0, 3))
+        self.branch7x7x3_3 = BasicConv2d(192, 192, kernel_size=(7, 1), padding=(3, 0))
+        self.branch7x7x3_4 = BasicConv2d(192, 192, kernel_size=3, stride=2)
+
+
+class InceptionE(_NoTorchForward):
+    def __init__(self, cin):
+        super().__init__()
+        self.branch1x1 = BasicConv2d(cin, 320, kernel_size=1)
+        self.branch3x3_1 = BasicConv2d(cin, 384, kernel_size=1)
+        self.branch3x3_2a = BasicConv2d(384, 384, kernel_size=(1, 3), padding=(0, 1))
+        self.branch3x3_2b = BasicConv2d(384, 384, kernel_size=(3, 1), padding=(1, 0))
+        self.branch3x3dbl_1 = BasicConv2d(cin, 448, kernel_size=1)
+        self.branch3x3dbl_2 = BasicConv2d(448, 384, kernel_size=3, padding=1)
+        self.branch3x3dbl_3a = BasicConv2d(384, 384, kernel_size=(1, 3), padding=(0, 1))
+        self.branch3x3dbl_3b = BasicConv2d(384, 384, kernel_size=(3, 1), padding=(1, 0))
+        self.branch_pool = BasicConv2d(cin, 192, kernel_size=1)
+
+
+class InceptionAux(_NoTorchForward):
+    """Present in the checkpoint the reference loads (aux_logits=True at construction,
+    extractors.py:26) but never executed (aux_logits set False at :36, eval mode)."""
+
+    def __init__(self, cin, num_classes):
+        super().__init__()
+        self.conv0 = BasicConv2d(cin, 128, kernel_size=1)
+        self.conv1 = BasicConv2d(128, 768, kernel_size=5)
+        self.fc = nn.Linear(768, num_classes)
+
+
+class Inception3(_NoTorchForward):
+    """torchvision ``Inception3`` module tree with ``fc = Identity`` and ``transform_input = True``
+    (what ``inception_v3(pretrained=True)`` sets)."""
+
+    def __init__(self):
+        super().__init__()
+        self.aux_logits = True
+        self.transform_input = True
+        self.Conv2d_1a_3x3 = BasicConv2d(3, 32, kernel_size=3, stride=2)
+        self.Conv2d_2a_3x3 = BasicConv2d(32, 32, kernel_size=3)
+        self.Conv2d_2b_3x3 = BasicConv2d(32, 64, kernel_size=3, padding=1)
+        self.maxpool1 = nn.MaxPool2d(kernel_size=3, stride=2)
+        self.Conv2d_3b_1x1 = BasicConv2d(64, 80, kernel_size=1)
+        self.Conv2d_4a_3x3 = BasicConv2d(80, 192, kernel_size=3)
+        self.maxpool2 = nn.MaxPool2d(kernel_size=3, stride=2)
+        self.Mixed_5b = InceptionA(192, 32)
+        self.Mixed_5c = InceptionA(256, 64)
+        self.Mixed_5d = InceptionA(288, 64)
+        self.Mixed_6a = InceptionB(288)
+        self.Mixed_6b = InceptionC(768, 128)
+        self.Mixed_6c = InceptionC(768, 160)
+        self.Mixed_6d = InceptionC(768, 160)
+        self.Mixed_6e = InceptionC(768, 192)
+        self.AuxLogits = InceptionAux(768, 1000)
+        self.Mixed_7a = InceptionD(768)
+        self.Mixed_7b = InceptionE(1280)
+        self.Mixed_7c = InceptionE(2048)
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.dropout = nn.Dropout(p=0.5)
+        self.fc = nn.Identity()
+        # Synthetic init (no pretrained weights offline): variance-preserving, so that eval-mode
+        # BatchNorm with running stats (0, 1) keeps activations O(1) through 94 convolutions.
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_in", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        self.eval()
+
+
+INCEPTION_TRANSFORM = (0.229 / 0.5, 0.224 / 0.5, 0.225 / 0.5,
+                       (0.485 - 0.5) / 0.5, (0.456 - 0.5) / 0.5, (0.406 - 0.5) / 0.5)
+
+
+class InceptionV3Runner:
+    """uint8 frames [N,299,299,3] -> fp32 [N,2048]; eval-mode BatchNorm folded into the convolutions."""
+
+    def __init__(self, net, dtype=torch.float32):
+        self.net, self.dtype = net, dtype
+        self._key = None
+        self._w = None
+
+    def _fold(self, bc, stem_px=None):
+        conv, bn = bc.conv, bc.bn
+        with torch.no_grad():
+            s = bn.weight.float() / torch.sqrt(bn.running_var.float() + bn.eps)
+            wt = conv.weight.float() * s.view(-1, 1, 1, 1)
+            bias = (bn.bias.float() - bn.running_mean.float() * s).contiguous()
+            w = _stem_weight(wt, stem_px, self.dtype) if stem_px else _ohwi(wt, self.dtype)
+        kh, kw = conv.kernel_size
+        return {"w": w, "b": bias, "kh": kh, "kw": kw, "s": conv.stride[0], "ph": conv.padding[0],
+                "pw": conv.padding[1], "cout": conv.out_channels}
+
+    def _prepare(self):
+        key = tuple((p.data_ptr(), p._version) for p in self.net.parameters()) + \
+            tuple((b.data_ptr(), b._version) for b in self.net.buffers()) + (self.dtype,)
+        if self._w is not None and key == self._key:
+            return self._w
+        w = {}
+        for name, m in self.net.named_modules():
+            if isinstance(m, BasicConv2d) and not name.startswith("AuxLogits"):
+                w[name] = self._fold(m, stem_px=4 if name == "Conv2d_1a_3x3" else None)
+        self._w, self._key = w, key
+        return w
+
+    # conv + folded BN + ReLU into `out` (an NHWC view, possibly a channel slice)
+    def _conv(self, w, name, x, out=None):
+        c = w[name]
+        n, h, ww, _ = x.shape
+        ho = (h + 2 * c["ph"] - c["kh"]) // c["s"] + 1
+        wo = (ww + 2 * c["pw"] - c["kw"]) // c["s"] + 1
+        if out is None:
+            out = torch.empty((n, ho, wo, c["cout"]), dtype=self.dtype, device=x.device)
+        return ops.conv2d(x, c["w"], c["kh"], c["kw"], c["s"], (c["ph"], c["pw"]), out, c["b"], ops.ACT_RELU)
+
+    def _pool(self, x, mode, k, s, p, out=None):
+        n, h, ww, c = x.shape
+        ho, wo = (h + 2 * p - k) // s + 1, (ww + 2 * p - k) // s + 1
+        if out is None:
+            out = torch.empty((n, ho, wo, c), dtype=self.dtype, device=x.device)
+        return ops.pool2d(x, mode, k, s, p, out)
+
+    def _cat_buffer(self, x, channels, stride=1):
+        n, h, ww, _ = x.shape
+        if stride == 2:
+            h, ww = (h - 3) // 2 + 1, (ww - 3) // 2 + 1
+        buf = torch.empty((n, h, ww, sum(channels)), dtype=self.dtype, device=x.device)
+        offs = [0]
+        for c in channels:
+            offs.append(offs[-1] + c)
+        return buf, [buf[..., offs[i]:offs[i + 1]] for i in range(len(channels))]
+
+    def _block_a(self, w, p, x, pf):
+        buf, (o1, o5, o3, op) = self._cat_buffer(x, [64, 64, 96, pf])
+        self._conv(w, p + ".branch1x1", x, o1)
+        self._conv(w, p + ".branch5x5_2", self._conv(w, p + ".branch5x5_1", x), o5)
+        t = self._conv(w, p + ".branch3x3dbl_2", self._conv(w, p + ".branch3x3dbl_1", x))
+        self._conv(w, p + ".branch3x3dbl_3", t, o3)
+        self._conv(w, p + ".branch_pool", self._pool(x, "avg", 3, 1, 1), op)
+        return buf
+
+    def _block_b(self, w, p, x):
+        buf, (o3, od, op) = self._cat_buffer(x, [384, 96, x.shape[3]], stride=2)
+        self._conv(w, p + ".branch3x3", x, o3)
+        t = self._conv(w, p + ".branch3x3dbl_2", self._conv(w, p + ".branch3x3dbl_1", x))
+        self._conv(w, p + ".branch3x3dbl_3", t, od)
+        self._pool(x, "max", 3, 2, 0, op)
+        return buf
+
+    def _block_c(self, w, p, x):
+        buf, (o1, o7, od, op) = self._cat_buffer(x, [192, 192, 192, 192])
+        self._conv(w, p + ".branch1x1", x, o1)
+        t = self._conv(w, p + ".branch7x7_2", self._conv(w, p + ".branch7x7_1", x))
+        self._conv(w, p + ".branch7x7_3", t, o7)
+        t = self._conv(w, p + ".branch7x7dbl_1", x)
+        for i in (2, 3, 4):
+            t = self._conv(w, f"{p}.branch7x7dbl_{i}", t)
+        self._conv(w, p + ".branch7x7dbl_5", t, od)
+        self._conv(w, p + ".branch_pool", self._pool(x, "avg", 3, 1, 1), op)
+        return buf
+
+    def _block_d(self, w, p, x):
+        buf, (o3, o7, op) = self._cat_buffer(x, [320, 192, x.shape[3]], stride=2)
+        self._conv(w, p + ".branch3x3_2", self._conv(w, p + ".branch3x3_1", x), o3)
+        t = self._conv(w, p + ".branch7x7x3_1", x)
+        t = self._conv(w, p + ".branch7x7x3_2", t)
+        t = self._conv(w, p + ".branch7x7x3_3", t)
+        self._conv(w, p + ".branch7x7x3_4", t, o7)
+        self._pool(x, "max", 3, 2, 0, op)
+        return buf
+
+    def _block_e(self, w, p, x):
+        buf, (o1, o3a, o3b, oda, odb, op) = self._cat_buffer(x, [320, 384, 384, 384, 384, 192])
+        self._conv(w, p + ".branch1x1", x, o1)
+        t = self._conv(w, p + ".branch3x3_1", x)
+        self._conv(w, p + ".branch3x3_2a", t, o3a)
+        self._conv(w, p + ".branch3x3_2b", t, o3b)
+        t = self._conv(w, p + ".branch3x3dbl_2", self._conv(w, p + ".branch3x3dbl_1", x))
+        self._conv(w, p + ".branch3x3dbl_3a", t, oda)
+        self._conv(w, p + ".branch3x3dbl_3b", t, odb)
+        self._conv(w, p + ".branch_pool", self._pool(x, "avg", 3, 1, 1), op)
+        return buf
+
+    def forward(self, frames_u8):
+        n, h, w_, _ = frames_u8.shape
+        if (h, w_) != (299, 299):
+            raise ValueError("InceptionV3Runner expects 299x299 frames (resize first)")
+        if n == 0:
+            return torch.zeros((0, 2048), dtype=torch.float32, device=frames_u8.device)
+        w = self._prepare()
+        dt, dev = self.dtype, frames_u8.device
+        # (x/255 - mean)/std (extractors.py:151-153) then transform_input; one spare zero
+        # pixel on the right so the stem's 4-pixel runs stay inside the row.
+        affine = INCEPTION_TRANSFORM if self.net.transform_input else None
+        x0 = ops.frames_normalize(frames_u8, dt, 255.0, RESNET_MEAN, RESNET_STD, 299, 300, 0, 0, affine)
+        c = w["Conv2d_1a_3x3"]
+        x = torch.empty((n, 149, 149, 32), dtype=dt, device=dev)
+        ops.conv2d_raw(ops.dtype_code(dt), n, 299, 149, 16, 3, 1, 2, 1, 0, 0, 149, 149, 32, x0, 299 * 300 * 4, 300 * 4, 8,
+                       c["w"], c["w"].stride(0), x, 32, c["b"], ops.ACT_RELU)
+        del x0
+        x = self._conv(w, "Conv2d_2a_3x3", x)
+        x = self._conv(w, "Conv2d_2b_3x3", x)
+        x = self._pool(x, "max", 3, 2, 0)
+        x = self._conv(w, "Conv2d_3b_1x1", x)
+        x = self._conv(w, "Conv2d_4a_3x3", x)
+        x = self._pool(x, "max", 3, 2, 0)
+        x = self._block_a(w, "Mixed_5b", x, 32)
+        x = self._block_a(w, "Mixed_5c", x, 64)
+        x = self._block_a(w, "Mixed_5d", x, 64)
+        x = self._block_b(w, "Mixed_6a", x)
+        for name in ("Mixed_6b", "Mixed_6c", "Mixed_6d", "Mixed_6e"):
+            x = self._block_c(w, name, x)
+        x = self._block_d(w, "Mixed_7a", x)
+        x = self._block_e(w, "Mixed_7b", x)
+        x = self._block_e(w, "Mixed_7c", x)
+        return ops.global_avgpool(x)

@@ -1,0 +1,133 @@
+// Audio front-end kernels.  The 400-point real DFT of every STFT
+// frame is a contraction against the windowed DFT basis and runs on the fp32
+// MFMA through avs_gemm_nt (row stride = hop, so overlapping frames are read in
+// place); this file holds the bandwidth-bound tail: |X|^2 -> mel -> log.
+#include "avs_internal.h"
+#include <math.h>
+
+__global__ __launch_bounds__(256) void reflect_pad_kernel(const float* __restrict__ x, long long t, int pad,
+                                                          float* __restrict__ out, long long out_len) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < out_len;
+       i += (long long)gridDim.x * blockDim.x) {
+    long long j = i - pad;
+    float v = 0.f;
+    if (i < t + 2ll * pad) {
+      if (j < 0) j = -j;
+      if (j >= t) j = 2 * (t - 1) - j;
+      v = x[j];
+    }
+    out[i] = v;
+  }
+}
+
+extern "C" int avs_reflect_pad_f32(const float* d_x, int64_t t, int pad, float* d_out, int64_t out_len,
+                                   avs_stream_t stream) {
+  AVS_REQUIRE(t > pad && pad >= 0 && out_len >= t + 2ll * pad, AVS_E_SHAPE,
+              "avs_reflect_pad_f32: need t > pad and out_len >= t + 2*pad (t=%lld pad=%d out_len=%lld)", (long long)t,
+              pad, (long long)out_len);
+  AVS_REQUIRE(d_x && d_out, AVS_E_ARG, "avs_reflect_pad_f32: null pointer");
+  long long gx = avs_cdiv(out_len, 256);
+  if (gx > 8192) gx = 8192;
+  hipLaunchKernelGGL(reflect_pad_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, d_x, (long long)t, pad,
+                     d_out, (long long)out_len);
+  AVS_CHECK_LAUNCH("avs_reflect_pad_f32");
+  return AVS_OK;
+}
+
+// One block = FPB STFT frames.  Power spectrum staged in LDS, then each thread
+// owns (frame, mel) pairs and sums its filter's non-zero bins in ascending order.
+#define AVS_MEL_FPB 8
+#define AVS_MEL_MAXBINS 1025
+
+__global__ __launch_bounds__(256) void power_mel_kernel(const float* __restrict__ spec, long long frames, int nbins,
+                                                        const float* __restrict__ fb, const int* __restrict__ fb_lo,
+                                                        const int* __restrict__ fb_hi, int nmel, int mode,
+                                                        float* __restrict__ out, float* __restrict__ gmax) {
+  extern __shared__ float pw[];  // [FPB][nbins]
+  const long long f0 = (long long)blockIdx.x * AVS_MEL_FPB;
+  const int nf = (int)((frames - f0) < AVS_MEL_FPB ? (frames - f0) : AVS_MEL_FPB);
+  for (int i = threadIdx.x; i < nf * nbins; i += blockDim.x) {
+    const int f = i / nbins, k = i - f * nbins;
+    const float re = spec[(f0 + f) * 2 * nbins + k];
+    const float im = spec[(f0 + f) * 2 * nbins + nbins + k];
+    pw[i] = re * re + im * im;
+  }
+  __syncthreads();
+  float lmax = 0.f;
+  for (int i = threadIdx.x; i < nf * nmel; i += blockDim.x) {
+    const int f = i / nmel, m = i - f * nmel;
+    const int lo = fb_lo[m], hi = fb_hi[m];
+    float a = 0.f;
+    for (int k = lo; k < hi; ++k) a += pw[f * nbins + k] * fb[(long long)k * nmel + m];
+    float v;
+    if (mode == 0) {
+      v = log2f(a + 1e-6f);
+    } else if (mode == 1) {
+      const float cl = fmaxf(a, 1e-10f);
+      lmax = fmaxf(lmax, cl);
+      v = 10.f * log10f(cl);
+    } else {
+      v = a;
+    }
+    out[(f0 + f) * nmel + m] = v;
+  }
+  if (mode == 1) {
+    lmax = avs_wave_max(lmax);
+    // positive floats order like their bit patterns
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(gmax), __float_as_uint(lmax));
+  }
+}
+
+extern "C" int avs_power_mel_f32(const float* d_spec, int64_t frames, int nbins, const float* d_fb, const int* d_fb_lo,
+                                 const int* d_fb_hi, int nmel, int mode, float* d_out, float* d_max,
+                                 avs_stream_t stream) {
+  AVS_REQUIRE(frames >= 0 && nbins > 0 && nbins <= AVS_MEL_MAXBINS && nmel > 0 && mode >= 0 && mode <= 2, AVS_E_SHAPE,
+              "avs_power_mel_f32: frames=%lld nbins=%d nmel=%d mode=%d", (long long)frames, nbins, nmel, mode);
+  if (frames == 0) return AVS_OK;
+  AVS_REQUIRE(d_spec && d_fb && d_fb_lo && d_fb_hi && d_out, AVS_E_ARG, "avs_power_mel_f32: null pointer");
+  AVS_REQUIRE(mode != 1 || d_max, AVS_E_ARG, "avs_power_mel_f32: mode 1 needs d_max");
+  const long long blocks = avs_cdiv(frames, AVS_MEL_FPB);
+  AVS_REQUIRE(blocks < (1ll << 31), AVS_E_SHAPE, "avs_power_mel_f32: too many frames");
+  const size_t shmem = (size_t)AVS_MEL_FPB * nbins * sizeof(float);
+  hipLaunchKernelGGL(power_mel_kernel, dim3((unsigned)blocks), dim3(256), shmem, (hipStream_t)stream, d_spec,
+                     (long long)frames, nbins, d_fb, d_fb_lo, d_fb_hi, nmel, mode, d_out, d_max);
+  AVS_CHECK_LAUNCH("avs_power_mel_f32");
+  return AVS_OK;
+}
+
+__global__ __launch_bounds__(256) void clamp_topdb_kernel(float* __restrict__ x, long long count,
+                                                          const float* __restrict__ gmax, float top_db) {
+  const float thr = 10.f * log10f(*gmax) - top_db;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += (long long)gridDim.x * blockDim.x)
+    x[i] = fmaxf(x[i], thr);
+}
+
+extern "C" int avs_clamp_topdb_f32(float* d_x, int64_t count, const float* d_max, float top_db, avs_stream_t stream) {
+  AVS_REQUIRE(count >= 0, AVS_E_SHAPE, "avs_clamp_topdb_f32: negative count");
+  if (count == 0) return AVS_OK;
+  AVS_REQUIRE(d_x && d_max, AVS_E_ARG, "avs_clamp_topdb_f32: null pointer");
+  long long gx = avs_cdiv(count, 256);
+  if (gx > 8192) gx = 8192;
+  hipLaunchKernelGGL(clamp_topdb_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, d_x, (long long)count,
+                     d_max, top_db);
+  AVS_CHECK_LAUNCH("avs_clamp_topdb_f32");
+  return AVS_OK;
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ x, long long count, float v) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += (long long)gridDim.x * blockDim.x)
+    x[i] = v;
+}
+
+extern "C" int avs_fill_f32(float* d_x, int64_t count, float value, avs_stream_t stream) {
+  AVS_REQUIRE(count >= 0, AVS_E_SHAPE, "avs_fill_f32: negative count");
+  if (count == 0) return AVS_OK;
+  AVS_REQUIRE(d_x, AVS_E_ARG, "avs_fill_f32: null pointer");
+  long long gx = avs_cdiv(count, 256);
+  if (gx > 8192) gx = 8192;
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, d_x, (long long)count, value);
+  AVS_CHECK_LAUNCH("avs_fill_f32");
+  return AVS_OK;
+}

@@ -1,0 +1,65 @@
+// Internal helpers shared by the gfx950 kernels of libavsum_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/avsum_hip.h"
+
+#define AVS_WAVE 64
+
+void avs_set_error(const char* fmt, ...);
+
+#define AVS_REQUIRE(cond, code, ...)      \
+  do {                                    \
+    if (!(cond)) {                        \
+      avs_set_error(__VA_ARGS__);         \
+      return (code);                      \
+    }                                     \
+  } while (0)
+
+// Launch-error check: kernel launches are asynchronous; this only catches
+// configuration errors, which is what the ABI promises.
+#define AVS_CHECK_LAUNCH(name)                                              \
+  do {                                                                      \
+    hipError_t e__ = hipGetLastError();                                     \
+    if (e__ != hipSuccess) {                                                \
+      avs_set_error("%s: HIP launch failed: %s", name, hipGetErrorString(e__)); \
+      return AVS_E_HIP;                                                     \
+    }                                                                       \
+  } while (0)
+
+static inline bool avs_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+static inline int64_t avs_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+typedef __bf16 avs_bf16;
+
+__device__ __forceinline__ float avs_bf16_to_f32(unsigned short u) {
+  return __uint_as_float(((unsigned)u) << 16);
+}
+__device__ __forceinline__ unsigned short avs_f32_to_bf16(float f) {
+  avs_bf16 b = (avs_bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+  return __builtin_bit_cast(unsigned short, b);
+}
+
+template <typename T> struct avs_elem;
+template <> struct avs_elem<float> {
+  static __device__ __forceinline__ float load(const float* p) { return *p; }
+  static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+};
+struct avs_bf16_tag { unsigned short bits; };
+template <> struct avs_elem<avs_bf16_tag> {
+  static __device__ __forceinline__ float load(const avs_bf16_tag* p) { return avs_bf16_to_f32(p->bits); }
+  static __device__ __forceinline__ void store(avs_bf16_tag* p, float v) { p->bits = avs_f32_to_bf16(v); }
+};
+
+__device__ __forceinline__ float avs_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float avs_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

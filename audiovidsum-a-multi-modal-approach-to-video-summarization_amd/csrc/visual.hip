@@ -1,0 +1,468 @@
+// Visual front-end kernels: all HBM-bound, one pass
+// over their tensor, 16-byte accesses along the channel axis of NHWC.
+#include "avs_internal.h"
+#include <math.h>
+
+// ---------------------------------------------------------------------------
+// u8 HWC frame -> normalised, zero-padded, 4-channel NHWC image
+// ---------------------------------------------------------------------------
+struct NormParams {
+  float denom;
+  float mean[3], stdv[3];
+  float aff_a[3], aff_b[3];
+  int has_affine;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void frames_normalize_kernel(const uint8_t* __restrict__ src, int n, int h, int w,
+                                                               NormParams np, T* __restrict__ out, int out_h,
+                                                               int out_w, int pad_t, int pad_l) {
+  const long long total = (long long)n * out_h * out_w;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % out_w);
+    const long long t = i / out_w;
+    const int oy = (int)(t % out_h);
+    const long long img = t / out_h;
+    const int sy = oy - pad_t, sx = ox - pad_l;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)sy < (unsigned)h && (unsigned)sx < (unsigned)w) {
+      const uint8_t* s = src + ((img * h + sy) * (long long)w + sx) * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float f = (float)s[c] / np.denom;
+        f = (f - np.mean[c]) / np.stdv[c];
+        if (np.has_affine) {
+          f = f * np.aff_a[c];
+          f = f + np.aff_b[c];
+        }
+        v[c] = f;
+      }
+    }
+    T* o = out + i * 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) avs_elem<T>::store(o + c, v[c]);
+  }
+}
+
+extern "C" int avs_frames_normalize_u8(int dtype, const uint8_t* d_src, int n, int h, int w, float denom,
+                                       const float* mean3, const float* std3, const float* affine6, void* d_out,
+                                       int out_h, int out_w, int pad_t, int pad_l, avs_stream_t stream) {
+  AVS_REQUIRE(dtype == AVS_F32 || dtype == AVS_BF16, AVS_E_ARG, "avs_frames_normalize_u8: bad dtype");
+  AVS_REQUIRE(n >= 0 && h > 0 && w > 0 && out_h >= h + pad_t && out_w >= w + pad_l && pad_t >= 0 && pad_l >= 0,
+              AVS_E_SHAPE, "avs_frames_normalize_u8: bad extents");
+  if (n == 0) return AVS_OK;
+  AVS_REQUIRE(d_src && d_out && mean3 && std3, AVS_E_ARG, "avs_frames_normalize_u8: null pointer");
+  AVS_REQUIRE(denom != 0.f, AVS_E_ARG, "avs_frames_normalize_u8: denom == 0");
+  NormParams np;
+  np.denom = denom;
+  for (int c = 0; c < 3; ++c) {
+    np.mean[c] = mean3[c];
+    np.stdv[c] = std3[c];
+    np.aff_a[c] = affine6 ? affine6[c] : 1.f;
+    np.aff_b[c] = affine6 ? affine6[3 + c] : 0.f;
+  }
+  np.has_affine = affine6 != nullptr;
+  const long long total = (long long)n * out_h * out_w;
+  const int grid = (int)(avs_cdiv(total, 256) < 16384 ? avs_cdiv(total, 256) : 16384);
+  if (dtype == AVS_F32)
+    hipLaunchKernelGGL(frames_normalize_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_src, n, h, w,
+                       np, (float*)d_out, out_h, out_w, pad_t, pad_l);
+  else
+    hipLaunchKernelGGL(frames_normalize_kernel<avs_bf16_tag>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_src, n,
+                       h, w, np, (avs_bf16_tag*)d_out, out_h, out_w, pad_t, pad_l);
+  AVS_CHECK_LAUNCH("avs_frames_normalize_u8");
+  return AVS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// cv2.resize(..., INTER_LINEAR) for uint8, 3 channels: 11-bit fixed-point
+// coefficients, horizontal pass in int32, vertical pass with the >>4, >>16, +2, >>2
+// rounding of OpenCV's VResizeLinear.  [3P-memory: OpenCV source absent here]
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void cv_linear_coef(int d, double scale, int smax, int& s0, int& s1, int& c0, int& c1) {
+  float f = (float)((d + 0.5) * scale - 0.5);
+  int s = (int)floorf(f);
+  f -= (float)s;
+  if (s < 0) {
+    f = 0.f;
+    s = 0;
+  }
+  if (s >= smax - 1) {
+    f = 0.f;
+    s = smax - 1;
+  }
+  s0 = s;
+  s1 = min(s + 1, smax - 1);
+  c0 = __float2int_rn((1.f - f) * 2048.f);
+  c1 = __float2int_rn(f * 2048.f);
+}
+
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const uint8_t* __restrict__ src, int n, int sh, int sw,
+                                                              uint8_t* __restrict__ dst, int dh, int dw,
+                                                              double scale_y, double scale_x) {
+  const long long total = (long long)n * dh * dw;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int dx = (int)(i % dw);
+    const long long t = i / dw;
+    const int dy = (int)(t % dh);
+    const long long img = t / dh;
+    int x0, x1, a0, a1, y0, y1, b0, b1;
+    cv_linear_coef(dx, scale_x, sw, x0, x1, a0, a1);
+    cv_linear_coef(dy, scale_y, sh, y0, y1, b0, b1);
+    const uint8_t* r0 = src + (img * sh + y0) * (long long)sw * 3;
+    const uint8_t* r1 = src + (img * sh + y1) * (long long)sw * 3;
+    uint8_t* o = dst + i * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int S0 = r0[x0 * 3 + c] * a0 + r0[x1 * 3 + c] * a1;
+      const int S1 = r1[x0 * 3 + c] * a0 + r1[x1 * 3 + c] * a1;
+      int v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
+      v = v < 0 ? 0 : (v > 255 ? 255 : v);
+      o[c] = (uint8_t)v;
+    }
+  }
+}
+
+extern "C" int avs_resize_bilinear_u8(const uint8_t* d_src, int n, int sh, int sw, uint8_t* d_dst, int dh, int dw,
+                                      avs_stream_t stream) {
+  AVS_REQUIRE(n >= 0 && sh > 0 && sw > 0 && dh > 0 && dw > 0, AVS_E_SHAPE, "avs_resize_bilinear_u8: bad extents");
+  if (n == 0) return AVS_OK;
+  AVS_REQUIRE(d_src && d_dst, AVS_E_ARG, "avs_resize_bilinear_u8: null pointer");
+  const long long total = (long long)n * dh * dw;
+  const int grid = (int)(avs_cdiv(total, 256) < 16384 ? avs_cdiv(total, 256) : 16384);
+  // OpenCV: inv_scale = dsize/ssize (double); scale = 1/inv_scale.
+  const double scale_x = 1.0 / ((double)dw / (double)sw);
+  const double scale_y = 1.0 / ((double)dh / (double)sh);
+  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_src, n, sh, sw, d_dst, dh,
+                     dw, scale_y, scale_x);
+  AVS_CHECK_LAUNCH("avs_resize_bilinear_u8");
+  return AVS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Batch-statistics BatchNorm: per (group, channel) mean / biased variance over
+// the group's rows, folded with gamma/beta into scale/shift.
+// Thread = 4 channels; a block is TC channel-threads x TR row-threads.  Sums
+// are taken about the group's first row (shifted data) so that the
+// E[d^2] - E[d]^2 form does not cancel.
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void load4(const T* p, float (&v)[4]);
+template <>
+__device__ __forceinline__ void load4<float>(const float* p, float (&v)[4]) {
+  const float4 f = *reinterpret_cast<const float4*>(p);
+  v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+}
+template <>
+__device__ __forceinline__ void load4<avs_bf16_tag>(const avs_bf16_tag* p, float (&v)[4]) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  v[0] = __uint_as_float(u.x << 16);
+  v[1] = __uint_as_float(u.x & 0xffff0000u);
+  v[2] = __uint_as_float(u.y << 16);
+  v[3] = __uint_as_float(u.y & 0xffff0000u);
+}
+template <typename T>
+__device__ __forceinline__ void store4(T* p, const float (&v)[4]);
+template <>
+__device__ __forceinline__ void store4<float>(float* p, const float (&v)[4]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <>
+__device__ __forceinline__ void store4<avs_bf16_tag>(avs_bf16_tag* p, const float (&v)[4]) {
+  uint2 u;
+  u.x = (unsigned)avs_f32_to_bf16(v[0]) | ((unsigned)avs_f32_to_bf16(v[1]) << 16);
+  u.y = (unsigned)avs_f32_to_bf16(v[2]) | ((unsigned)avs_f32_to_bf16(v[3]) << 16);
+  *reinterpret_cast<uint2*>(p) = u;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, int c, long long ldx,
+                                                       const int64_t* __restrict__ group_rows,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                                       int tc) {
+  __shared__ float red[2][256][4];
+  const int g = blockIdx.x;
+  const int tr = 256 / tc;
+  const int ct = threadIdx.x % tc;  // channel-thread
+  const int rt = threadIdx.x / tc;  // row-thread
+  const int ch = (blockIdx.y * tc + ct) * 4;
+  const long long r0 = group_rows[g], r1 = group_rows[g + 1];
+  const long long nrows = r1 - r0;
+  float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0}, ref[4] = {0, 0, 0, 0};
+  const bool active = ch < c && nrows > 0;
+  if (active) {
+    load4<T>(x + r0 * ldx + ch, ref);
+    for (long long r = r0 + rt; r < r1; r += tr) {
+      float v[4];
+      load4<T>(x + r * ldx + ch, v);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = v[j] - ref[j];
+        s1[j] += d;
+        s2[j] = fmaf(d, d, s2[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    red[0][threadIdx.x][j] = s1[j];
+    red[1][threadIdx.x][j] = s2[j];
+  }
+  __syncthreads();
+  if (rt == 0 && active) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float a = 0.f, b = 0.f;
+      for (int k = 0; k < tr; ++k) {
+        a += red[0][k * tc + ct][j];
+        b += red[1][k * tc + ct][j];
+      }
+      const float inv_n = 1.f / (float)nrows;
+      const float md = a * inv_n;
+      float var = b * inv_n - md * md;
+      var = fmaxf(var, 0.f);
+      const float mean = ref[j] + md;
+      const float rstd = 1.f / sqrtf(var + eps);
+      const float sc = rstd * gamma[ch + j];
+      scale[(long long)g * c + ch + j] = sc;
+      shift[(long long)g * c + ch + j] = beta[ch + j] - mean * sc;
+    }
+  }
+}
+
+extern "C" int avs_bn_batch_stats(int dtype, const void* d_x, int64_t rows, int c, int64_t ldx,
+                                  const int64_t* d_group_rows, int groups, const float* d_gamma, const float* d_beta,
+                                  float eps, float* d_scale, float* d_shift, avs_stream_t stream) {
+  AVS_REQUIRE(dtype == AVS_F32 || dtype == AVS_BF16, AVS_E_ARG, "avs_bn_batch_stats: bad dtype");
+  AVS_REQUIRE(rows >= 0 && c > 0 && c % 4 == 0 && ldx >= c && ldx % 4 == 0 && groups >= 0, AVS_E_SHAPE,
+              "avs_bn_batch_stats: rows=%lld c=%d ldx=%lld groups=%d", (long long)rows, c, (long long)ldx, groups);
+  if (groups == 0) return AVS_OK;
+  AVS_REQUIRE(d_x && d_group_rows && d_gamma && d_beta && d_scale && d_shift, AVS_E_ARG,
+              "avs_bn_batch_stats: null pointer");
+  AVS_REQUIRE(avs_aligned16(d_x), AVS_E_ALIGN, "avs_bn_batch_stats: x not 16-byte aligned");
+  int tc = 1;
+  while (tc < 64 && tc * 4 < c) tc <<= 1;  // power of two <= 64 channel-threads
+  dim3 grid(groups, (unsigned)avs_cdiv(c, tc * 4));
+  if (dtype == AVS_F32)
+    hipLaunchKernelGGL(bn_stats_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)d_x, c,
+                       (long long)ldx, d_group_rows, d_gamma, d_beta, eps, d_scale, d_shift, tc);
+  else
+    hipLaunchKernelGGL(bn_stats_kernel<avs_bf16_tag>, grid, dim3(256), 0, (hipStream_t)stream,
+                       (const avs_bf16_tag*)d_x, c, (long long)ldx, d_group_rows, d_gamma, d_beta, eps, d_scale,
+                       d_shift, tc);
+  AVS_CHECK_LAUNCH("avs_bn_batch_stats");
+  return AVS_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, int c, long long ldx,
+                                                       const int64_t* __restrict__ group_rows, long long rows,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       const T* __restrict__ res, long long ldr, int act,
+                                                       T* __restrict__ y, long long ldy) {
+  const int cv = c >> 2;
+  long long r0 = 0, r1 = rows;
+  long long g = 0;
+  if (group_rows) {
+    g = blockIdx.y;
+    r0 = group_rows[g];
+    r1 = group_rows[g + 1];
+  }
+  const long long total = (r1 - r0) * cv;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long row = r0 + i / cv;
+    const int ch = (int)(i % cv) * 4;
+    float v[4], sc[4], sf[4];
+    load4<T>(x + row * ldx + ch, v);
+    load4<float>(scale + g * c + ch, sc);
+    load4<float>(shift + g * c + ch, sf);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = v[j] * sc[j] + sf[j];
+    if (res) {
+      float rv[4];
+      load4<T>(res + row * ldr + ch, rv);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] += rv[j];
+    }
+    if (act == AVS_ACT_RELU) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+    }
+    store4<T>(y + row * ldy + ch, v);
+  }
+}
+
+extern "C" int avs_bn_apply(int dtype, const void* d_x, int64_t rows, int c, int64_t ldx, const int64_t* d_group_rows,
+                            int groups, int64_t max_group_rows, const float* d_scale, const float* d_shift,
+                            const void* d_residual, int64_t ldr, int act, void* d_y, int64_t ldy,
+                            avs_stream_t stream) {
+  AVS_REQUIRE(dtype == AVS_F32 || dtype == AVS_BF16, AVS_E_ARG, "avs_bn_apply: bad dtype");
+  AVS_REQUIRE(rows >= 0 && c > 0 && c % 4 == 0 && ldx >= c && ldx % 4 == 0 && ldy >= c && ldy % 4 == 0 &&
+                  (!d_residual || (ldr >= c && ldr % 4 == 0)),
+              AVS_E_SHAPE, "avs_bn_apply: rows=%lld c=%d ldx=%lld ldy=%lld ldr=%lld", (long long)rows, c,
+              (long long)ldx, (long long)ldy, (long long)ldr);
+  AVS_REQUIRE((groups > 0) == (d_group_rows != nullptr), AVS_E_ARG, "avs_bn_apply: groups and d_group_rows disagree");
+  if (rows == 0) return AVS_OK;
+  AVS_REQUIRE(d_x && d_scale && d_shift && d_y, AVS_E_ARG, "avs_bn_apply: null pointer");
+  const long long span = (groups > 0 ? max_group_rows : rows) * (c >> 2);
+  AVS_REQUIRE(span > 0, AVS_E_SHAPE, "avs_bn_apply: max_group_rows must be > 0");
+  long long gx = avs_cdiv(span, 256);
+  if (gx > 8192) gx = 8192;
+  dim3 grid((unsigned)gx, groups > 0 ? groups : 1);
+  AVS_REQUIRE(grid.y <= 65535, AVS_E_SHAPE, "avs_bn_apply: more than 65535 groups in one call");
+  if (dtype == AVS_F32)
+    hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)d_x, c,
+                       (long long)ldx, d_group_rows, (long long)rows, d_scale, d_shift, (const float*)d_residual,
+                       (long long)ldr, act, (float*)d_y, (long long)ldy);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<avs_bf16_tag>, grid, dim3(256), 0, (hipStream_t)stream,
+                       (const avs_bf16_tag*)d_x, c, (long long)ldx, d_group_rows, (long long)rows, d_scale, d_shift,
+                       (const avs_bf16_tag*)d_residual, (long long)ldr, act, (avs_bf16_tag*)d_y, (long long)ldy);
+  AVS_CHECK_LAUNCH("avs_bn_apply");
+  return AVS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Pooling on NHWC
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pool2d_kernel(int mode, const T* __restrict__ x, int n, int h, int w, int c,
+                                                     long long xps, int k, int s, int p, T* __restrict__ y, int ho,
+                                                     int wo, long long yps) {
+  const int cv = c >> 2;
+  const long long total = (long long)n * ho * wo * cv;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % cv) * 4;
+    long long t = i / cv;
+    const int ox = (int)(t % wo);
+    t /= wo;
+    const int oy = (int)(t % ho);
+    const long long img = t / ho;
+    float a[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = mode == 0 ? -INFINITY : 0.f;
+    for (int ky = 0; ky < k; ++ky) {
+      const int iy = oy * s - p + ky;
+      if ((unsigned)iy >= (unsigned)h) continue;
+      for (int kx = 0; kx < k; ++kx) {
+        const int ix = ox * s - p + kx;
+        if ((unsigned)ix >= (unsigned)w) continue;
+        float v[4];
+        load4<T>(x + ((img * h + iy) * (long long)w + ix) * xps + ch, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = mode == 0 ? fmaxf(a[j], v[j]) : a[j] + v[j];
+      }
+    }
+    if (mode == 1) {
+      const float d = (float)(k * k);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = a[j] / d;
+    }
+    store4<T>(y + ((img * ho + oy) * (long long)wo + ox) * yps + ch, a);
+  }
+}
+
+extern "C" int avs_pool2d_nhwc(int dtype, int mode, const void* d_x, int n, int h, int w, int c, int64_t x_px_stride,
+                               int k, int s, int p, void* d_y, int ho, int wo, int64_t y_px_stride,
+                               avs_stream_t stream) {
+  AVS_REQUIRE(dtype == AVS_F32 || dtype == AVS_BF16, AVS_E_ARG, "avs_pool2d_nhwc: bad dtype");
+  AVS_REQUIRE(mode == 0 || mode == 1, AVS_E_ARG, "avs_pool2d_nhwc: bad mode");
+  AVS_REQUIRE(n >= 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0 && k > 0 && s > 0 && p >= 0 && p < k && ho > 0 &&
+                  wo > 0 && x_px_stride >= c && x_px_stride % 4 == 0 && y_px_stride >= c && y_px_stride % 4 == 0,
+              AVS_E_SHAPE, "avs_pool2d_nhwc: bad extents");
+  AVS_REQUIRE((ho - 1) * s - p < h && (wo - 1) * s - p < w, AVS_E_SHAPE, "avs_pool2d_nhwc: output extent too large");
+  if (n == 0) return AVS_OK;
+  AVS_REQUIRE(d_x && d_y, AVS_E_ARG, "avs_pool2d_nhwc: null pointer");
+  const long long total = (long long)n * ho * wo * (c >> 2);
+  long long gx = avs_cdiv(total, 256);
+  if (gx > 16384) gx = 16384;
+  if (dtype == AVS_F32)
+    hipLaunchKernelGGL(pool2d_kernel<float>, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, mode,
+                       (const float*)d_x, n, h, w, c, (long long)x_px_stride, k, s, p, (float*)d_y, ho, wo,
+                       (long long)y_px_stride);
+  else
+    hipLaunchKernelGGL(pool2d_kernel<avs_bf16_tag>, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, mode,
+                       (const avs_bf16_tag*)d_x, n, h, w, c, (long long)x_px_stride, k, s, p, (avs_bf16_tag*)d_y, ho,
+                       wo, (long long)y_px_stride);
+  AVS_CHECK_LAUNCH("avs_pool2d_nhwc");
+  return AVS_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void global_avgpool_kernel(const T* __restrict__ x, int n, int hw, int c,
+                                                             float* __restrict__ y, long long ldy) {
+  const int cv = c >> 2;
+  const long long total = (long long)n * cv;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % cv) * 4;
+    const long long img = i / cv;
+    float a[4] = {0, 0, 0, 0};
+    const T* base = x + img * hw * (long long)c + ch;
+    for (int r = 0; r < hw; ++r) {
+      float v[4];
+      load4<T>(base + (long long)r * c, v);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] += v[j];
+    }
+    const float d = (float)hw;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = a[j] / d;
+    store4<float>(y + img * ldy + ch, a);
+  }
+}
+
+extern "C" int avs_global_avgpool_nhwc(int dtype, const void* d_x, int n, int hw, int c, float* d_y, int64_t ldy,
+                                       avs_stream_t stream) {
+  AVS_REQUIRE(dtype == AVS_F32 || dtype == AVS_BF16, AVS_E_ARG, "avs_global_avgpool_nhwc: bad dtype");
+  AVS_REQUIRE(n >= 0 && hw > 0 && c > 0 && c % 4 == 0 && ldy >= c && ldy % 4 == 0, AVS_E_SHAPE,
+              "avs_global_avgpool_nhwc: bad extents");
+  if (n == 0) return AVS_OK;
+  AVS_REQUIRE(d_x && d_y, AVS_E_ARG, "avs_global_avgpool_nhwc: null pointer");
+  AVS_REQUIRE(avs_aligned16(d_y), AVS_E_ALIGN, "avs_global_avgpool_nhwc: y not 16-byte aligned");
+  const long long total = (long long)n * (c >> 2);
+  long long gx = avs_cdiv(total, 256);
+  if (gx > 16384) gx = 16384;
+  if (dtype == AVS_F32)
+    hipLaunchKernelGGL(global_avgpool_kernel<float>, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)d_x, n, hw, c, d_y, (long long)ldy);
+  else
+    hipLaunchKernelGGL(global_avgpool_kernel<avs_bf16_tag>, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream,
+                       (const avs_bf16_tag*)d_x, n, hw, c, d_y, (long long)ldy);
+  AVS_CHECK_LAUNCH("avs_global_avgpool_nhwc");
+  return AVS_OK;
+}
+
+// out[s,:] = mean over rows seg[s]..seg[s+1] in row order (numpy mean(axis=0))
+__global__ __launch_bounds__(256) void segment_mean_kernel(const float* __restrict__ x, long long ldx, int d,
+                                                           const int64_t* __restrict__ seg, int nseg,
+                                                           float* __restrict__ out, long long ldo) {
+  const long long total = (long long)nseg * d;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % d);
+    const long long s = i / d;
+    const long long r0 = seg[s], r1 = seg[s + 1];
+    float a = 0.f;
+    for (long long r = r0; r < r1; ++r) a += x[r * ldx + ch];
+    out[s * ldo + ch] = r1 > r0 ? a / (float)(r1 - r0) : 0.f;
+  }
+}
+
+extern "C" int avs_segment_mean_f32(const float* d_x, int64_t ldx, int d, const int64_t* d_seg, int nseg, float* d_out,
+                                    int64_t ldo, avs_stream_t stream) {
+  AVS_REQUIRE(d > 0 && ldx >= d && ldo >= d && nseg >= 0, AVS_E_SHAPE, "avs_segment_mean_f32: bad extents");
+  if (nseg == 0) return AVS_OK;
+  AVS_REQUIRE(d_x && d_seg && d_out, AVS_E_ARG, "avs_segment_mean_f32: null pointer");
+  long long gx = avs_cdiv((long long)nseg * d, 256);
+  if (gx > 16384) gx = 16384;
+  hipLaunchKernelGGL(segment_mean_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, d_x, (long long)ldx,
+                     d, d_seg, nseg, d_out, (long long)ldo);
+  AVS_CHECK_LAUNCH("avs_segment_mean_f32");
+  return AVS_OK;
+}

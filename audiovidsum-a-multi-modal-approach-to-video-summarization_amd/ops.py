@@ -1,0 +1,314 @@
+"""Tensor-level wrappers over the C-ABI: argument checking + launch on torch's
+current HIP stream.  torch is used for device memory and streams only; every
+computation below is a call into libavsum_hip.so.
+"""
+import ctypes
+from ctypes import c_float, c_void_p
+
+import torch
+
+from . import _abi
+from ._abi import ACT_NONE, ACT_RELU, AVS_BF16, AVS_F32, BIAS_COL, BIAS_NONE, BIAS_ROW, check, lib
+
+__all__ = [
+    "ACT_NONE", "ACT_RELU", "linear", "gemm_nt_batched", "conv2d", "conv2d_raw", "frames_normalize", "resize_bilinear",
+    "bn_batch_stats", "bn_apply", "pool2d", "global_avgpool", "segment_mean", "reflect_pad", "power_mel",
+    "clamp_topdb", "fill", "lstm", "mha_batchaxis", "score_head", "softmax_rows", "cdist", "dtw_path",
+    "gather_scale", "dtype_code",
+]
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t, offset_elems=0):
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr() + offset_elems * t.element_size())
+
+
+def dtype_code(dtype):
+    if dtype == torch.float32:
+        return AVS_F32
+    if dtype == torch.bfloat16:
+        return AVS_BF16
+    raise TypeError(f"unsupported compute dtype {dtype}")
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise ValueError("avsum HIP ops need device tensors (there is no CPU fallback)")
+
+
+def _f32(t, name):
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+
+
+def _rowmajor2d(t, name):
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise ValueError(f"{name} must be 2-D with unit column stride, got shape {tuple(t.shape)} strides {t.stride()}")
+
+
+# --------------------------------------------------------------------------- GEMM / conv
+def gemm_nt_batched(dtype, m, n, k, a, a_off, lda, sa, b, b_off, ldb, sb, c, c_off, ldc, sc, bias=None,
+                    bias_mode=BIAS_NONE, sbias=0, alpha=1.0, act=ACT_NONE, batch=1):
+    """Raw strided-batched C = act(alpha * A.B^T + bias); offsets/strides in elements."""
+    _dev(a, b, c, bias)
+    check(lib().avs_gemm_nt(dtype, m, n, k, _p(a, a_off), lda, sa, _p(b, b_off), ldb, sb, _p(c, c_off), ldc, sc,
+                            _p(bias), bias_mode, sbias, float(alpha), act, batch, _stream()), "avs_gemm_nt")
+
+
+def linear(x, w, bias=None, act=ACT_NONE, out=None, alpha=1.0):
+    """out[M,N] = act(alpha * x[M,K] . w[N,K]^T + bias[N]) — nn.Linear semantics."""
+    _rowmajor2d(x, "x")
+    _rowmajor2d(w, "w")
+    if x.dtype != w.dtype:
+        raise TypeError(f"x {x.dtype} and w {w.dtype} differ")
+    m, k = x.shape
+    n = w.shape[0]
+    if w.shape[1] != k:
+        raise ValueError(f"x [{m},{k}] vs w {tuple(w.shape)}")
+    if out is None:
+        out = torch.empty((m, n), dtype=x.dtype, device=x.device)
+    _rowmajor2d(out, "out")
+    if out.shape != (m, n) or out.dtype != x.dtype:
+        raise ValueError("out has the wrong shape or dtype")
+    if bias is not None:
+        _f32(bias, "bias")
+        if bias.numel() != n or not bias.is_contiguous():
+            raise ValueError("bias must be contiguous with N entries")
+    lda = x.stride(0) if m > 1 else k
+    ldb = w.stride(0) if n > 1 else k
+    ldc = out.stride(0) if m > 1 else n
+    gemm_nt_batched(dtype_code(x.dtype), m, n, k, x, 0, lda, 0, w, 0, ldb, 0, out, 0, ldc, 0, bias,
+                    BIAS_COL if bias is not None else BIAS_NONE, 0, alpha, act, 1)
+    return out
+
+
+def conv2d_raw(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x, x_img_stride, x_row_stride, x_px_stride,
+               wt, w_row_stride, y, y_px_stride, bias=None, act=ACT_NONE, alpha=1.0, x_off=0, y_off=0):
+    _dev(x, wt, y, bias)
+    d = _abi.ConvDesc(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x_img_stride, x_row_stride,
+                      x_px_stride, w_row_stride, y_px_stride, act, float(alpha))
+    check(lib().avs_conv2d_nhwc(ctypes.byref(d), _p(x, x_off), _p(wt), _p(bias), _p(y, y_off), _stream()),
+          "avs_conv2d_nhwc")
+
+
+def conv2d(x, wt, kh, kw, stride, pad, out, bias=None, act=ACT_NONE):
+    """x: NHWC view [n,h,w,cin] (unit channel stride); wt: [cout, kh*kw*cin]; out: NHWC view [n,ho,wo,cout]
+    whose pixels are dense in (n,ho,wo) order (a channel slice of a dense buffer is fine)."""
+    n, h, w, cin = x.shape
+    sh, sw = stride if isinstance(stride, tuple) else (stride, stride)
+    ph, pw = pad if isinstance(pad, tuple) else (pad, pad)
+    n2, ho, wo, cout = out.shape
+    if n2 != n or x.stride(3) != 1 or out.stride(3) != 1:
+        raise ValueError("bad conv operands")
+    if ho != (h + 2 * ph - kh) // sh + 1 or wo != (w + 2 * pw - kw) // sw + 1:
+        raise ValueError(f"out extent {ho}x{wo} does not match conv arithmetic")
+    yps = out.stride(2)
+    if n * ho * wo > 1 and not (out.stride(1) == wo * yps and (n == 1 or out.stride(0) == ho * wo * yps)):
+        raise ValueError("out pixels must be dense in (n,ho,wo) order")
+    if wt.shape != (cout, kh * kw * cin) or wt.dtype != x.dtype or out.dtype != x.dtype:
+        raise ValueError(f"weight {tuple(wt.shape)} / dtypes do not match")
+    if bias is not None:
+        _f32(bias, "bias")
+    conv2d_raw(dtype_code(x.dtype), n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x, x.stride(0), x.stride(1),
+               x.stride(2), wt, wt.stride(0), out, yps, bias, act)
+    return out
+
+
+# --------------------------------------------------------------------------- visual front end
+def frames_normalize(frames_u8, dtype, denom, mean, std, out_h, out_w, pad_t, pad_l, affine=None, out=None):
+    """frames_u8 [n,h,w,3] uint8 -> [n,out_h,out_w,4] normalised (4th channel 0), zero padded."""
+    _dev(frames_u8)
+    if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or frames_u8.shape[3] != 3 or not frames_u8.is_contiguous():
+        raise ValueError("frames must be contiguous uint8 [n,h,w,3]")
+    n, h, w, _ = frames_u8.shape
+    if out is None:
+        out = torch.empty((n, out_h, out_w, 4), dtype=dtype, device=frames_u8.device)
+    m3 = (c_float * 3)(*[float(v) for v in mean])
+    s3 = (c_float * 3)(*[float(v) for v in std])
+    a6 = (c_float * 6)(*[float(v) for v in affine]) if affine is not None else None
+    check(lib().avs_frames_normalize_u8(dtype_code(dtype), _p(frames_u8), n, h, w, float(denom), m3, s3, a6, _p(out),
+                                        out_h, out_w, pad_t, pad_l, _stream()), "avs_frames_normalize_u8")
+    return out
+
+
+def resize_bilinear(frames_u8, dh, dw):
+    _dev(frames_u8)
+    if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or frames_u8.shape[3] != 3 or not frames_u8.is_contiguous():
+        raise ValueError("frames must be contiguous uint8 [n,h,w,3]")
+    n, h, w, _ = frames_u8.shape
+    out = torch.empty((n, dh, dw, 3), dtype=torch.uint8, device=frames_u8.device)
+    check(lib().avs_resize_bilinear_u8(_p(frames_u8), n, h, w, _p(out), dh, dw, _stream()), "avs_resize_bilinear_u8")
+    return out
+
+
+def bn_batch_stats(x2d, group_rows, gamma, beta, eps):
+    """x2d [rows, C] (row stride >= C); group_rows int64 [G+1] device.  Returns scale, shift [G, C] fp32."""
+    _dev(x2d, group_rows, gamma, beta)
+    _rowmajor2d(x2d, "x")
+    rows, c = x2d.shape
+    g = group_rows.numel() - 1
+    scale = torch.empty((g, c), dtype=torch.float32, device=x2d.device)
+    shift = torch.empty((g, c), dtype=torch.float32, device=x2d.device)
+    check(lib().avs_bn_batch_stats(dtype_code(x2d.dtype), _p(x2d), rows, c, x2d.stride(0), _p(group_rows), g,
+                                   _p(gamma), _p(beta), float(eps), _p(scale), _p(shift), _stream()),
+          "avs_bn_batch_stats")
+    return scale, shift
+
+
+def bn_apply(x2d, scale, shift, group_rows=None, max_group_rows=0, residual=None, act=ACT_NONE, out=None):
+    _dev(x2d, scale, shift, group_rows, residual)
+    _rowmajor2d(x2d, "x")
+    rows, c = x2d.shape
+    if out is None:
+        out = torch.empty((rows, c), dtype=x2d.dtype, device=x2d.device)
+    g = group_rows.numel() - 1 if group_rows is not None else 0
+    check(lib().avs_bn_apply(dtype_code(x2d.dtype), _p(x2d), rows, c, x2d.stride(0), _p(group_rows), g,
+                             int(max_group_rows), _p(scale), _p(shift), _p(residual),
+                             residual.stride(0) if residual is not None else 0, act, _p(out), out.stride(0),
+                             _stream()), "avs_bn_apply")
+    return out
+
+
+def pool2d(x, mode, k, s, p, out):
+    """x, out: NHWC views (unit channel stride, dense pixels).  mode 'max' | 'avg'."""
+    n, h, w, c = x.shape
+    _, ho, wo, _ = out.shape
+    check(lib().avs_pool2d_nhwc(dtype_code(x.dtype), 0 if mode == "max" else 1, _p(x), n, h, w, c, x.stride(2), k, s,
+                                p, _p(out), ho, wo, out.stride(2), _stream()), "avs_pool2d_nhwc")
+    return out
+
+
+def global_avgpool(x, out=None):
+    """x [n,h,w,c] dense NHWC -> fp32 [n,c]."""
+    n, h, w, c = x.shape
+    if not x.is_contiguous():
+        raise ValueError("global_avgpool needs a dense NHWC tensor")
+    if out is None:
+        out = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    check(lib().avs_global_avgpool_nhwc(dtype_code(x.dtype), _p(x), n, h * w, c, _p(out), out.stride(0), _stream()),
+          "avs_global_avgpool_nhwc")
+    return out
+
+
+def segment_mean(x2d, seg, out=None):
+    _f32(x2d, "x")
+    _rowmajor2d(x2d, "x")
+    nseg = seg.numel() - 1
+    d = x2d.shape[1]
+    if out is None:
+        out = torch.empty((nseg, d), dtype=torch.float32, device=x2d.device)
+    check(lib().avs_segment_mean_f32(_p(x2d), x2d.stride(0), d, _p(seg), nseg, _p(out), out.stride(0), _stream()),
+          "avs_segment_mean_f32")
+    return out
+
+
+# --------------------------------------------------------------------------- audio front end
+def reflect_pad(x, pad, out_len):
+    _f32(x, "x")
+    out = torch.empty(out_len, dtype=torch.float32, device=x.device)
+    check(lib().avs_reflect_pad_f32(_p(x), x.numel(), pad, _p(out), out_len, _stream()), "avs_reflect_pad_f32")
+    return out
+
+
+def power_mel(spec, nbins, fb, fb_lo, fb_hi, mode, gmax=None):
+    frames = spec.shape[0]
+    nmel = fb.shape[1]
+    out = torch.empty((frames, nmel), dtype=torch.float32, device=spec.device)
+    check(lib().avs_power_mel_f32(_p(spec), frames, nbins, _p(fb), _p(fb_lo), _p(fb_hi), nmel, mode, _p(out),
+                                  _p(gmax), _stream()), "avs_power_mel_f32")
+    return out
+
+
+def clamp_topdb(x, gmax, top_db):
+    check(lib().avs_clamp_topdb_f32(_p(x), x.numel(), _p(gmax), float(top_db), _stream()), "avs_clamp_topdb_f32")
+    return x
+
+
+def fill(x, value):
+    _f32(x, "x")
+    check(lib().avs_fill_f32(_p(x), x.numel(), float(value), _stream()), "avs_fill_f32")
+    return x
+
+
+# --------------------------------------------------------------------------- scorer
+def lstm(xproj, whh_t, hidden, ndir, reverse_mask, seq_rows, out, out_col0):
+    _f32(xproj, "xproj")
+    _f32(whh_t, "whh_t")
+    _f32(out, "out")
+    if xproj.shape[1] != ndir * 4 * hidden or not xproj.is_contiguous() or not whh_t.is_contiguous():
+        raise ValueError("xproj must be contiguous [rows, ndir*4H], whh_t contiguous [ndir,H,4H]")
+    if tuple(whh_t.shape) != (ndir, hidden, 4 * hidden):
+        raise ValueError(f"whh_t shape {tuple(whh_t.shape)}")
+    nseq = seq_rows.numel() - 1
+    check(lib().avs_lstm_f32(_p(xproj), _p(whh_t), hidden, ndir, reverse_mask, _p(seq_rows), nseq, _p(out),
+                             out.stride(0), out_col0, _stream()), "avs_lstm_f32")
+    return out
+
+
+def mha_batchaxis(qkv, b, t, e, heads):
+    _f32(qkv, "qkv")
+    if tuple(qkv.shape) != (b * t, 3 * e) or not qkv.is_contiguous():
+        raise ValueError("qkv must be contiguous [B*T, 3E]")
+    ctx = torch.empty((b * t, e), dtype=torch.float32, device=qkv.device)
+    check(lib().avs_mha_batchaxis_f32(_p(qkv), b, t, e, heads, _p(ctx), _stream()), "avs_mha_batchaxis_f32")
+    return ctx
+
+
+def score_head(hid, w2, b2):
+    _f32(hid, "hid")
+    _rowmajor2d(hid, "hid")
+    rows, d = hid.shape
+    out = torch.empty(rows, dtype=torch.float32, device=hid.device)
+    check(lib().avs_score_head_f32(_p(hid), rows, d, hid.stride(0), _p(w2), _p(b2), _p(out), _stream()),
+          "avs_score_head_f32")
+    return out
+
+
+def softmax_rows(x, rows, n, ldx):
+    _f32(x, "x")
+    check(lib().avs_softmax_rows_f32(_p(x), rows, n, ldx, _stream()), "avs_softmax_rows_f32")
+    return x
+
+
+# --------------------------------------------------------------------------- fusion
+def cdist(v, a):
+    _f32(v, "v")
+    _f32(a, "a")
+    if v.dim() != 2 or a.dim() != 2 or v.shape[1] != a.shape[1]:
+        raise ValueError("XA and XB must have the same number of columns (i.e. feature dimension.)")
+    v = v.contiguous()
+    a = a.contiguous()
+    out = torch.empty((v.shape[0], a.shape[0]), dtype=torch.float64, device=v.device)
+    check(lib().avs_cdist_f64(_p(v), v.shape[0], _p(a), a.shape[0], v.shape[1], _p(out), _stream()), "avs_cdist_f64")
+    return out
+
+
+def dtw_path(cost):
+    if cost.dtype != torch.float64 or cost.dim() != 2 or not cost.is_contiguous():
+        raise ValueError("cost must be a contiguous float64 matrix")
+    n, m = cost.shape
+    ws_bytes = lib().avs_dtw_workspace_bytes(n, m)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=cost.device)
+    path = torch.empty((n + m - 1, 2), dtype=torch.int64, device=cost.device)
+    plen = torch.zeros(1, dtype=torch.int64, device=cost.device)
+    total = torch.zeros(1, dtype=torch.float64, device=cost.device)
+    check(lib().avs_dtw_path_f64(_p(cost), n, m, _p(ws), ws_bytes, _p(path), _p(plen), _p(total), _stream()),
+          "avs_dtw_path_f64")
+    return path, plen, total
+
+
+def gather_scale(x, idx, w):
+    _f32(x, "x")
+    _rowmajor2d(x, "x")
+    count = idx.numel()
+    d = x.shape[1]
+    out = torch.empty((count, d), dtype=torch.float32, device=x.device)
+    check(lib().avs_gather_scale_f32(_p(x), x.stride(0), d, _p(idx), _p(w), count, _p(out), _stream()),
+          "avs_gather_scale_f32")
+    return out

@@ -1,0 +1,238 @@
+/*
+ * avsum_hip.h — C-ABI of libavsum_hip.so, the MI355X (gfx950) hot path of the
+ * audio-visual frame-scoring pipeline.
+ *
+ * The reference (AudioVidSum) has no FFI layer: its boundary is the Python
+ * class/function API of features/extractors.py, features/fusion.py,
+ * models/attention.py and models/av_model.py.  This header is the thin C-ABI
+ * the Python host mirror of those classes calls (ctypes).  Every entry point
+ * names the reference lines it replaces.
+ *
+ * Conventions (all entry points):
+ *   - `extern "C"`, plain pointers and sizes; no torch / C++ types.
+ *   - returns int status: AVS_OK (0) or a negative AVS_E_* code; never throws.
+ *     avs_last_error() returns a thread-local message for the last failure.
+ *   - every pointer named d_* is DEVICE memory owned by the caller (the host
+ *     side passes torch tensor data_ptr()s); nothing is allocated or freed.
+ *   - asynchronous on the caller's `stream` (a hipStream_t cast to void*;
+ *     NULL = the null stream); no host synchronisation inside.
+ *   - tensors are dense row-major unless a stride is given; "NHWC" activations
+ *     are [image][row][pixel][channel].
+ *   - dtype: AVS_F32 = IEEE fp32 operands, fp32 accumulate on the f32 MFMA
+ *     (exact fmaf chain; the parity mode).  AVS_BF16 = bf16 operands, fp32
+ *     accumulate on the bf16 MFMA (the throughput mode).
+ */
+#ifndef AVSUM_HIP_H
+#define AVSUM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AVS_ABI_VERSION 1
+
+enum {
+  AVS_OK = 0,
+  AVS_E_ARG = -1,       /* null pointer / bad enum / negative size            */
+  AVS_E_SHAPE = -2,     /* sizes inconsistent with what the kernel assumes    */
+  AVS_E_ALIGN = -3,     /* pointer or stride not 16-byte aligned              */
+  AVS_E_HIP = -4,       /* the HIP runtime reported an error at launch        */
+  AVS_E_WORKSPACE = -5  /* workspace too small                                */
+};
+
+enum { AVS_F32 = 0, AVS_BF16 = 1 };
+enum { AVS_ACT_NONE = 0, AVS_ACT_RELU = 1 };
+enum { AVS_BIAS_NONE = 0, AVS_BIAS_COL = 1, AVS_BIAS_ROW = 2 };
+
+typedef void* avs_stream_t;
+
+/* ---- library ------------------------------------------------------------ */
+int avs_abi_version(void);
+const char* avs_last_error(void);
+/* CU count, max clock (kHz), total HBM bytes and gcnArchName of device `dev`. */
+int avs_device_info(int dev, int* cu_count, int* clock_khz, int64_t* hbm_bytes,
+                    char* arch, int arch_len);
+
+/* ---- dense contraction (K3, K6, K16-K20 of SURVEY §2.3) ------------------ */
+
+/* Implicit-GEMM 2-D convolution on NHWC activations, weights [cout][kh][kw][cin]:
+ *   y[n,ho,wo,co] = act( alpha * sum_{kh,kw,ci} x[n, ho*sh-ph+kh, wo*sw-pw+kw, ci]
+ *                                              * w[co,kh,kw,ci] + bias[co] )
+ * Replaces torch conv2d inside torchvision resnet50 / inception_v3 as called at
+ * features/extractors.py:65,83.  Element strides allow padded / sliced views
+ * (channel-concat outputs, pre-padded images).  cin must be a multiple of
+ * 16 bytes / element size; out-of-image taps read as zero.                  */
+typedef struct {
+  int dtype;                /* AVS_F32 | AVS_BF16 (x, w, y); bias is fp32     */
+  int n, h, w;              /* images, input rows, input pixels per row       */
+  int cin, kh, kw;          /* reduction extent                               */
+  int sh, sw, ph, pw;       /* stride, zero padding                           */
+  int ho, wo, cout;         /* output extent                                  */
+  int64_t x_img_stride;     /* elements between images                        */
+  int64_t x_row_stride;     /* elements between input rows                    */
+  int64_t x_px_stride;      /* elements between input pixels                  */
+  int64_t w_row_stride;     /* elements between output channels in w (>= kh*kw*cin) */
+  int64_t y_px_stride;      /* elements between output pixels (>= cout)       */
+  int act;                  /* AVS_ACT_*                                      */
+  float alpha;
+} avs_conv_desc;
+
+int avs_conv2d_nhwc(const avs_conv_desc* desc, const void* d_x, const void* d_w,
+                    const float* d_bias, void* d_y, avs_stream_t stream);
+
+/* Batched C[b] = act(alpha * A[b] . B[b]^T + bias):  A [M,K] (row stride lda),
+ * B [N,K] (row stride ldb; the nn.Linear weight layout), C [M,N] (ldc).
+ * Replaces nn.Linear (models/av_model.py:10-15,29-31; models/attention.py:8-11;
+ * features/extractors.py:193), the LSTM input projections (av_model.py:18-23),
+ * the in/out projections of nn.MultiheadAttention (av_model.py:26) and the two
+ * einsums of models/attention.py:21,23.  K, lda, ldb multiples of 16 bytes.  */
+int avs_gemm_nt(int dtype, int m, int n, int k,
+                const void* d_a, int64_t lda, int64_t stride_a,
+                const void* d_b, int64_t ldb, int64_t stride_b,
+                void* d_c, int64_t ldc, int64_t stride_c,
+                const float* d_bias, int bias_mode, int64_t stride_bias,
+                float alpha, int act, int batch, avs_stream_t stream);
+
+/* ---- visual front end (K1, K2, K4, K5, K7) ------------------------------ */
+
+/* uint8 HWC frames -> normalised, zero-padded NHWC images with 4 channels
+ * (4th = 0), in `dtype`:  out[n, pad_t+y, pad_l+x, c] = (src/denom - mean[c]) / std[c]
+ * (then the per-channel affine a[c]*v + b[c] when affine6 = {a0,a1,a2,b0,b1,b2}
+ * is given: torchvision inception_v3 transform_input).  Replaces _preprocess_frame
+ * (features/extractors.py:126-140; denom 1, i.e. NO /255) and the arithmetic of
+ * _preprocess_inception (:142-155; denom 255).  out is [n, out_h, out_w, 4].
+ * mean3 / std3 / affine6 are HOST pointers (copied into the launch).         */
+int avs_frames_normalize_u8(int dtype, const uint8_t* d_src, int n, int h, int w,
+                            float denom, const float* mean3, const float* std3,
+                            const float* affine6, void* d_out, int out_h, int out_w,
+                            int pad_t, int pad_l, avs_stream_t stream);
+
+/* OpenCV-style bilinear resize of uint8 HWC frames (cv2.resize INTER_LINEAR,
+ * fixed-point 11-bit coefficients): features/extractors.py:132,147.          */
+int avs_resize_bilinear_u8(const uint8_t* d_src, int n, int sh, int sw,
+                           uint8_t* d_dst, int dh, int dw, avs_stream_t stream);
+
+/* Batch-statistics BatchNorm2d, the mode the reference actually runs its
+ * ResNet-50 trunk in (features/extractors.py:29 never calls .eval()):
+ * statistics per (group, channel) over the rows of the group's frames, biased
+ * variance, eps.  d_group_rows[g]..d_group_rows[g+1] are the row ranges of the
+ * groups (a group = one micro-batch of <=4 frames, extractors.py:48-56).
+ * Writes the folded affine  scale[g,c] = gamma*rstd,  shift[g,c] = beta - mean*scale. */
+int avs_bn_batch_stats(int dtype, const void* d_x, int64_t rows, int c, int64_t ldx,
+                       const int64_t* d_group_rows, int groups,
+                       const float* d_gamma, const float* d_beta, float eps,
+                       float* d_scale, float* d_shift, avs_stream_t stream);
+
+/* y = act( x*scale[g] + shift[g] (+ residual) ), rows of group g as above;
+ * max_group_rows = the largest group's row count (sizes the launch).
+ * groups==0 with d_group_rows NULL: one affine for all rows (folded eval BN). */
+int avs_bn_apply(int dtype, const void* d_x, int64_t rows, int c, int64_t ldx,
+                 const int64_t* d_group_rows, int groups, int64_t max_group_rows,
+                 const float* d_scale, const float* d_shift,
+                 const void* d_residual, int64_t ldr, int act,
+                 void* d_y, int64_t ldy, avs_stream_t stream);
+
+/* 2-D pooling on NHWC.  mode 0 = max (padding = -inf), 1 = average with
+ * count_include_pad (torch defaults).  ResNet maxpool 3x3/2 p1, Inception
+ * max 3x3/2 p0 and avg 3x3/1 p1.  y may be a channel slice (y_px_stride).   */
+int avs_pool2d_nhwc(int dtype, int mode, const void* d_x, int n, int h, int w, int c,
+                    int64_t x_px_stride, int k, int s, int p, void* d_y, int ho, int wo,
+                    int64_t y_px_stride, avs_stream_t stream);
+
+/* Global average pool: y[n,c] = mean over h*w (fp32 out).  (adaptive avgpool) */
+int avs_global_avgpool_nhwc(int dtype, const void* d_x, int n, int hw, int c,
+                            float* d_y, int64_t ldy, avs_stream_t stream);
+
+/* Segment mean: out[s,:] = mean(x[seg[s]:seg[s+1], :]) summed in row order in
+ * fp32 then divided (numpy .mean(axis=0), extractors.py:108-110); empty
+ * segment -> zeros (extractors.py:44-45).                                   */
+int avs_segment_mean_f32(const float* d_x, int64_t ldx, int d, const int64_t* d_seg,
+                         int nseg, float* d_out, int64_t ldo, avs_stream_t stream);
+
+/* ---- audio front end (K8-K12) ------------------------------------------- */
+
+/* Reflect-pad a mono waveform by `pad` samples each side (torch.stft
+ * center=True, pad_mode="reflect"); out has t + 2*pad samples (+ tail zeroed
+ * up to out_len).                                                           */
+int avs_reflect_pad_f32(const float* d_x, int64_t t, int pad, float* d_out,
+                        int64_t out_len, avs_stream_t stream);
+
+/* Power spectrum -> mel filterbank -> log.  d_spec is [frames, 2*nbins]
+ * (re | im per frame, from avs_gemm_nt against the windowed DFT basis);
+ * d_fb is [nbins, nmel] (torchaudio melscale_fbanks layout).
+ *   mode 0: out = log2(mel + 1e-6)          (features/extractors.py:245)
+ *   mode 1: out = 10*log10(max(mel,1e-10)), and atomically folds the maximum
+ *           of max(mel,1e-10) into *d_max, which the caller zeroed
+ *           (AmplitudeToDB, first half)
+ *   mode 2: out = mel                                                        */
+int avs_power_mel_f32(const float* d_spec, int64_t frames, int nbins,
+                      const float* d_fb, const int* d_fb_lo, const int* d_fb_hi,
+                      int nmel, int mode, float* d_out, float* d_max,
+                      avs_stream_t stream);
+
+/* x = max(x, 10*log10(*d_max) - top_db) in place (AmplitudeToDB top_db clamp). */
+int avs_clamp_topdb_f32(float* d_x, int64_t count, const float* d_max, float top_db,
+                        avs_stream_t stream);
+int avs_fill_f32(float* d_x, int64_t count, float value, avs_stream_t stream);
+
+/* ---- importance scorer (K17-K19) ---------------------------------------- */
+
+/* Batched LSTM recurrences, PyTorch gate order i,f,g,o, h0=c0=0
+ * (nn.LSTM at models/av_model.py:18-23,39-40).
+ *   d_xproj [rows, ndir*4H]: x_t.W_ih^T + b_ih + b_hh for every direction
+ *           (direction d occupies columns d*4H..), rows = sum of seq lengths;
+ *   d_whh_t [ndir, H, 4H]: W_hh TRANSPOSED per direction;
+ *   d_seq_rows[s]..d_seq_rows[s+1]: the rows of sequence s;
+ *   reverse_mask bit d set = direction d runs t = T-1..0;
+ *   d_out [rows, ldo]: h_t of direction d at columns out_col0 + d*H.         */
+int avs_lstm_f32(const float* d_xproj, const float* d_whh_t, int hidden, int ndir,
+                 unsigned reverse_mask, const int64_t* d_seq_rows, int nseq,
+                 float* d_out, int64_t ldo, int out_col0, avs_stream_t stream);
+
+/* Attention core of nn.MultiheadAttention fed [B,T,E] WITHOUT batch_first
+ * (models/av_model.py:26,44): for every time-step t and head h,
+ * softmax over the B axis.  d_qkv [B*T, 3E] (q|k|v, already projected),
+ * d_ctx [B*T, E].  One wave per (t, head, b); wave-shuffle softmax.          */
+int avs_mha_batchaxis_f32(const float* d_qkv, int b, int t, int e, int heads,
+                          float* d_ctx, avs_stream_t stream);
+
+/* scores[r] = sigmoid( dot(hid[r,:], w2) + b2 )  (scorer.2 + Sigmoid,
+ * models/av_model.py:30).                                                    */
+int avs_score_head_f32(const float* d_hid, int64_t rows, int d, int64_t ldh,
+                       const float* d_w2, const float* d_b2, float* d_scores,
+                       avs_stream_t stream);
+
+/* Row softmax in place: x[r, 0:n] for `rows` rows of stride ldx
+ * (torch.softmax(dim=-1) at models/attention.py:22).                         */
+int avs_softmax_rows_f32(float* d_x, int64_t rows, int n, int64_t ldx,
+                         avs_stream_t stream);
+
+/* ---- fusion (K13-K15) --------------------------------------------------- */
+
+/* out[i,j] = sqrt(sum_d (double(v[i,d]) - double(a[j,d]))^2), float64 out
+ * (scipy cdist "euclidean" at features/fusion.py:11).                        */
+int avs_cdist_f64(const float* d_v, int tv, const float* d_a, int ta, int d,
+                  double* d_out, avs_stream_t stream);
+
+/* Exact DTW on a cost matrix [n,m] (features/fusion.py:15-18 intent; SURVEY
+ * A.9): D = C + min(up, left, diag) with tie order up, left, diag; path from
+ * (0,0) to (n-1,m-1) written as int64 pairs to d_path (capacity n+m-1 pairs),
+ * its length to *d_path_len, total cost to *d_cost.  The three live
+ * anti-diagonals stay in LDS (n <= 6400); the workspace holds one predecessor
+ * byte per cell.                                                            */
+int64_t avs_dtw_workspace_bytes(int n, int m);
+int avs_dtw_path_f64(const double* d_cost_matrix, int n, int m, void* d_workspace,
+                     int64_t workspace_bytes, int64_t* d_path, int64_t* d_path_len,
+                     double* d_cost, avs_stream_t stream);
+
+/* out[u,:] = x[idx[u],:] * float(w[u])  (features/fusion.py:28-32).          */
+int avs_gather_scale_f32(const float* d_x, int64_t ldx, int d, const int64_t* d_idx,
+                         const double* d_w, int count, float* d_out,
+                         avs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVSUM_HIP_H */
