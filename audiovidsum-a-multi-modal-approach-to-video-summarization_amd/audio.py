@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import ops
-from ._abi import BIAS_NONE
+from ._abi import AVS_F32_ACC64, BIAS_NONE
 
 N_FFT = 400
 HOP = 200
@@ -29,32 +29,35 @@ def _hz_to_mel(f):
 
 
 def mel_filterbank(sample_rate, n_mels, n_freqs=N_BINS, f_min=0.0, f_max=None):
-    """[n_freqs, n_mels] triangular HTK filters, norm=None (float64)."""
+    """[n_freqs, n_mels] triangular HTK filters, norm=None.  Evaluated in float32 tensor arithmetic in the
+    order torchaudio.functional.melscale_fbanks uses, because the reference's numbers ARE that float32
+    evaluation (a float64 evaluation differs by ~1e-5 in some weights and by one non-zero entry)."""
     f_max = float(sample_rate // 2) if f_max is None else f_max
-    all_freqs = np.linspace(0.0, sample_rate // 2, n_freqs)
-    m_pts = np.linspace(_hz_to_mel(f_min), _hz_to_mel(f_max), n_mels + 2)
-    f_pts = 700.0 * (10.0 ** (m_pts / 2595.0) - 1.0)
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+    m_pts = torch.linspace(_hz_to_mel(f_min), _hz_to_mel(f_max), n_mels + 2)
+    f_pts = 700.0 * (10 ** (m_pts / 2595.0) - 1.0)
     f_diff = f_pts[1:] - f_pts[:-1]
-    slopes = f_pts[None, :] - all_freqs[:, None]
-    down = -slopes[:, :-2] / f_diff[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    down = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
     up = slopes[:, 2:] / f_diff[1:]
-    return np.maximum(0.0, np.minimum(down, up))
+    return torch.max(torch.zeros(1), torch.min(down, up)).numpy()
 
 
 def dct_matrix(n_mfcc, n_mels):
-    """[n_mfcc, n_mels] DCT-II with ortho normalisation (rows = coefficients)."""
-    n = np.arange(n_mels, dtype=np.float64)
-    k = np.arange(n_mfcc, dtype=np.float64)[:, None]
-    d = np.cos(math.pi / n_mels * (n + 0.5) * k)
+    """[n_mfcc, n_mels] DCT-II with ortho normalisation (rows = coefficients), float32 as torchaudio.create_dct."""
+    n = torch.arange(float(n_mels))
+    k = torch.arange(float(n_mfcc)).unsqueeze(1)
+    d = torch.cos(math.pi / float(n_mels) * (n + 0.5) * k)
     d[0] *= 1.0 / math.sqrt(2.0)
-    d *= math.sqrt(2.0 / n_mels)
-    return d
+    d *= math.sqrt(2.0 / float(n_mels))
+    return d.numpy()
 
 
 def windowed_dft_basis():
     """[2*N_BINS, N_FFT]: rows 0..200 = w[n] cos(2 pi k n / N), rows 201..401 = -w[n] sin(...)."""
     n = np.arange(N_FFT)
-    window = 0.5 * (1.0 - np.cos(2.0 * math.pi * n / N_FFT))  # periodic Hann
+    # the float32 values of torch.hann_window(400) (periodic), which is the window the reference multiplies by
+    window = torch.hann_window(N_FFT).double().numpy()
     k = np.arange(N_BINS)[:, None]
     ang = 2.0 * math.pi * ((k * n[None, :]) % N_FFT) / N_FFT
     return np.concatenate([np.cos(ang) * window, -np.sin(ang) * window], 0)
@@ -98,7 +101,7 @@ class MelPlan:
         frames = self.num_frames(t)
         padded = ops.reflect_pad(wave.contiguous(), N_FFT // 2, t + N_FFT)
         spec = torch.empty((frames, 2 * N_BINS), dtype=torch.float32, device=wave.device)
-        ops.gemm_nt_batched(ops.dtype_code(torch.float32), frames, 2 * N_BINS, N_FFT, padded, 0, HOP, 0, self.basis, 0,
+        ops.gemm_nt_batched(AVS_F32_ACC64, frames, 2 * N_BINS, N_FFT, padded, 0, HOP, 0, self.basis, 0,
                             N_FFT, 0, spec, 0, 2 * N_BINS, 0, None, BIAS_NONE, 0, 1.0, ops.ACT_NONE, 1)
         return spec
 

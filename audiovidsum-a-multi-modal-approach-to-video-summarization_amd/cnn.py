@@ -137,7 +137,7 @@ class ResNet50Runner:
         return ops.bn_apply(raw2d, scale.view(1, -1), shift.view(1, -1), None, 0, residual, act,
                             raw2d if out is None else out)
 
-    def forward(self, frames_u8, group_frames=None):
+    def forward(self, frames_u8, group_frames=None, out=None):
         """frames_u8: device uint8 [N,224,224,3] (already 224x224, extractors.py:132).
         group_frames: int64 CPU tensor / list [G+1] of frame offsets of the BatchNorm micro-batch groups
         (extractors.py:48-56); default = one group per frame."""
@@ -161,7 +161,7 @@ class ResNet50Runner:
         x0 = ops.frames_normalize(frames_u8, dt, 1.0, RESNET_MEAN, RESNET_STD, 230, 232, 3, 3)
         c1 = torch.empty((n, 112, 112, 64), dtype=dt, device=dev)
         ops.conv2d_raw(ops.dtype_code(dt), n, 230, 112, 32, 7, 1, 2, 1, 0, 0, 112, 112, 64, x0, 230 * 232 * 4, 232 * 4,
-                       8, w["stem"], w["stem"].stride(0), c1, 64)
+                       8, w["stem"], w["stem"].stride(0), c1, 64, algo_k=147)
         del x0
         a1 = self._bn(c1.view(-1, 64), w["bn1"], groups, 112 * 112).view(n, 112, 112, 64)
         del c1
@@ -193,7 +193,7 @@ class ResNet50Runner:
             x = x.view(n, hout, hout, planes * 4)
             del t3, idn
             hcur = hout
-        return ops.global_avgpool(x)
+        return ops.global_avgpool(x, out)
 
 
 # ============================================================================ Inception-v3 container
@@ -430,7 +430,7 @@ class InceptionV3Runner:
         self._conv(w, p + ".branch_pool", self._pool(x, "avg", 3, 1, 1), op)
         return buf
 
-    def forward(self, frames_u8):
+    def forward(self, frames_u8, out=None):
         n, h, w_, _ = frames_u8.shape
         if (h, w_) != (299, 299):
             raise ValueError("InceptionV3Runner expects 299x299 frames (resize first)")
@@ -445,7 +445,7 @@ class InceptionV3Runner:
         c = w["Conv2d_1a_3x3"]
         x = torch.empty((n, 149, 149, 32), dtype=dt, device=dev)
         ops.conv2d_raw(ops.dtype_code(dt), n, 299, 149, 16, 3, 1, 2, 1, 0, 0, 149, 149, 32, x0, 299 * 300 * 4, 300 * 4, 8,
-                       c["w"], c["w"].stride(0), x, 32, c["b"], ops.ACT_RELU)
+                       c["w"], c["w"].stride(0), x, 32, c["b"], ops.ACT_RELU, algo_k=27)
         del x0
         x = self._conv(w, "Conv2d_2a_3x3", x)
         x = self._conv(w, "Conv2d_2b_3x3", x)
@@ -462,4 +462,4 @@ class InceptionV3Runner:
         x = self._block_d(w, "Mixed_7a", x)
         x = self._block_e(w, "Mixed_7b", x)
         x = self._block_e(w, "Mixed_7c", x)
-        return ops.global_avgpool(x)
+        return ops.global_avgpool(x, out)

@@ -37,8 +37,9 @@ struct IgemmParams {
   int tiles_n;
 };
 
-template <int ES, int BN>
+template <int ES, int BN, bool ACC64>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
+  static_assert(!ACC64 || (ES == 4 && BN == 64), "fp64 slice accumulation: fp32 operands, narrow tile only");
   constexpr int CE = 16 / ES;   // elements per 16-byte chunk
   constexpr int BKE = 64 / ES;  // elements per LDS row
   constexpr int NB = BN / 64;   // B rows staged per thread
@@ -154,6 +155,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  // ACC64: every 16-element reduction slice is an exact-fmaf MFMA chain in fp32; the slices are summed in
+  // fp64, so the rounding error scales with the size of a SLICE sum, not of the whole running sum.
+  double acc64[ACC64 ? 2 : 1][ACC64 ? NT : 1][ACC64 ? 16 : 1];
+  if constexpr (ACC64) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc64[i][j][e] = 0.0;
+  }
+
   const int steps = (p.K + BKE - 1) / BKE;
   gload();
   lwrite(0);
@@ -194,6 +207,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
           }
         }
     }
+    if constexpr (ACC64) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            acc64[i][j][e] += (double)acc[i][j][e];
+            acc[i][j][e] = 0.f;
+          }
+    }
     if (s + 1 < steps) lwrite(buf ^ 1);
     __syncthreads();
   }
@@ -212,7 +236,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
       for (int e = 0; e < 16; ++e) {
         const int row = m0 + wr * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         if (row >= p.M) continue;
-        float v = acc[mt][nt][e] * p.alpha + bcol;
+        float v;
+        if constexpr (ACC64)
+          v = (float)(acc64[mt][nt][e] * (double)p.alpha) + bcol;
+        else
+          v = acc[mt][nt][e] * p.alpha + bcol;
         if (p.bias_mode == AVS_BIAS_ROW) v += bias[row];
         if (p.act == AVS_ACT_RELU) v = fmaxf(v, 0.f);
         char* dst = y + ((long long)row * p.ldc + col) * ES;
@@ -227,7 +255,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream, const char* who) {
   const int es = dtype == AVS_BF16 ? 2 : 4;
   const int ce = 16 / es;
-  AVS_REQUIRE(dtype == AVS_F32 || dtype == AVS_BF16, AVS_E_ARG, "%s: bad dtype %d", who, dtype);
+  AVS_REQUIRE(dtype == AVS_F32 || dtype == AVS_BF16 || dtype == AVS_F32_ACC64, AVS_E_ARG, "%s: bad dtype %d", who,
+              dtype);
   AVS_REQUIRE(p.M >= 0 && p.N > 0 && p.K > 0 && batch > 0, AVS_E_SHAPE, "%s: bad sizes M=%d N=%d K=%d batch=%d", who,
               p.M, p.N, p.K, batch);
   if (p.M == 0) return AVS_OK;
@@ -242,7 +271,7 @@ static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream
   AVS_REQUIRE(p.ldc >= p.N, AVS_E_SHAPE, "%s: output row stride %lld < N=%d", who, p.ldc, p.N);
   AVS_REQUIRE(batch <= 65535, AVS_E_SHAPE, "%s: batch %d > 65535", who, batch);
 
-  const bool narrow = p.N <= 64;
+  const bool narrow = p.N <= 64 || dtype == AVS_F32_ACC64;
   const int bn = narrow ? 64 : 128;
   p.tiles_n = (p.N + bn - 1) / bn;
   const long long tiles_m = ((long long)p.M + 127) / 128;
@@ -251,14 +280,16 @@ static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream
   dim3 grid((unsigned)total, 1, (unsigned)batch), block(256);
   if (dtype == AVS_BF16) {
     if (narrow)
-      hipLaunchKernelGGL((igemm_kernel<2, 64>), grid, block, 0, stream, p);
+      hipLaunchKernelGGL((igemm_kernel<2, 64, false>), grid, block, 0, stream, p);
     else
-      hipLaunchKernelGGL((igemm_kernel<2, 128>), grid, block, 0, stream, p);
+      hipLaunchKernelGGL((igemm_kernel<2, 128, false>), grid, block, 0, stream, p);
+  } else if (dtype == AVS_F32_ACC64) {
+    hipLaunchKernelGGL((igemm_kernel<4, 64, true>), grid, block, 0, stream, p);
   } else {
     if (narrow)
-      hipLaunchKernelGGL((igemm_kernel<4, 64>), grid, block, 0, stream, p);
+      hipLaunchKernelGGL((igemm_kernel<4, 64, false>), grid, block, 0, stream, p);
     else
-      hipLaunchKernelGGL((igemm_kernel<4, 128>), grid, block, 0, stream, p);
+      hipLaunchKernelGGL((igemm_kernel<4, 128, false>), grid, block, 0, stream, p);
   }
   AVS_CHECK_LAUNCH(who);
   return AVS_OK;

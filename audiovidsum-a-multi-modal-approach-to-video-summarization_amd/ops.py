@@ -22,6 +22,44 @@ def _stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class LaunchProfiler:
+    """Optional per-launch HIP-event timing of the contraction kernel (bench.py's roofline leg):
+    events are recorded on the stream the kernel is launched on, read back after a synchronize."""
+
+    def __init__(self):
+        self.records = []  # (kind, dtype_code, algorithmic_flops, start_event, end_event)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for kind, dt, flops, s, e in self.records:
+            d = out.setdefault((kind, dt), {"launches": 0, "flops": 0.0, "ms": 0.0})
+            d["launches"] += 1
+            d["flops"] += flops
+            d["ms"] += s.elapsed_time(e)
+        return out
+
+
+_profiler = None
+
+
+def set_profiler(p):
+    global _profiler
+    _profiler = p
+
+
+def _timed(kind, dtype, flops, fn):
+    if _profiler is None:
+        return fn()
+    s = torch.cuda.Event(enable_timing=True)
+    e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    r = fn()
+    e.record()
+    _profiler.records.append((kind, dtype, float(flops), s, e))
+    return r
+
+
 def _p(t, offset_elems=0):
     if t is None:
         return None
@@ -57,8 +95,9 @@ def gemm_nt_batched(dtype, m, n, k, a, a_off, lda, sa, b, b_off, ldb, sb, c, c_o
                     bias_mode=BIAS_NONE, sbias=0, alpha=1.0, act=ACT_NONE, batch=1):
     """Raw strided-batched C = act(alpha * A.B^T + bias); offsets/strides in elements."""
     _dev(a, b, c, bias)
-    check(lib().avs_gemm_nt(dtype, m, n, k, _p(a, a_off), lda, sa, _p(b, b_off), ldb, sb, _p(c, c_off), ldc, sc,
-                            _p(bias), bias_mode, sbias, float(alpha), act, batch, _stream()), "avs_gemm_nt")
+    _timed("gemm", dtype, 2.0 * m * n * k * batch, lambda: check(
+        lib().avs_gemm_nt(dtype, m, n, k, _p(a, a_off), lda, sa, _p(b, b_off), ldb, sb, _p(c, c_off), ldc, sc,
+                          _p(bias), bias_mode, sbias, float(alpha), act, batch, _stream()), "avs_gemm_nt"))
 
 
 def linear(x, w, bias=None, act=ACT_NONE, out=None, alpha=1.0):
@@ -89,12 +128,15 @@ def linear(x, w, bias=None, act=ACT_NONE, out=None, alpha=1.0):
 
 
 def conv2d_raw(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x, x_img_stride, x_row_stride, x_px_stride,
-               wt, w_row_stride, y, y_px_stride, bias=None, act=ACT_NONE, alpha=1.0, x_off=0, y_off=0):
+               wt, w_row_stride, y, y_px_stride, bias=None, act=ACT_NONE, alpha=1.0, x_off=0, y_off=0, algo_k=None):
+    """algo_k: the algorithmic reduction length when it differs from kh*kw*cin (zero-padded stem rows)."""
     _dev(x, wt, y, bias)
     d = _abi.ConvDesc(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x_img_stride, x_row_stride,
                       x_px_stride, w_row_stride, y_px_stride, act, float(alpha))
-    check(lib().avs_conv2d_nhwc(ctypes.byref(d), _p(x, x_off), _p(wt), _p(bias), _p(y, y_off), _stream()),
-          "avs_conv2d_nhwc")
+    flops = 2.0 * n * ho * wo * cout * (algo_k if algo_k is not None else kh * kw * cin)
+    _timed("conv", dtype, flops, lambda: check(
+        lib().avs_conv2d_nhwc(ctypes.byref(d), _p(x, x_off), _p(wt), _p(bias), _p(y, y_off), _stream()),
+        "avs_conv2d_nhwc"))
 
 
 def conv2d(x, wt, kh, kw, stride, pad, out, bias=None, act=ACT_NONE):

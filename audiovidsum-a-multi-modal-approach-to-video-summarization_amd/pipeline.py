@@ -1,0 +1,74 @@
+"""Device-resident end-to-end path: frames -> CNN embeddings -> fused scorer -> per-frame scores -> selection.
+
+The reference does this in two stages with a .npy round-trip (scripts/preprocess.py:74-81 ->
+data/dataset.py:45-52 -> scripts/evaluate.py:12-15); here the whole batch of videos stays in HBM.
+Videos are independent (each is its own LSTM recurrence and its own B=1 attention call), so a
+batch of videos is rows concatenated + row offsets, and a multi-GPU run shards the list of videos.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .evaluation.metrics import select_frames
+
+
+class FrameScoringPipeline:
+    def __init__(self, visual_extractor, scorer, use_inception=True, chunk_frames=256, frames_per_group=1):
+        """visual_extractor: features.extractors.VisualFeatureExtractor (on the device);
+        scorer: models.av_model.AVBiLSTMModel (on the device, eval mode).
+        frames_per_group: BatchNorm micro-batch size inside one video (reference: 4 per shot; the
+        per-frame scoring mode embeds every frame as its own one-frame shot => 1)."""
+        self.visual = visual_extractor
+        self.scorer = scorer
+        self.use_inception = use_inception
+        self.chunk_frames = int(chunk_frames)
+        self.frames_per_group = int(frames_per_group)
+
+    def _group_offsets(self, video_offsets):
+        """BatchNorm groups never straddle a video: per video, groups of frames_per_group (+ remainder)."""
+        offs = [0]
+        for a, b in zip(video_offsets[:-1], video_offsets[1:]):
+            cur = a
+            while cur < b:
+                cur = min(cur + self.frames_per_group, b)
+                offs.append(cur)
+        return offs
+
+    def embed(self, frames_u8, video_offsets):
+        """uint8 [N,224,224,3] on device -> fp32 [N,4096] (ResNet-50 | Inception-v3 halves)."""
+        n = frames_u8.shape[0]
+        visual = torch.zeros((n, 4096), dtype=torch.float32, device=frames_u8.device)
+        groups = self._group_offsets(video_offsets)
+        gi = 0
+        while gi < len(groups) - 1:
+            start = groups[gi]
+            gj = gi + 1
+            while gj < len(groups) - 1 and groups[gj + 1] - start <= self.chunk_frames:
+                gj += 1
+            end = groups[gj]
+            chunk = frames_u8[start:end]
+            local = [g - start for g in groups[gi:gj + 1]]
+            self.visual._resnet_runner.forward(chunk, local, out=visual[start:end, :2048])
+            if self.use_inception:
+                big = ops.resize_bilinear(chunk, 299, 299)
+                self.visual._inception_runner.forward(big, out=visual[start:end, 2048:])
+            gi = gj
+        return visual
+
+    @torch.no_grad()
+    def score(self, frames_u8, video_offsets, audio_rows=None):
+        """Per-frame importance scores fp32 [N] for videos given as frame offsets [V+1]."""
+        video_offsets = [int(v) for v in video_offsets]
+        visual = self.embed(frames_u8, video_offsets)
+        if audio_rows is None:
+            # AudioFeatureExtractor.forward literally returns zeros(296)
+            audio_rows = torch.zeros((visual.shape[0], self.scorer.audio_fc[0].in_features), dtype=torch.float32,
+                                     device=visual.device)
+        seq = torch.tensor(video_offsets, dtype=torch.int64, device=visual.device)
+        return self.scorer.score_rows(visual, audio_rows, seq, attn_batch=1)
+
+    @staticmethod
+    def select(scores, video_offsets):
+        """Selection rule of scripts/evaluate.py:26 per video, on the host (bit-exact numpy)."""
+        host = scores.detach().cpu().numpy()
+        return [select_frames(host[a:b]) for a, b in zip(video_offsets[:-1], video_offsets[1:])]

@@ -20,7 +20,10 @@
  *     are [image][row][pixel][channel].
  *   - dtype: AVS_F32 = IEEE fp32 operands, fp32 accumulate on the f32 MFMA
  *     (exact fmaf chain; the parity mode).  AVS_BF16 = bf16 operands, fp32
- *     accumulate on the bf16 MFMA (the throughput mode).
+ *     accumulate on the bf16 MFMA (the throughput mode).  AVS_F32_ACC64
+ *     (avs_gemm_nt / avs_conv2d_nhwc only) = fp32 operands and fp32 MFMA over
+ *     each 16-element slice of the reduction, slices summed in fp64: used for
+ *     the STFT, where a long fp32 running sum would lose the quiet bins.
  */
 #ifndef AVSUM_HIP_H
 #define AVSUM_HIP_H
@@ -42,7 +45,7 @@ enum {
   AVS_E_WORKSPACE = -5  /* workspace too small                                */
 };
 
-enum { AVS_F32 = 0, AVS_BF16 = 1 };
+enum { AVS_F32 = 0, AVS_BF16 = 1, AVS_F32_ACC64 = 2 };
 enum { AVS_ACT_NONE = 0, AVS_ACT_RELU = 1 };
 enum { AVS_BIAS_NONE = 0, AVS_BIAS_COL = 1, AVS_BIAS_ROW = 2 };
 

@@ -1,0 +1,2 @@
+"""Alias package: `src.models.*` re-exports avsum_amd.models.* so that the reference's scripts, which import
+`models.*` and `src.models.*`, run unmodified against the MI355X implementation."""

@@ -1,0 +1,115 @@
+"""CPU-side checks: the C-ABI library loads and exports every declared symbol (no compute calls without a
+GPU), argument validation that happens before any launch, host logic of the mirrors."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_library_exports_every_declared_symbol():
+    from avsum_amd import _abi
+    names = _abi.declared_symbols()
+    assert len(names) >= 24 and "avs_conv2d_nhwc" in names and "avs_lstm_f32" in names
+    lib = _abi.lib()
+    for n in names:
+        assert hasattr(lib, n), n
+    assert set(names) == set(_abi._SIGNATURES)
+    assert lib.avs_abi_version() == 1
+    assert os.path.dirname(_abi.LIB_PATH).startswith(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def test_validation_before_launch_needs_no_gpu():
+    """Bad arguments are rejected with a status code + message before any HIP call."""
+    from avsum_amd import _abi
+    lib = _abi.lib()
+    st = lib.avs_gemm_nt(0, 8, 8, 6, None, 6, 0, None, 6, 0, None, 8, 0, None, 0, 0, 1.0, 0, 1, None)
+    assert st == -1 or st == -2
+    assert lib.avs_last_error()
+    st = lib.avs_gemm_nt(7, 8, 8, 8, None, 8, 0, None, 8, 0, None, 8, 0, None, 0, 0, 1.0, 0, 1, None)
+    assert st == -1 and b"dtype" in lib.avs_last_error()
+    assert lib.avs_dtw_workspace_bytes(10, 20) >= 200
+    assert lib.avs_lstm_f32(None, None, 0, 2, 0, None, 1, None, 0, 0, None) == -2
+    assert lib.avs_cdist_f64(None, 4, None, 4, 0, None, None) == -2
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from avsum_amd import _abi
+    monkeypatch.setattr(_abi, "_lib", None)
+    monkeypatch.setattr(_abi, "LIB_PATH", "/nonexistent/libavsum_hip.so")
+    with pytest.raises(_abi.AvsError, match="no CPU fallback"):
+        _abi.lib()
+
+
+def test_product_path_never_imports_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "audiovidsum-a-multi-modal-approach-to-video-summarization_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, os.path.join(dp, f)
+
+
+def test_host_tensors_are_rejected_not_computed_on_cpu():
+    from avsum_amd import ops
+    from avsum_amd.models.av_model import AVBiLSTMModel
+    with pytest.raises(ValueError, match="no CPU fallback"):
+        ops.linear(torch.zeros(4, 8), torch.zeros(4, 8))
+    m = AVBiLSTMModel(16, 8, 8).eval()
+    with pytest.raises(RuntimeError, match="HIP path only"):
+        m(torch.zeros(1, 3, 16), torch.zeros(1, 3, 8))
+
+
+def test_sampling_rule_and_selection():
+    from avsum_amd.features.extractors import sample_shot_indices
+    from avsum_amd.evaluation.metrics import binary_f1, segments_from_indices, select_frames
+    assert sample_shot_indices(0, 10) == [0, 3, 6, 9]
+    assert sample_shot_indices(4, 11) == [6, 9]          # ABSOLUTE index % 3 (extractors.py:406)
+    assert len(sample_shot_indices(0, 1000)) == 100      # max 100 frames (extractors.py:400,404)
+    assert sample_shot_indices(5, 5) == []
+    pred = np.array([0.1, 0.9, 0.8, 0.2, 0.7, 0.1], dtype=np.float32)
+    assert select_frames(pred).tolist() == [1, 2, 4]
+    assert segments_from_indices(select_frames(pred)) == [(1, 3), (4, 5)]
+    assert segments_from_indices(np.array([], dtype=np.int64)) == []
+    tgt = np.array([0, 1, 0, 0, 1, 1], dtype=np.float32)
+    p, r = 2 / 3, 2 / 3
+    assert binary_f1(pred, tgt) == 2 * (p * r) / (p + r + 1e-8)
+
+
+def test_extractor_containers_have_torchvision_keys():
+    from avsum_amd.cnn import Inception3, resnet50_trunk
+    t = resnet50_trunk()
+    keys = list(t.state_dict().keys())
+    assert keys[0] == "0.weight" and "4.0.downsample.0.weight" in keys and "7.2.bn3.running_var" in keys
+    assert sum(p.numel() for p in t.parameters()) == 23508032       # resnet50 minus fc
+    i = Inception3()
+    ik = i.state_dict().keys()
+    assert "Conv2d_1a_3x3.conv.weight" in ik and "Mixed_7c.branch_pool.bn.running_mean" in ik
+    assert "AuxLogits.conv0.conv.weight" in ik and not any(k.startswith("fc.") for k in ik)
+    assert sum(p.numel() for n, p in i.named_parameters() if not n.startswith("AuxLogits")) == 21785568
+    assert t.training and not i.training  # only the Inception net is put in eval mode
+
+
+def test_pipeline_group_offsets():
+    from avsum_amd.pipeline import FrameScoringPipeline
+    p = FrameScoringPipeline(None, None, frames_per_group=4)
+    assert p._group_offsets([0, 6, 6, 15]) == [0, 4, 6, 10, 14, 15]   # groups never straddle a video
+    p1 = FrameScoringPipeline(None, None, frames_per_group=1)
+    assert p1._group_offsets([0, 3]) == [0, 1, 2, 3]
+
+
+def test_audio_constants_match_oracle_formulas():
+    from avsum_amd.audio import dct_matrix, mel_filterbank, windowed_dft_basis
+    from oracle import audio as oa
+    fb = mel_filterbank(16000, 128)
+    assert np.array_equal(fb, oa.melscale_fbanks().numpy())
+    assert ((fb > 0).sum(), (fb.sum(0) == 0).sum(), (fb > 0).sum(1).max()) == (394, 4, 2)
+    d = dct_matrix(40, 128)
+    assert np.array_equal(d.T, oa.create_dct().numpy())
+    assert np.abs(d.astype(np.float64) @ d.T.astype(np.float64) - np.eye(40)).max() < 1e-5  # orthonormal rows
+    b = windowed_dft_basis()
+    assert b.shape == (402, 400)
+    w = torch.hann_window(400).double().numpy()
+    assert np.abs(b[0] - w).max() < 1e-12 and np.abs(b[201]).max() == 0  # k=0: cos=1, sin=0

@@ -1,0 +1,190 @@
+"""GPU parity of the host-side mirrors (reference API surface) against the oracle on seeded inputs."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _seeded_scorer(seed, spread=True, **kw):
+    from avsum_amd.models.av_model import AVBiLSTMModel
+    torch.manual_seed(seed)
+    m = AVBiLSTMModel(**kw).eval()
+    if spread:
+        # default init gives scores within ~0.01 of each other; widen the last layers so that
+        # the selection rule is exercised away from the decision boundary
+        with torch.no_grad():
+            m.scorer[0].weight.mul_(6.0)
+            m.scorer[2].weight.mul_(6.0)
+    return m
+
+
+def _guarded_equal_selection(got, ref, tol):
+    from oracle import selection
+    mean = np.mean(ref)
+    safe = np.abs(ref - mean) > 2 * tol
+    sel_ref = ref > mean
+    sel_got = got > np.mean(got)
+    assert np.array_equal(sel_ref[safe], sel_got[safe])
+    return int((~safe).sum()), selection.select_frames(ref)
+
+
+@pytest.mark.parametrize("b,t", [(1, 300), (1, 1), (2, 17), (3, 5)])
+def test_av_bilstm_full_dims(dev, b, t):
+    from oracle import scorer as osc
+    m = _seeded_scorer(7)
+    g = torch.Generator().manual_seed(100 + t)
+    visual = torch.randn(b, t, 4096, generator=g)
+    audio = torch.zeros(b, t, 296)  # the literal audio features are all-zero
+    ref = osc.av_bilstm_forward(m.state_dict(), visual, audio)
+    md = m.to(dev)
+    with torch.no_grad():
+        got = md(visual.to(dev), audio.to(dev)).cpu()
+    assert got.shape == ref.shape  # .squeeze() rules (av_model.py:46)
+    tol = 1e-4  # north_star: importance scores within 1e-4 fp32
+    assert (got - ref).abs().max().item() < tol
+    if b == 1 and t > 1:
+        dropped, _ = _guarded_equal_selection(got.numpy(), ref.numpy(), 2e-6)
+        assert dropped <= t // 10
+
+
+def test_av_bilstm_small_dims_random_audio(dev):
+    from oracle import scorer as osc
+    m = _seeded_scorer(3, visual_dim=64, audio_dim=24, hidden_dim=32)
+    g = torch.Generator().manual_seed(5)
+    v, a = torch.randn(2, 40, 64, generator=g), torch.randn(2, 40, 24, generator=g)
+    ref = osc.av_bilstm_forward(m.state_dict(), v, a)
+    with torch.no_grad():
+        got = m.to(dev)(v.to(dev), a.to(dev)).cpu()
+    assert (got - ref).abs().max().item() < 1e-5
+
+
+def test_av_bilstm_train_mode_fails_loudly(dev):
+    m = _seeded_scorer(1, visual_dim=64, audio_dim=24, hidden_dim=32).to(dev).train()
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(1, 4, 64, device=dev), torch.zeros(1, 4, 24, device=dev))
+    with pytest.raises(RuntimeError):
+        m.eval()(torch.zeros(1, 4, 64), torch.zeros(1, 4, 24))  # host tensors: no CPU fallback
+
+
+@pytest.mark.parametrize("e,h,b,t", [(1024, 4, 1, 300), (512, 8, 2, 77), (64, 4, 3, 1), (1024, 4, 1, 1801)])
+def test_mhsa(dev, e, h, b, t):
+    from avsum_amd.models.attention import MultiHeadSelfAttention
+    from oracle import scorer as osc
+    torch.manual_seed(11)
+    m = MultiHeadSelfAttention(e, h).eval()
+    x = torch.randn(b, t, e, generator=torch.Generator().manual_seed(t))
+    ref = osc.mhsa_forward(m.state_dict(), x, h)
+    with torch.no_grad():
+        got = m.to(dev)(x.to(dev)).cpu()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() < 1e-4
+
+
+def _frames(n, seed, h=224, w=224):
+    return np.random.default_rng(seed).integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+
+
+def test_resnet50_trunk_batchstat_fp32(dev):
+    """5 frames = micro-batches of 4 + 1 (extractors.py:48-56): train-mode BN statistics per micro-batch."""
+    from avsum_amd.cnn import ResNet50Runner, resnet50_trunk
+    from oracle import cnn as ocnn
+    torch.manual_seed(21)
+    trunk = resnet50_trunk()
+    frames = _frames(5, 1)
+    sd = trunk.state_dict()
+    with torch.no_grad():
+        x = torch.cat([ocnn.preprocess_frame(f) for f in frames])
+        ref = torch.cat([ocnn.resnet50_trunk_forward(sd, x[:4]), ocnn.resnet50_trunk_forward(sd, x[4:])])
+    runner = ResNet50Runner(trunk.to(dev), torch.float32, "batch")
+    got = runner.forward(torch.from_numpy(frames).to(dev), [0, 4, 5]).cpu()
+    assert got.shape == (5, 2048)
+    err = (got - ref).abs().max().item()
+    assert err < 1e-4 * max(1.0, ref.abs().max().item()), err
+
+
+def test_resnet50_bf16_close_to_fp32(dev):
+    from avsum_amd.cnn import ResNet50Runner, resnet50_trunk
+    torch.manual_seed(22)
+    trunk = resnet50_trunk().to(dev)
+    frames = torch.from_numpy(_frames(8, 2)).to(dev)
+    f32 = ResNet50Runner(trunk, torch.float32).forward(frames, [0, 4, 8]).cpu()
+    bf = ResNet50Runner(trunk, torch.bfloat16).forward(frames, [0, 4, 8]).cpu()
+    # bf16 activations through 53 batch-normalised layers of a RANDOM-weight network: the feature vectors
+    # stay strongly aligned but not close element-wise (measured ~0.11 relative L2)
+    rel = ((bf - f32).norm() / f32.norm()).item()
+    cos = torch.nn.functional.cosine_similarity(bf, f32, dim=1).min().item()
+    assert rel < 0.2 and cos > 0.98, (rel, cos)
+
+
+def test_inception_v3_fp32(dev):
+    from avsum_amd.cnn import Inception3, InceptionV3Runner
+    from oracle import cnn as ocnn
+    torch.manual_seed(23)
+    net = Inception3()
+    # non-trivial running stats so that the BN folding is exercised
+    g = torch.Generator().manual_seed(1)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+    frames = _frames(2, 3)
+    sd = net.state_dict()
+    with torch.no_grad():
+        ref = ocnn.inception_v3_forward(sd, torch.cat([ocnn.preprocess_inception(f) for f in frames]))
+    from avsum_amd import ops
+    big = ops.resize_bilinear(torch.from_numpy(frames).to(dev), 299, 299)
+    got = InceptionV3Runner(net.to(dev), torch.float32).forward(big).cpu()
+    err = (got - ref).abs().max().item()
+    assert err < 1e-4 * max(1.0, ref.abs().max().item()), err
+
+
+def test_visual_extractor_api(dev):
+    from avsum_amd.features.extractors import VisualFeatureExtractor
+    from oracle import cnn as ocnn
+    torch.manual_seed(31)
+    ext = VisualFeatureExtractor()
+    frames = list(_frames(6, 4))
+    ref = ocnn.visual_forward(ext.resnet.state_dict(), ext.inception.state_dict(), frames)
+    ext = ext.to(dev)
+    got = ext(frames)
+    assert got.dtype == np.float32 and got.shape == (4096,)
+    assert np.abs(got - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+    assert np.array_equal(ext([]), np.zeros(4096, np.float32))  # extractors.py:44-45
+    p = ext._preprocess_frame(frames[0])
+    assert p.shape == (1, 3, 224, 224) and torch.equal(p, ocnn.preprocess_frame(frames[0]))
+    pi = ext._preprocess_inception(frames[0])
+    assert pi.shape == (1, 3, 299, 299) and torch.equal(pi, ocnn.preprocess_inception(frames[0]))
+
+
+def test_audio_extractor_api(dev):
+    from avsum_amd.features.extractors import AudioFeatureExtractor
+    from oracle import audio as oa
+    torch.manual_seed(41)
+    ext = AudioFeatureExtractor()
+    t = np.arange(32000) / 16000.0
+    wave = (0.4 * np.sin(2 * np.pi * 300 * t) + 0.01 * np.random.default_rng(0).standard_normal(32000)).astype(np.float32)
+    lit = ext(wave)
+    assert lit.dtype == np.float64 and lit.shape == (296,) and not lit.any()  # literal zeros
+    assert ext(wave[:0]).dtype == np.float32
+    mel = ext._extract_mel(torch.from_numpy(wave))
+    assert mel.shape == (161, 128) and np.abs(mel - oa.extract_mel(torch.from_numpy(wave))).max() < 1e-4
+    mf = ext._extract_mfcc(torch.from_numpy(wave))
+    ref = oa.extract_mfcc(torch.from_numpy(wave), ext.mfcc_proj.weight.detach().cpu(), ext.mfcc_proj.bias.detach().cpu())
+    assert mf.shape == (161, 128) and np.abs(mf - ref).max() < 1e-4 * np.abs(ref).max()
+
+
+def test_fusion_api(dev):
+    from avsum_amd.features import fusion
+    from oracle import fusion as ofu
+    g = torch.Generator().manual_seed(2)
+    v, a = torch.randn(60, 512, generator=g), torch.randn(80, 512, generator=g)
+    c = fusion.compute_dtw(v, a)
+    assert c.dtype == np.float64 and np.abs(c - ofu.compute_dtw(v, a)).max() < 1e-12 * c.max()
+    path = fusion.compute_optimal_path(c)
+    assert np.array_equal(path, ofu.compute_optimal_path(ofu.compute_dtw(v, a)))
+    out = fusion.interpolate_features(v, path, 50)
+    assert torch.equal(out, ofu.interpolate_features(v, path, 50))
+    with pytest.raises(ValueError):
+        fusion.compute_dtw(v, torch.randn(5, 7))

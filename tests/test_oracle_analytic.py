@@ -1,0 +1,125 @@
+"""Analytic known-answer pins for the parts of the oracle whose reference arithmetic is third-party and
+absent (torchaudio, torchvision, cv2): PARITY UNPINNED against the libraries themselves, pinned here by
+closed-form facts."""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from oracle import audio as oa, cnn as ocnn
+
+
+def test_stft_single_bin_sine_and_parseval():
+    n = 16000
+    k0 = 11  # exactly on bin 11: f = 11 * 16000 / 400 = 440 Hz
+    t = torch.arange(n, dtype=torch.float32)
+    x = 0.5 * torch.sin(2 * math.pi * k0 * t / 400)
+    p = oa.power_spectrogram(x)
+    assert p.shape == (201, 81)  # 1 + T // 200 frames
+    mid = p[:, 10:70]
+    assert (mid.argmax(0) == k0).all()
+    # Hann-windowed on-bin tone: |X[k0]| = A * N / 4 (window sum N/2, times A/2)
+    assert torch.allclose(mid[k0], torch.full((60,), (0.5 * 400 / 4) ** 2), rtol=1e-4)
+    assert (mid[k0 + 3:].max() < 1e-3 * mid[k0].max())  # Hann leakage is confined to k0 +- 1
+    # Parseval on one interior frame: sum |X|^2 (two-sided) = N * sum (w x)^2
+    w = torch.hann_window(400)
+    fr = (x[1800:2200] * w).double()
+    two_sided = p[0, 10] + p[200, 10] + 2 * p[1:200, 10].sum()
+    assert abs(two_sided.item() - 400 * (fr ** 2).sum().item()) < 1e-3 * two_sided.item()
+    assert abs(oa.extract_mel(x) - oa.extract_mel_f64(x.numpy())).max() < 5e-3
+
+
+def test_mel_filterbank_and_dct_structure():
+    fb = oa.melscale_fbanks()
+    assert fb.shape == (201, 128)
+    assert int((fb.sum(0) == 0).sum()) == 4 and int((fb > 0).sum()) == 394 and int((fb > 0).sum(1).max()) == 2
+    d = oa.create_dct(40, 128)
+    assert d.shape == (128, 40)
+    assert torch.allclose(d.t() @ d, torch.eye(40), atol=1e-5)
+    assert abs(d[:, 0] - 1 / math.sqrt(128)).max() < 1e-6
+
+
+def test_mfcc_topdb_clamp_and_shapes():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(4000, generator=g) * 0.1
+    x[2000:] = 0  # silence => mel = 0 => -100 dB before the clamp
+    db = oa.amplitude_to_db_power(oa.mel_spectrogram(x))
+    assert abs((db.max() - db.min()).item() - 80.0) < 1e-4
+    m = oa.mfcc(x)
+    assert m.shape == (40, 21)
+    w, b = torch.randn(128, 40, generator=g), torch.randn(128, generator=g)
+    assert oa.extract_mfcc(x, w, b).shape == (21, 128)
+    assert oa.audio_forward_literal(np.ones(5)).dtype == np.float64 and not oa.audio_forward_literal(np.ones(5)).any()
+    assert oa.audio_forward_literal(np.ones(0)).dtype == np.float32
+
+
+def test_bn_batch_matches_torch_train_mode():
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(4, 8, 5, 5, generator=g) * 3 + 2
+    bn = nn.BatchNorm2d(8)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(8, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(8, generator=g))
+    bn.train()
+    with torch.no_grad():
+        ref = bn(x)
+    got = ocnn.bn_batch(x, bn.weight.detach(), bn.bias.detach())
+    assert (got - ref).abs().max().item() < 1e-5
+    y = ocnn.bn_batch(x, torch.ones(8), torch.zeros(8))
+    assert y.mean((0, 2, 3)).abs().max() < 1e-5 and (y.var((0, 2, 3), unbiased=False) - 1).abs().max() < 1e-3
+
+
+def test_resnet50_restatement_macs_and_shapes(monkeypatch):
+    from avsum_amd.cnn import resnet50_trunk
+    torch.manual_seed(0)
+    sd = resnet50_trunk().state_dict()
+    macs = []
+    real = F.conv2d
+
+    def counting(x, w, *a, **k):
+        y = real(x, w, *a, **k)
+        macs.append(y.numel() // y.shape[0] * w[0].numel())
+        return y
+
+    monkeypatch.setattr(ocnn.F, "conv2d", counting)
+    with torch.no_grad():
+        out = ocnn.resnet50_trunk_forward(sd, torch.randn(2, 3, 224, 224))
+    assert out.shape == (2, 2048)
+    assert len(macs) == 53
+    assert abs(sum(macs) / 1e6 - 4087.8) < 1.0  # 4 087.8 MMAC per frame
+    assert macs[0] == 118013952
+
+
+def test_inception_restatement_macs_and_shapes(monkeypatch):
+    from avsum_amd.cnn import Inception3
+    torch.manual_seed(0)
+    sd = Inception3().state_dict()
+    macs = []
+    real = F.conv2d
+
+    def counting(x, w, *a, **k):
+        y = real(x, w, *a, **k)
+        macs.append(y.numel() // y.shape[0] * w[0].numel())
+        return y
+
+    monkeypatch.setattr(ocnn.F, "conv2d", counting)
+    with torch.no_grad():
+        out = ocnn.inception_v3_forward(sd, torch.randn(1, 3, 299, 299))
+    assert out.shape == (1, 2048) and len(macs) == 94
+    assert abs(sum(macs) / 1e9 - 5.71) < 0.03  # SURVEY: 5.71 GMAC per frame
+    assert torch.isfinite(out).all() and out.abs().max() < 1e3
+
+
+def test_cv_resize_identity_and_constant():
+    img = np.random.default_rng(0).integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    assert np.array_equal(ocnn.cv_resize_linear_u8(img, 37, 53), img)
+    const = np.full((20, 30, 3), 137, np.uint8)
+    assert (ocnn.cv_resize_linear_u8(const, 299, 299) == 137).all()
+    ramp = np.tile(np.arange(0, 200, 2, dtype=np.uint8)[None, :, None], (10, 1, 3))
+    up = ocnn.cv_resize_linear_u8(ramp, 10, 200).astype(int)
+    assert (np.diff(up[0, :, 0]) >= 0).all() and up[0, 0, 0] == 0 and up[0, -1, 0] == 198
+    fr = ocnn.preprocess_frame(img)
+    assert fr.shape == (1, 3, 224, 224) and fr.max() > 100  # NOT divided by 255
+    assert ocnn.preprocess_inception(img).abs().max() < 3
