@@ -7,9 +7,10 @@ n_fft = win = 400, periodic Hann, hop 200, center/reflect, power 2, HTK mel
 scale 0..sr/2, norm None, DCT-II ortho, AmplitudeToDB('power', top_db=80)).
 
 Constants are built once per (sample_rate, device) in float64 and rounded to
-fp32; the Hann window is folded into the DFT basis so the STFT is one NT GEMM
-whose A rows are the overlapping frames of the reflect-padded waveform
-(row stride = hop).
+fp32 (filterbank, DCT) or kept in float64 (the windowed DFT basis); the Hann
+window is folded into the basis so the STFT is one dense contraction on the
+fp64 matrix cores whose rows are the overlapping frames of the reflect-padded
+waveform, read in place (row stride = hop).
 """
 import math
 
@@ -17,7 +18,6 @@ import numpy as np
 import torch
 
 from . import ops
-from ._abi import AVS_F32_ACC64, BIAS_NONE
 
 N_FFT = 400
 HOP = 200
@@ -70,7 +70,10 @@ class MelPlan:
 
     def __init__(self, sample_rate, n_mels, n_mfcc, device):
         self.sample_rate, self.n_mels, self.n_mfcc, self.device = sample_rate, n_mels, n_mfcc, device
-        self.basis = torch.from_numpy(windowed_dft_basis().astype(np.float32)).to(device)
+        basis = windowed_dft_basis()  # [402, 400] float64: fp32 window values x cos/sin evaluated in float64
+        bt = np.zeros((N_FFT, 448), dtype=np.float64)
+        bt[:, :2 * N_BINS] = basis.T
+        self.basis_t = torch.from_numpy(bt).to(device)
         fb = mel_filterbank(sample_rate, n_mels).astype(np.float32)
         nz = fb > 0
         lo = np.where(nz.any(0), nz.argmax(0), 0).astype(np.int32)
@@ -100,10 +103,7 @@ class MelPlan:
                                f"but got: padding ({N_FFT // 2}, {N_FFT // 2}) at dimension 1 of input [1, {t}]")
         frames = self.num_frames(t)
         padded = ops.reflect_pad(wave.contiguous(), N_FFT // 2, t + N_FFT)
-        spec = torch.empty((frames, 2 * N_BINS), dtype=torch.float32, device=wave.device)
-        ops.gemm_nt_batched(AVS_F32_ACC64, frames, 2 * N_BINS, N_FFT, padded, 0, HOP, 0, self.basis, 0,
-                            N_FFT, 0, spec, 0, 2 * N_BINS, 0, None, BIAS_NONE, 0, 1.0, ops.ACT_NONE, 1)
-        return spec
+        return ops.stft_f64(padded, frames, HOP, N_FFT, self.basis_t, 2 * N_BINS)
 
     def log2_mel(self, wave):
         """[frames, n_mels] = log2(mel + 1e-6)  (features/extractors.py:241-246)."""

@@ -1,7 +1,6 @@
-// Audio front-end kernels.  The 400-point real DFT of every STFT
-// frame is a contraction against the windowed DFT basis and runs on the fp32
-// MFMA through avs_gemm_nt (row stride = hop, so overlapping frames are read in
-// place); this file holds the bandwidth-bound tail: |X|^2 -> mel -> log.
+// Audio front-end kernels: reflect pad, the STFT as a dense real DFT on the
+// fp64 matrix cores (frames read in place, row stride = hop), and the bandwidth-bound tail
+// |X|^2 -> mel -> log / dB.
 #include "avs_internal.h"
 #include <math.h>
 
@@ -31,6 +30,72 @@ extern "C" int avs_reflect_pad_f32(const float* d_x, int64_t t, int pad, float* 
   hipLaunchKernelGGL(reflect_pad_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, d_x, (long long)t, pad,
                      d_out, (long long)out_len);
   AVS_CHECK_LAUNCH("avs_reflect_pad_f32");
+  return AVS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// STFT as a dense real DFT on the fp64 matrix cores (v_mfma_f64_16x16x4_f64).
+// Why fp64: log2(mel + 1e-6) is ill-conditioned in the rare bins whose |X|^2 is ~1e-4 of their
+// neighbours'; an fp32 accumulation (dense or FFT — torch.stft's included) is 1e-4..2e-3 off
+// there.  fp32 samples and the windowed basis are exact in fp64 and so are their products, so
+// the spectrum below is the correctly rounded value of the defining formula.
+// Frames are read in place from the reflect-padded waveform (row stride = hop).
+// Block = 4 waves = 64 frames x 64 basis columns; wave = 16 frames x 4 column tiles.
+// Lane l feeds A[row l&15][k l>>4] and B[k l>>4][col l&15]; result register j of a lane is
+// row (l>>4) + 4*j, column l&15.
+// ---------------------------------------------------------------------------
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void stft_f64_kernel(const float* __restrict__ xpad, long long frames, int hop,
+                                                       int nfft, const double* __restrict__ basis_t, int ncols,
+                                                       int ncols_pad, float* __restrict__ spec) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lr = lane & 15, lq = lane >> 4;
+  const long long r0 = (long long)blockIdx.x * 64 + wave * 16;
+  const int c0 = blockIdx.y * 64;
+  const long long fr = r0 + lr;
+  const bool row_ok = fr < frames;
+  const float* __restrict__ xrow = xpad + (row_ok ? fr : 0) * hop;
+  f64x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  for (int k0 = 0; k0 < nfft; k0 += 4) {
+    const int k = k0 + lq;
+    const double a = (row_ok && k < nfft) ? (double)xrow[k] : 0.0;
+    const double* __restrict__ brow = basis_t + (long long)(k < nfft ? k : 0) * ncols_pad + c0 + lr;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const double b = k < nfft ? brow[nt * 16] : 0.0;
+      acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[nt], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int col = c0 + nt * 16 + lr;
+    if (col >= ncols) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long row = r0 + lq + 4 * j;
+      if (row < frames) spec[row * ncols + col] = (float)acc[nt][j];
+    }
+  }
+}
+
+extern "C" int avs_stft_f64(const float* d_xpad, int64_t xpad_len, int64_t frames, int hop, int nfft,
+                            const double* d_basis_t, int ncols, int ncols_pad, float* d_spec, avs_stream_t stream) {
+  AVS_REQUIRE(frames >= 0 && hop > 0 && nfft > 0 && ncols > 0 && ncols_pad >= ncols && ncols_pad % 64 == 0,
+              AVS_E_SHAPE, "avs_stft_f64: frames=%lld hop=%d nfft=%d ncols=%d ncols_pad=%d", (long long)frames, hop,
+              nfft, ncols, ncols_pad);
+  if (frames == 0) return AVS_OK;
+  AVS_REQUIRE(d_xpad && d_basis_t && d_spec, AVS_E_ARG, "avs_stft_f64: null pointer");
+  AVS_REQUIRE((frames - 1) * hop + nfft <= xpad_len, AVS_E_SHAPE,
+              "avs_stft_f64: %lld frames of %d samples at hop %d overrun the %lld-sample waveform", (long long)frames,
+              nfft, hop, (long long)xpad_len);
+  const long long bx = avs_cdiv(frames, 64);
+  AVS_REQUIRE(bx < (1ll << 31), AVS_E_SHAPE, "avs_stft_f64: too many frames");
+  hipLaunchKernelGGL(stft_f64_kernel, dim3((unsigned)bx, ncols_pad / 64), dim3(256), 0, (hipStream_t)stream, d_xpad,
+                     (long long)frames, hop, nfft, d_basis_t, ncols, ncols_pad, d_spec);
+  AVS_CHECK_LAUNCH("avs_stft_f64");
   return AVS_OK;
 }
 

@@ -12,7 +12,7 @@ from ._abi import ACT_NONE, ACT_RELU, AVS_BF16, AVS_F32, BIAS_COL, BIAS_NONE, BI
 
 __all__ = [
     "ACT_NONE", "ACT_RELU", "linear", "gemm_nt_batched", "conv2d", "conv2d_raw", "frames_normalize", "resize_bilinear",
-    "bn_batch_stats", "bn_apply", "pool2d", "global_avgpool", "segment_mean", "reflect_pad", "power_mel",
+    "bn_batch_stats", "bn_apply", "pool2d", "global_avgpool", "segment_mean", "reflect_pad", "stft_f64", "power_mel",
     "clamp_topdb", "fill", "lstm", "mha_batchaxis", "score_head", "softmax_rows", "cdist", "dtw_path",
     "gather_scale", "dtype_code",
 ]
@@ -256,6 +256,17 @@ def reflect_pad(x, pad, out_len):
     out = torch.empty(out_len, dtype=torch.float32, device=x.device)
     check(lib().avs_reflect_pad_f32(_p(x), x.numel(), pad, _p(out), out_len, _stream()), "avs_reflect_pad_f32")
     return out
+
+
+def stft_f64(xpad, frames, hop, nfft, basis_t, ncols):
+    """xpad fp32 [L]; basis_t float64 [nfft, ncols_pad]; returns fp32 [frames, ncols]."""
+    _f32(xpad, "xpad")
+    if basis_t.dtype != torch.float64 or not basis_t.is_contiguous() or basis_t.shape[0] != nfft:
+        raise ValueError("basis_t must be contiguous float64 [nfft, ncols_pad]")
+    spec = torch.empty((frames, ncols), dtype=torch.float32, device=xpad.device)
+    check(lib().avs_stft_f64(_p(xpad), xpad.numel(), frames, hop, nfft, _p(basis_t), ncols, basis_t.shape[1], _p(spec),
+                             _stream()), "avs_stft_f64")
+    return spec
 
 
 def power_mel(spec, nbins, fb, fb_lo, fb_hi, mode, gmax=None):

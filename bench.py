@@ -36,6 +36,14 @@ MFMA_F32_PEAK_TFLOPS = 157.3
 RESNET50_FLOP_PER_FRAME = 2 * 4.0878e9
 
 
+T_START = time.perf_counter()
+
+
+def log(msg):
+    """Progress on stderr (stdout carries exactly one JSON line)."""
+    print(f"[bench {time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def video_lengths(num_videos, mean, std, lo, hi, seed):
     g = torch.Generator().manual_seed(seed)
     ln = (torch.randn(num_videos, generator=g) * std + mean).round().clamp(lo, hi).long()
@@ -55,7 +63,10 @@ def make_frames(total, device, seed):
 def cpu_baseline(trunk_sd, scorer_sd, sample_frames, use_inception, inception_sd):
     """Oracle leg: the CPU restatement (oracle/) of the same per-frame path on a bounded sample."""
     from oracle import cnn as ocnn, scorer as osc
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # the GPU box grants a CPU share of 16 cores per GPU; asking torch for every visible core (256 on the host)
+    # oversubscribes that share and is ~1000x slower
+    visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(16, visible)
     torch.set_num_threads(cores)
     rng = np.random.default_rng(7)
     frames = rng.integers(0, 256, (sample_frames, 224, 224, 3), dtype=np.uint8)
@@ -86,7 +97,7 @@ def main():
     ap.add_argument("--mean-frames", type=int, default=1800)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--extractor", default="resnet50", choices=["resnet50", "resnet50+inception3"])
-    ap.add_argument("--chunk", type=int, default=256)
+    ap.add_argument("--chunk", type=int, default=1024)
     ap.add_argument("--cpu-sample", type=int, default=48, help="frames for the CPU baseline (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
@@ -126,7 +137,10 @@ def main():
     for ln in lengths:
         offsets.append(offsets[-1] + ln)
     total = offsets[-1]
+    log(f"rank {rank}: {args.videos} videos, {total} frames; generating frames in HBM")
     frames = make_frames(total, dev, 1000 + rank)
+    torch.cuda.synchronize()
+    log("frames ready")
     pipe = FrameScoringPipeline(extractor, scorer, use_inception=use_inception, chunk_frames=args.chunk,
                                 frames_per_group=1)
 
@@ -141,16 +155,19 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         step()
+        torch.cuda.synchronize()
+        log(f"warmup step {i} done")
     prof = None
     if not args.no_profile:
         prof = ops.LaunchProfiler()
         ops.set_profiler(prof)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         selected = step()
+        log(f"timed step {i} issued")
     barrier()
     elapsed = time.perf_counter() - t0
     ops.set_profiler(None)
@@ -180,6 +197,7 @@ def main():
                             "conv_share_of_step": round(conv["ms"] * 1e-3 / elapsed, 3)}
         cpu = None
         if sd_cpu is not None:
+            log(f"timed region {elapsed:.2f}s; CPU baseline on {args.cpu_sample} frames")
             cpu = cpu_baseline(sd_cpu[0], sd_cpu[1], args.cpu_sample, use_inception, sd_cpu[2])
         out = {
             "metric": "frames/sec end-to-end (extract+fuse+score), 224x224 + 16kHz",

@@ -162,6 +162,15 @@ int avs_segment_mean_f32(const float* d_x, int64_t ldx, int d, const int64_t* d_
 int avs_reflect_pad_f32(const float* d_x, int64_t t, int pad, float* d_out,
                         int64_t out_len, avs_stream_t stream);
 
+/* STFT of a (reflect-padded) waveform as a dense real DFT on the fp64 matrix cores:
+ *   spec[f, c] = float( sum_n double(xpad[f*hop + n]) * basis_t[n, c] ),  f < frames, c < ncols
+ * basis_t is [nfft, ncols_pad] float64 (window folded in; columns = re | im bins, zero padded to a
+ * multiple of 64).  Replaces torch.stft inside torchaudio Spectrogram (features/extractors.py:237,242).
+ * fp64 because log2(mel+1e-6) is ill-conditioned in quiet bins.            */
+int avs_stft_f64(const float* d_xpad, int64_t xpad_len, int64_t frames, int hop, int nfft,
+                 const double* d_basis_t, int ncols, int ncols_pad, float* d_spec,
+                 avs_stream_t stream);
+
 /* Power spectrum -> mel filterbank -> log.  d_spec is [frames, 2*nbins]
  * (re | im per frame, from avs_gemm_nt against the windowed DFT basis);
  * d_fb is [nbins, nmel] (torchaudio melscale_fbanks layout).

@@ -74,7 +74,7 @@ def extract_mel_f64(wave, sample_rate=16000, n_mels=128):
     frames = 1 + len(x) // HOP
     fr = np.stack([xp[HOP * f:HOP * f + N_FFT] for f in range(frames)])
     n = np.arange(N_FFT)
-    win = 0.5 * (1.0 - np.cos(2.0 * np.pi * n / N_FFT))
+    win = torch.hann_window(N_FFT).double().numpy()  # the float32 window values ARE the algorithm's constants
     ang = 2.0 * np.pi * ((np.arange(N_BINS)[:, None] * n[None, :]) % N_FFT) / N_FFT
     re = (fr * win) @ np.cos(ang).T
     im = (fr * win) @ np.sin(ang).T

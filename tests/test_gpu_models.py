@@ -169,7 +169,11 @@ def test_audio_extractor_api(dev):
     assert lit.dtype == np.float64 and lit.shape == (296,) and not lit.any()  # literal zeros
     assert ext(wave[:0]).dtype == np.float32
     mel = ext._extract_mel(torch.from_numpy(wave))
-    assert mel.shape == (161, 128) and np.abs(mel - oa.extract_mel(torch.from_numpy(wave))).max() < 1e-4
+    assert mel.shape == (161, 128) and mel.dtype == np.float32
+    truth = oa.extract_mel_f64(wave)
+    ref32 = oa.extract_mel(torch.from_numpy(wave))
+    assert np.abs(mel - truth).max() < 1e-4  # vs the float64 value of the reference's formula
+    assert np.abs(mel - ref32).max() <= np.abs(ref32 - truth).max() + 1e-4  # vs the fp32 CPU reference
     mf = ext._extract_mfcc(torch.from_numpy(wave))
     ref = oa.extract_mfcc(torch.from_numpy(wave), ext.mfcc_proj.weight.detach().cpu(), ext.mfcc_proj.bias.detach().cpu())
     assert mf.shape == (161, 128) and np.abs(mf - ref).max() < 1e-4 * np.abs(ref).max()
