@@ -5,21 +5,37 @@
 // tensor, so a 1x1/stride-1 convolution, an nn.Linear and a strided-batched
 // GEMM are the same code with different address parameters.
 //
-// Tile: 128 x BN outputs per 256-thread workgroup (4 waves as 2 x 2), 64 BYTES
-// of reduction per LDS row and step (16 fp32 / 32 bf16), two LDS buffers with a
-// register-staged prefetch (global loads of step s+1 are in flight while step s
-// is on the matrix cores).  An LDS row is four 16-byte chunks, XOR-swizzled by
-// (row >> 2) & 3 so that the ds_read_b128 fragment reads are conflict-free.
+// Tile: 128 x BN outputs per 256-thread workgroup (4 waves as 2 x 2); 128 BYTES
+// of reduction per LDS row and step (32 fp32 / 64 bf16), so both dtypes share
+// the loads, the LDS image and the swizzle.
+//
+// Staging is LDS-DMA: every thread issues global_load_lds_dwordx4 (16 bytes,
+// per-lane SOURCE address, wave-linear LDS destination) for 4 A chunks and
+// BN/32 B chunks per step into the buffer that is not being read; nothing
+// passes through VGPRs and there is no ds_write.  Taps that fall into the
+// zero padding, rows past M/N and the K tail read a 16-byte zero word instead.
+// An LDS row is eight 16-byte slots; chunk q of row r lives in slot
+// q ^ ((r >> 1) & 7): the DMA image is linear, the permutation is applied to
+// the SOURCE chunk each thread fetches and again when fragments are read, so
+// the ds_read_b128 fragment reads of 16 different rows are conflict-free.
 //
 //   bf16: v_mfma_f32_32x32x16_bf16 — lane (r = l & 31, h = l >> 5) feeds the
-//         8 bf16 of chunk 2*ks + h.
-//   fp32: v_mfma_f32_32x32x2_f32 x 4 — the same 16-byte chunk holds 4 floats,
-//         used as four K=2 steps; the k order inside a tile is permuted
-//         identically for A and B, which only reorders an exact-fmaf sum.
+//         8 bf16 of chunk 2*ks + h, ks = 0..3.
+//   fp32: v_mfma_f32_32x32x2_f32 x 4 per chunk — the 4 floats of a chunk are
+//         four K=2 steps; the k order inside a tile is permuted identically
+//         for A and B, which only reorders an exact-fmaf sum.
+//
+// bf16 results leave through LDS (the tile is re-read row-major and stored as
+// 16-byte runs); fp32 results are stored from the accumulators (lanes 0..31 of
+// one register are 32 consecutive channels = 128 bytes).
+// With SPATIAL = false (1x1 kernels without padding, linears, GEMMs) the
+// per-tap bounds tests compile away.
 #include "avs_internal.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __attribute__((aligned(16))) unsigned int avs_zero16[4];
 
 struct IgemmParams {
   const char* x;
@@ -37,16 +53,22 @@ struct IgemmParams {
   int tiles_n;
 };
 
-template <int ES, int BN, bool ACC64>
+#define AVS_GLDS16(src, dst)                                                                        \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),            \
+                                   (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+
+template <int ES, int BN, bool ACC64, bool SPATIAL>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   static_assert(!ACC64 || (ES == 4 && BN == 64), "fp64 slice accumulation: fp32 operands, narrow tile only");
-  constexpr int CE = 16 / ES;   // elements per 16-byte chunk
-  constexpr int BKE = 64 / ES;  // elements per LDS row
-  constexpr int NB = BN / 64;   // B rows staged per thread
-  constexpr int NT = BN / 64;   // 32-wide column tiles per wave
+  constexpr int CE = 16 / ES;    // elements per 16-byte chunk
+  constexpr int BKE = 128 / ES;  // elements per LDS row (one reduction step)
+  constexpr int NA = 4;          // A rows staged per thread (128 rows / 32)
+  constexpr int NB = BN / 32;    // B rows staged per thread
+  constexpr int NT = BN / 64;    // 32-wide column tiles per wave
   constexpr int A_ROWS = 128;
+  constexpr int BUF = (A_ROWS + BN) * 8;  // uint4 slots per buffer
 
-  __shared__ uint4 lds[2][(A_ROWS + BN) * 4];
+  __shared__ uint4 lds[2 * BUF];
 
   // XCD-aware, bijective block remap: blocks that share an XCD (orig % 8)
   // take consecutive tiles, so neighbouring column tiles reuse A rows in L2.
@@ -63,62 +85,65 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   const char* __restrict__ w = p.w + z * p.sB * ES;
   char* __restrict__ y = p.y + z * p.sC * ES;
   const float* __restrict__ bias = p.bias ? p.bias + z * p.sBias : nullptr;
+  const char* zsrc = reinterpret_cast<const char*>(avs_zero16);
 
   const int t = threadIdx.x;
-  const int c = t & 3;
-  const int r = t >> 2;
+  const int wave = t >> 6, lane = t & 63;
+  const int c = t & 7;
+  const int rb = t >> 3;                  // 0..31
+  const int cq = c ^ ((rb >> 1) & 7);     // the k-chunk this thread fetches into slot c
 
-  long long a_off[2];
-  int hi0[2], wi0[2];
+  // ---- per-thread row bases (rows rb + 32*i of the A tile, and of the B tile) ----
+  const char* a_base[NA];
+  int hi0[NA], wi0[NA];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = m0 + r + 64 * i;
+  for (int i = 0; i < NA; ++i) {
+    const int m = m0 + rb + 32 * i;
     if (m < p.M) {
       const int n = m / p.HoWo;
       const int rem = m - n * p.HoWo;
       const int ho = rem / p.Wo;
       const int wo = rem - ho * p.Wo;
-      a_off[i] = (long long)n * p.x_img_stride;
       hi0[i] = ho * p.sh - p.ph;
       wi0[i] = wo * p.sw - p.pw;
+      a_base[i] = x + ((long long)n * p.x_img_stride + (long long)hi0[i] * p.x_row_stride +
+                       (long long)wi0[i] * p.x_px_stride) * ES;
     } else {
-      a_off[i] = 0;
       hi0[i] = -(1 << 29);
       wi0[i] = 0;
+      a_base[i] = nullptr;  // never dereferenced: marks the row invalid
     }
   }
-  long long b_off[NB];
+  const char* b_base[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
-    const int n = n0 + r + 64 * i;
-    b_off[i] = n < p.N ? (long long)n * p.ldb : -1;
+    const int n = n0 + rb + 32 * i;
+    b_base[i] = n < p.N ? w + (long long)n * p.ldb * ES : nullptr;
   }
 
-  int kc = c * CE;
+  int kc = cq * CE;
   int kk = kc / p.cin;
   int ci = kc - kk * p.cin;
   int kh = kk / p.KW;
   int kw = kk - kh * p.KW;
 
-  uint4 va[2], vb[NB];
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
-
-  auto gload = [&]() {
+  auto stage = [&](int buf) {
+    uint4* abuf = lds + buf * BUF + wave * 64;        // wave-uniform; lane l lands at +l
+    uint4* bbuf = abuf + A_ROWS * 8;
     const bool kval = kc < p.K;
+    const long long koff = ((long long)kh * p.x_row_stride + (long long)kw * p.x_px_stride + ci) * ES;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int hi = hi0[i] + kh, wi = wi0[i] + kw;
-      const bool ok = kval && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-      va[i] = zero4;
-      if (ok)
-        va[i] = *reinterpret_cast<const uint4*>(
-            x + (a_off[i] + hi * p.x_row_stride + wi * p.x_px_stride + ci) * ES);
+    for (int i = 0; i < NA; ++i) {
+      bool ok = kval && a_base[i] != nullptr;
+      if constexpr (SPATIAL)
+        ok = ok && (unsigned)(hi0[i] + kh) < (unsigned)p.H && (unsigned)(wi0[i] + kw) < (unsigned)p.W;
+      const char* src = ok ? a_base[i] + koff : zsrc;
+      AVS_GLDS16(src, abuf + 256 * i);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      vb[i] = zero4;
-      if (kval && b_off[i] >= 0)
-        vb[i] = *reinterpret_cast<const uint4*>(w + (b_off[i] + kc) * ES);
+      const char* src = (kval && b_base[i] != nullptr) ? b_base[i] + (long long)kc * ES : zsrc;
+      AVS_GLDS16(src, bbuf + 256 * i);
     }
     kc += BKE;
     ci += BKE;
@@ -130,20 +155,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
       }
     }
   };
-  auto lwrite = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = r + 64 * i;
-      lds[buf][row * 4 + (c ^ ((row >> 2) & 3))] = va[i];
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int row = r + 64 * i;
-      lds[buf][(A_ROWS + row) * 4 + (c ^ ((row >> 2) & 3))] = vb[i];
-    }
-  };
 
-  const int wave = t >> 6, lane = t & 63;
   const int wr = wave >> 1, wc = wave & 1;
   const int lr = lane & 31, lh = lane >> 5;
 
@@ -155,8 +167,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  // ACC64: every 16-element reduction slice is an exact-fmaf MFMA chain in fp32; the slices are summed in
-  // fp64, so the rounding error scales with the size of a SLICE sum, not of the whole running sum.
+  // ACC64: every reduction step (32 fp32 elements) is an exact-fmaf MFMA chain in fp32; the steps are summed
+  // in fp64, so the rounding error scales with the size of a STEP sum, not of the whole running sum.
   double acc64[ACC64 ? 2 : 1][ACC64 ? NT : 1][ACC64 ? 16 : 1];
   if constexpr (ACC64) {
 #pragma unroll
@@ -168,45 +180,53 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   }
 
   const int steps = (p.K + BKE - 1) / BKE;
-  gload();
-  lwrite(0);
-  __syncthreads();
+  stage(0);
+  __syncthreads();  // drains the DMA (vmcnt) and makes every wave's part of the tile visible
 
   for (int s = 0; s < steps; ++s) {
     const int buf = s & 1;
-    if (s + 1 < steps) gload();
+    const uint4* abuf = lds + buf * BUF;
+    const uint4* bbuf = abuf + A_ROWS * 8;
+    // 1. all fragments of this step into registers (the compiler orders every LDS read behind the
+    //    outstanding LDS-DMA, so the reads must come BEFORE the next tile's DMA is issued)
+    uint4 fa[4][2], fb[4][NT];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < 4; ++ks) {
       const int chunk = 2 * ks + lh;
-      uint4 fa[2], fb[NT];
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         const int row = wr * 64 + mt * 32 + lr;
-        fa[mt] = lds[buf][row * 4 + (chunk ^ ((row >> 2) & 3))];
+        fa[ks][mt] = abuf[row * 8 + (chunk ^ ((row >> 1) & 7))];
       }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int row = wc * (BN / 2) + nt * 32 + lr;
-        fb[nt] = lds[buf][(A_ROWS + row) * 4 + (chunk ^ ((row >> 2) & 3))];
+        fb[ks][nt] = bbuf[row * 8 + (chunk ^ ((row >> 1) & 7))];
       }
+    }
+    // 2. DMA of the next tile into the other buffer: every wave finished reading it before the barrier
+    //    that ended the previous step.  It is in flight during the MFMAs below.
+    if (s + 1 < steps) stage(buf ^ 1);
+    // 3. matrix cores
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           if constexpr (ES == 2) {
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                __builtin_bit_cast(bf16x8, fa[mt]), __builtin_bit_cast(bf16x8, fb[nt]),
+                __builtin_bit_cast(bf16x8, fa[ks][mt]), __builtin_bit_cast(bf16x8, fb[ks][nt]),
                 acc[mt][nt], 0, 0, 0);
           } else {
-            const float4 a4 = __builtin_bit_cast(float4, fa[mt]);
-            const float4 b4 = __builtin_bit_cast(float4, fb[nt]);
+            const float4 a4 = __builtin_bit_cast(float4, fa[ks][mt]);
+            const float4 b4 = __builtin_bit_cast(float4, fb[ks][nt]);
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[mt][nt], 0, 0, 0);
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[mt][nt], 0, 0, 0);
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[mt][nt], 0, 0, 0);
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[mt][nt], 0, 0, 0);
           }
         }
-    }
     if constexpr (ACC64) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -218,38 +238,81 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
             acc[i][j][e] = 0.f;
           }
     }
-    if (s + 1 < steps) lwrite(buf ^ 1);
+    // keep the MFMAs ahead of the wait: without this the scheduler hoists the barrier (and its vmcnt(0))
+    // above them and the DMA latency is no longer covered by the matrix work of this step
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
   }
 
-  // Epilogue straight from the accumulators: register e of a 32x32 tile is
-  // row (e&3) + 8*(e>>2) + 4*lh, column lr — lanes 0..31 of one register store
-  // 32 consecutive output channels of one row.
+  // ---- epilogue ----
+  // Register e of a 32x32 tile is row (e&3) + 8*(e>>2) + 4*lh, column lr.
+  if constexpr (ES == 2) {
+    // bf16: through LDS, then 16-byte row-major stores.  Row pitch BN*2 + 16 bytes.
+    constexpr int PITCH = BN * 2 + 16;
+    char* ct = reinterpret_cast<char*>(lds);
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int col = n0 + wc * (BN / 2) + nt * 32 + lr;
-      if (col >= p.N) continue;
-      const float bcol = (p.bias_mode == AVS_BIAS_COL) ? bias[col] : 0.f;
+      for (int nt = 0; nt < NT; ++nt) {
+        const int lcol = wc * (BN / 2) + nt * 32 + lr;
+        const int col = n0 + lcol;
+        const float bcol = (p.bias_mode == AVS_BIAS_COL && col < p.N) ? bias[col] : 0.f;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = m0 + wr * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        if (row >= p.M) continue;
-        float v;
-        if constexpr (ACC64)
-          v = (float)(acc64[mt][nt][e] * (double)p.alpha) + bcol;
-        else
-          v = acc[mt][nt][e] * p.alpha + bcol;
-        if (p.bias_mode == AVS_BIAS_ROW) v += bias[row];
-        if (p.act == AVS_ACT_RELU) v = fmaxf(v, 0.f);
-        char* dst = y + ((long long)row * p.ldc + col) * ES;
-        if constexpr (ES == 2)
-          *reinterpret_cast<unsigned short*>(dst) = avs_f32_to_bf16(v);
-        else
-          *reinterpret_cast<float*>(dst) = v;
+        for (int e = 0; e < 16; ++e) {
+          const int lrow = wr * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          float v = acc[mt][nt][e] * p.alpha + bcol;
+          if (p.bias_mode == AVS_BIAS_ROW && m0 + lrow < p.M) v += bias[m0 + lrow];
+          if (p.act == AVS_ACT_RELU) v = fmaxf(v, 0.f);
+          *reinterpret_cast<unsigned short*>(ct + lrow * PITCH + lcol * 2) = avs_f32_to_bf16(v);
+        }
+      }
+    __syncthreads();
+    constexpr int CPRW = BN / 8;  // 16-byte chunks per tile row
+    const bool vec_ok = ((p.ldc * 2) % 16 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) && (n0 % 8 == 0);
+    for (int idx = t; idx < A_ROWS * CPRW; idx += 256) {
+      const int lrow = idx / CPRW, ch = idx - lrow * CPRW;
+      const int row = m0 + lrow, col = n0 + ch * 8;
+      if (row >= p.M || col >= p.N) continue;
+      const char* srcp = ct + lrow * PITCH + ch * 16;
+      char* dst = y + ((long long)row * p.ldc + col) * 2;
+      if (vec_ok && col + 8 <= p.N) {
+        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(srcp);
+      } else {
+        for (int j = 0; j < 8 && col + j < p.N; ++j)
+          reinterpret_cast<unsigned short*>(dst)[j] = reinterpret_cast<const unsigned short*>(srcp)[j];
       }
     }
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int col = n0 + wc * (BN / 2) + nt * 32 + lr;
+        if (col >= p.N) continue;
+        const float bcol = (p.bias_mode == AVS_BIAS_COL) ? bias[col] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = m0 + wr * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          if (row >= p.M) continue;
+          float v;
+          if constexpr (ACC64)
+            v = (float)(acc64[mt][nt][e] * (double)p.alpha) + bcol;
+          else
+            v = acc[mt][nt][e] * p.alpha + bcol;
+          if (p.bias_mode == AVS_BIAS_ROW) v += bias[row];
+          if (p.act == AVS_ACT_RELU) v = fmaxf(v, 0.f);
+          *reinterpret_cast<float*>(y + ((long long)row * p.ldc + col) * 4) = v;
+        }
+      }
+  }
+}
+
+template <int ES, int BN, bool ACC64>
+static void igemm_dispatch(bool spatial, dim3 grid, hipStream_t stream, const IgemmParams& p) {
+  if (spatial)
+    hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, true>), grid, dim3(256), 0, stream, p);
+  else
+    hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, false>), grid, dim3(256), 0, stream, p);
 }
 
 static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream, const char* who) {
@@ -277,19 +340,22 @@ static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream
   const long long tiles_m = ((long long)p.M + 127) / 128;
   const long long total = tiles_m * p.tiles_n;
   AVS_REQUIRE(total < (1ll << 31), AVS_E_SHAPE, "%s: too many tiles", who);
-  dim3 grid((unsigned)total, 1, (unsigned)batch), block(256);
+  // the per-tap bounds tests are only needed when a tap can leave the image
+  const bool spatial = !(p.ph == 0 && p.pw == 0 && (p.HoWo / p.Wo - 1) * p.sh + (p.K / (p.cin * p.KW)) - 1 < p.H &&
+                         (p.Wo - 1) * p.sw + p.KW - 1 < p.W);
+  dim3 grid((unsigned)total, 1, (unsigned)batch);
   if (dtype == AVS_BF16) {
     if (narrow)
-      hipLaunchKernelGGL((igemm_kernel<2, 64, false>), grid, block, 0, stream, p);
+      igemm_dispatch<2, 64, false>(spatial, grid, stream, p);
     else
-      hipLaunchKernelGGL((igemm_kernel<2, 128, false>), grid, block, 0, stream, p);
+      igemm_dispatch<2, 128, false>(spatial, grid, stream, p);
   } else if (dtype == AVS_F32_ACC64) {
-    hipLaunchKernelGGL((igemm_kernel<4, 64, true>), grid, block, 0, stream, p);
+    igemm_dispatch<4, 64, true>(spatial, grid, stream, p);
   } else {
     if (narrow)
-      hipLaunchKernelGGL((igemm_kernel<4, 64, false>), grid, block, 0, stream, p);
+      igemm_dispatch<4, 64, false>(spatial, grid, stream, p);
     else
-      hipLaunchKernelGGL((igemm_kernel<4, 128, false>), grid, block, 0, stream, p);
+      igemm_dispatch<4, 128, false>(spatial, grid, stream, p);
   }
   AVS_CHECK_LAUNCH(who);
   return AVS_OK;
