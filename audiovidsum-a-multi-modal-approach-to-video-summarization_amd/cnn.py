@@ -125,17 +125,31 @@ class ResNet50Runner:
         self._w, self._key = w, key
         return w
 
-    def _bn(self, raw2d, bnp, groups, hw, residual=None, relu=True, out=None):
+    def _conv_bn(self, conv, c, bnp, groups, hw, residual=None, relu=True):
+        """Convolution `conv(bnstats) -> raw NHWC output` followed by BatchNorm (+residual, +ReLU), in place.
+        Batch-statistics mode with equal-sized groups takes the statistics from the convolution's epilogue;
+        ragged groups (a shot whose frame count is not a multiple of 4) use the separate statistics pass."""
         gamma, beta, eps, rmean, rvar = bnp
         act = ops.ACT_RELU if relu else ops.ACT_NONE
         if self.bn_mode == "batch":
-            grows, gmax = groups[hw]
-            scale, shift = ops.bn_batch_stats(raw2d, grows, gamma, beta, eps)
-            return ops.bn_apply(raw2d, scale, shift, grows, gmax, residual, act, raw2d if out is None else out)
+            grows, gmax, uniform = groups[hw]
+            # the epilogue statistics are E[x^2]-E[x]^2 sums added with float atomics: fine for bf16 activations,
+            # not for the fp32 parity mode (which keeps the shifted, deterministic statistics pass)
+            if uniform and self.dtype == torch.bfloat16:
+                raw, (scale, shift) = conv((gmax, gamma, beta, eps))
+                raw2d = raw.view(-1, c)
+            else:
+                raw, _ = conv(None)
+                raw2d = raw.view(-1, c)
+                scale, shift = ops.bn_batch_stats(raw2d, grows, gamma, beta, eps)
+            ops.bn_apply(raw2d, scale, shift, grows, gmax, residual, act, raw2d)
+            return raw
+        raw, _ = conv(None)
+        raw2d = raw.view(-1, c)
         scale = (gamma / torch.sqrt(rvar + eps)).contiguous()
         shift = (beta - rmean * scale).contiguous()
-        return ops.bn_apply(raw2d, scale.view(1, -1), shift.view(1, -1), None, 0, residual, act,
-                            raw2d if out is None else out)
+        ops.bn_apply(raw2d, scale.view(1, -1), shift.view(1, -1), None, 0, residual, act, raw2d)
+        return raw
 
     def forward(self, frames_u8, group_frames=None, out=None):
         """frames_u8: device uint8 [N,224,224,3] (already 224x224, extractors.py:132).
@@ -153,18 +167,32 @@ class ResNet50Runner:
         group_frames = torch.as_tensor(group_frames, dtype=torch.int64)
         if int(group_frames[0]) != 0 or int(group_frames[-1]) != n:
             raise ValueError("group_frames must start at 0 and end at N")
-        gsz = int((group_frames[1:] - group_frames[:-1]).max())
-        groups = {hw: ((group_frames * hw).to(dev), gsz * hw) for hw in (112 * 112, 56 * 56, 28 * 28, 14 * 14, 7 * 7)}
+        sizes = group_frames[1:] - group_frames[:-1]
+        gsz = int(sizes.max())
+        uniform = bool((sizes == gsz).all())
+        groups = {hw: ((group_frames * hw).to(dev), gsz * hw, uniform)
+                  for hw in (112 * 112, 56 * 56, 28 * 28, 14 * 14, 7 * 7)}
+        dcode = ops.dtype_code(dt)
+
+        def conv_op(x, wt, k, s, p, cout, hout):
+            def run(bnstats):
+                y = torch.empty((n, hout, hout, cout), dtype=dt, device=dev)
+                r = ops.conv2d(x, wt, k, k, s, p, y, bnstats=bnstats)
+                return y, (r if bnstats is not None else None)
+            return run
 
         # stem: (x - mean)/std without /255 (extractors.py:133-139), zero padded by 3 (conv1 pad) into
         # [N,230,232,4]; conv1 7x7/2 reads 8-pixel (32-element) runs: kh=7 rows x 32 elements.
         x0 = ops.frames_normalize(frames_u8, dt, 1.0, RESNET_MEAN, RESNET_STD, 230, 232, 3, 3)
-        c1 = torch.empty((n, 112, 112, 64), dtype=dt, device=dev)
-        ops.conv2d_raw(ops.dtype_code(dt), n, 230, 112, 32, 7, 1, 2, 1, 0, 0, 112, 112, 64, x0, 230 * 232 * 4, 232 * 4,
-                       8, w["stem"], w["stem"].stride(0), c1, 64, algo_k=147)
+
+        def stem(bnstats):
+            y = torch.empty((n, 112, 112, 64), dtype=dt, device=dev)
+            r = ops.conv2d_raw(dcode, n, 230, 112, 32, 7, 1, 2, 1, 0, 0, 112, 112, 64, x0, 230 * 232 * 4, 232 * 4, 8,
+                               w["stem"], w["stem"].stride(0), y, 64, algo_k=147, bnstats=bnstats)
+            return y, r
+
+        a1 = self._conv_bn(stem, 64, w["bn1"], groups, 112 * 112)
         del x0
-        a1 = self._bn(c1.view(-1, 64), w["bn1"], groups, 112 * 112).view(n, 112, 112, 64)
-        del c1
         x = torch.empty((n, 56, 56, 64), dtype=dt, device=dev)
         ops.pool2d(a1, "max", 3, 2, 1, x)
         del a1
@@ -173,25 +201,17 @@ class ResNet50Runner:
             s, planes = blk["stride"], blk["planes"]
             cin = x.shape[3]
             hout = hcur // s
-            t1 = torch.empty((n, hcur, hcur, planes), dtype=dt, device=dev)
-            ops.conv2d(x, blk["c1"], 1, 1, 1, 0, t1)
-            t1 = self._bn(t1.view(-1, planes), blk["b1"], groups, hcur * hcur).view(n, hcur, hcur, planes)
-            t2 = torch.empty((n, hout, hout, planes), dtype=dt, device=dev)
-            ops.conv2d(t1, blk["c2"], 3, 3, s, 1, t2)
+            t1 = self._conv_bn(conv_op(x, blk["c1"], 1, 1, 0, planes, hcur), planes, blk["b1"], groups, hcur * hcur)
+            t2 = self._conv_bn(conv_op(t1, blk["c2"], 3, s, 1, planes, hout), planes, blk["b2"], groups, hout * hout)
             del t1
-            t2 = self._bn(t2.view(-1, planes), blk["b2"], groups, hout * hout).view(n, hout, hout, planes)
-            t3 = torch.empty((n, hout, hout, planes * 4), dtype=dt, device=dev)
-            ops.conv2d(t2, blk["c3"], 1, 1, 1, 0, t3)
-            del t2
             if "cd" in blk:
-                idn = torch.empty((n, hout, hout, planes * 4), dtype=dt, device=dev)
-                ops.conv2d(x, blk["cd"], 1, 1, s, 0, idn)
-                idn = self._bn(idn.view(-1, planes * 4), blk["bd"], groups, hout * hout, relu=False)
+                idn = self._conv_bn(conv_op(x, blk["cd"], 1, s, 0, planes * 4, hout), planes * 4, blk["bd"], groups,
+                                    hout * hout, relu=False).view(-1, planes * 4)
             else:
                 idn = x.view(-1, cin)
-            x = self._bn(t3.view(-1, planes * 4), blk["b3"], groups, hout * hout, residual=idn, relu=True)
-            x = x.view(n, hout, hout, planes * 4)
-            del t3, idn
+            x = self._conv_bn(conv_op(t2, blk["c3"], 1, 1, 0, planes * 4, hout), planes * 4, blk["b3"], groups,
+                              hout * hout, residual=idn, relu=True)
+            del t2, idn
             hcur = hout
         return ops.global_avgpool(x, out)
 

@@ -51,6 +51,11 @@ struct IgemmParams {
   float alpha;
   int act, bias_mode;
   int tiles_n;
+  // optional fused BatchNorm batch statistics: per (row / rows_per_group, column) sum and sum of squares of
+  // the values as stored, accumulated with float atomics
+  float* stat_sum;
+  float* stat_sq;
+  int rows_per_group;
 };
 
 #define AVS_GLDS16(src, dst)                                                                        \
@@ -246,6 +251,42 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 
   // ---- epilogue ----
   // Register e of a 32x32 tile is row (e&3) + 8*(e>>2) + 4*lh, column lr.
+  if (p.stat_sum != nullptr) {
+    // Fused batch statistics (no bias / activation on this path).  A lane owns one column of each 32-wide
+    // tile: it sums its 2 x 16 rows per group, the two lane halves are folded by one shuffle, and lanes
+    // 0..31 issue one atomic pair per (group, column).  Rows past M hold exact zeros and add nothing.
+    const int r_first = m0 + wr * 64;
+    if (r_first < p.M) {
+      const int r_last = (r_first + 63 < p.M ? r_first + 63 : p.M - 1);
+      const int g0 = r_first / p.rows_per_group, g1 = r_last / p.rows_per_group;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int col = n0 + wc * (BN / 2) + nt * 32 + lr;
+        for (int g = g0; g <= g1; ++g) {
+          const int lo = g * p.rows_per_group, hi = lo + p.rows_per_group;
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int row = r_first + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+              float v = acc[mt][nt][e] * p.alpha;
+              if constexpr (ES == 2) v = avs_bf16_to_f32(avs_f32_to_bf16(v));
+              const bool in = (g0 == g1) || (row >= lo && row < hi);
+              v = in ? v : 0.f;
+              s1 += v;
+              s2 = fmaf(v, v, s2);
+            }
+          s1 += __shfl_xor(s1, 32, 64);
+          s2 += __shfl_xor(s2, 32, 64);
+          if (lh == 0 && col < p.N) {
+            atomicAdd(p.stat_sum + (long long)g * p.N + col, s1);
+            atomicAdd(p.stat_sq + (long long)g * p.N + col, s2);
+          }
+        }
+      }
+    }
+  }
   if constexpr (ES == 2) {
     // bf16: through LDS, then 16-byte row-major stores.  Row pitch BN*2 + 16 bytes.
     constexpr int PITCH = BN * 2 + 16;
@@ -361,20 +402,18 @@ static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream
   return AVS_OK;
 }
 
-extern "C" int avs_conv2d_nhwc(const avs_conv_desc* d, const void* d_x, const void* d_w, const float* d_bias,
-                               void* d_y, avs_stream_t stream) {
-  AVS_REQUIRE(d != nullptr, AVS_E_ARG, "avs_conv2d_nhwc: null descriptor");
+static int conv_fill_params(const avs_conv_desc* d, const void* d_x, const void* d_w, const float* d_bias, void* d_y,
+                            IgemmParams& p, const char* who) {
+  AVS_REQUIRE(d != nullptr, AVS_E_ARG, "%s: null descriptor", who);
   AVS_REQUIRE(d->n >= 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->kh > 0 && d->kw > 0 && d->sh > 0 && d->sw > 0 &&
                   d->ph >= 0 && d->pw >= 0 && d->ho > 0 && d->wo > 0 && d->cout > 0,
-              AVS_E_SHAPE, "avs_conv2d_nhwc: non-positive extent");
+              AVS_E_SHAPE, "%s: non-positive extent", who);
   // every output tap row/pixel must stay inside the padded input
   AVS_REQUIRE((d->ho - 1) * d->sh - d->ph + d->kh - 1 < d->h + d->ph &&
                   (d->wo - 1) * d->sw - d->pw + d->kw - 1 < d->w + d->pw,
-              AVS_E_SHAPE, "avs_conv2d_nhwc: output extent %dx%d exceeds what input %dx%d allows", d->ho, d->wo, d->h,
-              d->w);
+              AVS_E_SHAPE, "%s: output extent %dx%d exceeds what input %dx%d allows", who, d->ho, d->wo, d->h, d->w);
   const long long rows = (long long)d->n * d->ho * d->wo;
-  AVS_REQUIRE(rows < (1ll << 31), AVS_E_SHAPE, "avs_conv2d_nhwc: %lld output pixels exceed int32", rows);
-  IgemmParams p{};
+  AVS_REQUIRE(rows < (1ll << 31), AVS_E_SHAPE, "%s: %lld output pixels exceed int32", who, rows);
   p.x = (const char*)d_x;
   p.w = (const char*)d_w;
   p.y = (char*)d_y;
@@ -400,8 +439,69 @@ extern "C" int avs_conv2d_nhwc(const avs_conv_desc* d, const void* d_x, const vo
   p.alpha = d->alpha;
   p.act = d->act;
   p.bias_mode = d_bias ? AVS_BIAS_COL : AVS_BIAS_NONE;
-  AVS_REQUIRE(p.ldb >= p.K, AVS_E_SHAPE, "avs_conv2d_nhwc: w_row_stride %lld < kh*kw*cin=%d", p.ldb, p.K);
+  AVS_REQUIRE(p.ldb >= p.K, AVS_E_SHAPE, "%s: w_row_stride %lld < kh*kw*cin=%d", who, p.ldb, p.K);
+  return AVS_OK;
+}
+
+extern "C" int avs_conv2d_nhwc(const avs_conv_desc* d, const void* d_x, const void* d_w, const float* d_bias,
+                               void* d_y, avs_stream_t stream) {
+  IgemmParams p{};
+  int st = conv_fill_params(d, d_x, d_w, d_bias, d_y, p, "avs_conv2d_nhwc");
+  if (st != AVS_OK) return st;
   return igemm_launch(d->dtype, p, 1, (hipStream_t)stream, "avs_conv2d_nhwc");
+}
+
+extern "C" int avs_conv2d_nhwc_bnstats(const avs_conv_desc* d, const void* d_x, const void* d_w, void* d_y,
+                                       int64_t rows_per_group, float* d_sum, float* d_sumsq, avs_stream_t stream) {
+  IgemmParams p{};
+  int st = conv_fill_params(d, d_x, d_w, nullptr, d_y, p, "avs_conv2d_nhwc_bnstats");
+  if (st != AVS_OK) return st;
+  AVS_REQUIRE(d->act == AVS_ACT_NONE, AVS_E_ARG, "avs_conv2d_nhwc_bnstats: activation must be none");
+  AVS_REQUIRE(rows_per_group > 0 && rows_per_group < (1ll << 31) && d_sum && d_sumsq, AVS_E_ARG,
+              "avs_conv2d_nhwc_bnstats: bad statistics arguments");
+  if (p.M == 0) return AVS_OK;
+  const long long groups = ((long long)p.M + rows_per_group - 1) / rows_per_group;
+  hipError_t e = hipMemsetAsync(d_sum, 0, sizeof(float) * groups * p.N, (hipStream_t)stream);
+  if (e == hipSuccess) e = hipMemsetAsync(d_sumsq, 0, sizeof(float) * groups * p.N, (hipStream_t)stream);
+  if (e != hipSuccess) {
+    avs_set_error("avs_conv2d_nhwc_bnstats: memset failed: %s", hipGetErrorString(e));
+    return AVS_E_HIP;
+  }
+  p.stat_sum = d_sum;
+  p.stat_sq = d_sumsq;
+  p.rows_per_group = (int)rows_per_group;
+  return igemm_launch(d->dtype, p, 1, (hipStream_t)stream, "avs_conv2d_nhwc_bnstats");
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sq,
+                                                          long long total, int c, float inv_n,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps,
+                                                          float* __restrict__ scale, float* __restrict__ shift) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % c);
+    const float mean = sum[i] * inv_n;
+    const float var = fmaxf(sq[i] * inv_n - mean * mean, 0.f);
+    const float sc = gamma[ch] / sqrtf(var + eps);
+    scale[i] = sc;
+    shift[i] = beta[ch] - mean * sc;
+  }
+}
+
+extern "C" int avs_bn_finalize(const float* d_sum, const float* d_sumsq, int groups, int c, int64_t rows_per_group,
+                               const float* d_gamma, const float* d_beta, float eps, float* d_scale, float* d_shift,
+                               avs_stream_t stream) {
+  AVS_REQUIRE(groups >= 0 && c > 0 && rows_per_group > 0, AVS_E_SHAPE, "avs_bn_finalize: bad extents");
+  if (groups == 0) return AVS_OK;
+  AVS_REQUIRE(d_sum && d_sumsq && d_gamma && d_beta && d_scale && d_shift, AVS_E_ARG, "avs_bn_finalize: null pointer");
+  const long long total = (long long)groups * c;
+  long long gx = avs_cdiv(total, 256);
+  if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, d_sum, d_sumsq, total,
+                     c, 1.f / (float)rows_per_group, d_gamma, d_beta, eps, d_scale, d_shift);
+  AVS_CHECK_LAUNCH("avs_bn_finalize");
+  return AVS_OK;
 }
 
 extern "C" int avs_gemm_nt(int dtype, int m, int n, int k, const void* d_a, int64_t lda, int64_t stride_a,

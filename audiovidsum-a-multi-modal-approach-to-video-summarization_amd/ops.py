@@ -128,20 +128,41 @@ def linear(x, w, bias=None, act=ACT_NONE, out=None, alpha=1.0):
 
 
 def conv2d_raw(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x, x_img_stride, x_row_stride, x_px_stride,
-               wt, w_row_stride, y, y_px_stride, bias=None, act=ACT_NONE, alpha=1.0, x_off=0, y_off=0, algo_k=None):
-    """algo_k: the algorithmic reduction length when it differs from kh*kw*cin (zero-padded stem rows)."""
+               wt, w_row_stride, y, y_px_stride, bias=None, act=ACT_NONE, alpha=1.0, x_off=0, y_off=0, algo_k=None,
+               bnstats=None):
+    """algo_k: the algorithmic reduction length when it differs from kh*kw*cin (zero-padded stem rows).
+    bnstats = (rows_per_group, gamma, beta, eps): accumulate the BatchNorm batch statistics of equal-sized row
+    groups in the kernel's epilogue (no bias / activation) and return the folded (scale, shift) [G, cout]."""
     _dev(x, wt, y, bias)
     d = _abi.ConvDesc(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x_img_stride, x_row_stride,
                       x_px_stride, w_row_stride, y_px_stride, act, float(alpha))
     flops = 2.0 * n * ho * wo * cout * (algo_k if algo_k is not None else kh * kw * cin)
+    if bnstats is None:
+        _timed("conv", dtype, flops, lambda: check(
+            lib().avs_conv2d_nhwc(ctypes.byref(d), _p(x, x_off), _p(wt), _p(bias), _p(y, y_off), _stream()),
+            "avs_conv2d_nhwc"))
+        return None
+    rpg, gamma, beta, eps = bnstats
+    if bias is not None or act != ACT_NONE:
+        raise ValueError("the fused-statistics convolution takes no bias / activation")
+    rows = n * ho * wo
+    groups = (rows + rpg - 1) // rpg
+    ssum = torch.empty((groups, cout), dtype=torch.float32, device=x.device)
+    ssq = torch.empty((groups, cout), dtype=torch.float32, device=x.device)
     _timed("conv", dtype, flops, lambda: check(
-        lib().avs_conv2d_nhwc(ctypes.byref(d), _p(x, x_off), _p(wt), _p(bias), _p(y, y_off), _stream()),
-        "avs_conv2d_nhwc"))
+        lib().avs_conv2d_nhwc_bnstats(ctypes.byref(d), _p(x, x_off), _p(wt), _p(y, y_off), rpg, _p(ssum), _p(ssq),
+                                      _stream()), "avs_conv2d_nhwc_bnstats"))
+    scale = torch.empty((groups, cout), dtype=torch.float32, device=x.device)
+    shift = torch.empty((groups, cout), dtype=torch.float32, device=x.device)
+    check(lib().avs_bn_finalize(_p(ssum), _p(ssq), groups, cout, rpg, _p(gamma), _p(beta), float(eps), _p(scale),
+                                _p(shift), _stream()), "avs_bn_finalize")
+    return scale, shift
 
 
-def conv2d(x, wt, kh, kw, stride, pad, out, bias=None, act=ACT_NONE):
+def conv2d(x, wt, kh, kw, stride, pad, out, bias=None, act=ACT_NONE, bnstats=None):
     """x: NHWC view [n,h,w,cin] (unit channel stride); wt: [cout, kh*kw*cin]; out: NHWC view [n,ho,wo,cout]
-    whose pixels are dense in (n,ho,wo) order (a channel slice of a dense buffer is fine)."""
+    whose pixels are dense in (n,ho,wo) order (a channel slice of a dense buffer is fine).
+    bnstats: see conv2d_raw (returns (scale, shift) then, else `out`)."""
     n, h, w, cin = x.shape
     sh, sw = stride if isinstance(stride, tuple) else (stride, stride)
     ph, pw = pad if isinstance(pad, tuple) else (pad, pad)
@@ -157,9 +178,9 @@ def conv2d(x, wt, kh, kw, stride, pad, out, bias=None, act=ACT_NONE):
         raise ValueError(f"weight {tuple(wt.shape)} / dtypes do not match")
     if bias is not None:
         _f32(bias, "bias")
-    conv2d_raw(dtype_code(x.dtype), n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x, x.stride(0), x.stride(1),
-               x.stride(2), wt, wt.stride(0), out, yps, bias, act)
-    return out
+    r = conv2d_raw(dtype_code(x.dtype), n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x, x.stride(0),
+                   x.stride(1), x.stride(2), wt, wt.stride(0), out, yps, bias, act, bnstats=bnstats)
+    return out if bnstats is None else r
 
 
 # --------------------------------------------------------------------------- visual front end

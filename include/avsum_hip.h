@@ -85,6 +85,17 @@ typedef struct {
 int avs_conv2d_nhwc(const avs_conv_desc* desc, const void* d_x, const void* d_w,
                     const float* d_bias, void* d_y, avs_stream_t stream);
 
+/* The same convolution (no bias, no activation) that also accumulates BatchNorm batch statistics in its
+ * epilogue: for every group g = output_row / rows_per_group (equal-sized micro-batch groups) and channel c,
+ * d_sum[g,c] += y and d_sumsq[g,c] += y*y over the group's rows (values as stored; the two buffers are
+ * zeroed on the stream first).  avs_bn_finalize turns them into the folded affine of avs_bn_batch_stats.
+ * Saves the separate read pass of avs_bn_batch_stats (features/extractors.py:65, train-mode BN).            */
+int avs_conv2d_nhwc_bnstats(const avs_conv_desc* desc, const void* d_x, const void* d_w, void* d_y,
+                            int64_t rows_per_group, float* d_sum, float* d_sumsq, avs_stream_t stream);
+int avs_bn_finalize(const float* d_sum, const float* d_sumsq, int groups, int c, int64_t rows_per_group,
+                    const float* d_gamma, const float* d_beta, float eps, float* d_scale, float* d_shift,
+                    avs_stream_t stream);
+
 /* Batched C[b] = act(alpha * A[b] . B[b]^T + bias):  A [M,K] (row stride lda),
  * B [N,K] (row stride ldb; the nn.Linear weight layout), C [M,N] (ldc).
  * Replaces nn.Linear (models/av_model.py:10-15,29-31; models/attention.py:8-11;

@@ -68,7 +68,7 @@ def test_linear_bf16(dev, m, n, k):
 
 
 def test_gemm_f32_acc64_slices(dev):
-    """fp64 accumulation of 16-element fp32 slices (the STFT mode): closer to the exact product than plain fp32."""
+    """fp64 accumulation of 32-element fp32 slices: closer to the exact product than a plain fp32 running sum."""
     ops = _ops()
     from avsum_amd._abi import AVS_F32_ACC64
     g = torch.Generator().manual_seed(4)
@@ -81,8 +81,8 @@ def test_gemm_f32_acc64_slices(dev):
     c32 = ops.linear(a.to(dev), b.to(dev)).cpu()
     e64 = (c64.cpu().double() - exact).abs().max().item()
     e32 = (c32.double() - exact).abs().max().item()
-    assert e64 <= 2.0 * exact.abs().max().item() * 2 ** -24  # ~ one final rounding
-    assert e64 < e32
+    assert e64 <= 8.0 * exact.abs().max().item() * 2 ** -24
+    assert e64 < 0.6 * e32
 
 
 def test_gemm_batched_strided(dev):

@@ -103,13 +103,59 @@ def test_resnet50_trunk_batchstat_fp32(dev):
     assert err < 1e-4 * max(1.0, ref.abs().max().item()), err
 
 
-def test_resnet50_bf16_close_to_fp32(dev):
+@pytest.mark.parametrize("gsize", [1, 2])
+def test_resnet50_trunk_equal_groups(dev, gsize):
+    """Equal-sized BatchNorm groups: per-frame groups (the per-frame scoring mode) and 2-frame groups,
+    fp32 parity mode against the oracle."""
+    from avsum_amd.cnn import ResNet50Runner, resnet50_trunk
+    from oracle import cnn as ocnn
+    torch.manual_seed(24)
+    trunk = resnet50_trunk()
+    frames = _frames(4, 5)
+    sd = trunk.state_dict()
+    with torch.no_grad():
+        x = torch.cat([ocnn.preprocess_frame(f) for f in frames])
+        ref = torch.cat([ocnn.resnet50_trunk_forward(sd, x[i:i + gsize]) for i in range(0, 4, gsize)])
+    got = ResNet50Runner(trunk.to(dev), torch.float32, "batch").forward(
+        torch.from_numpy(frames).to(dev), list(range(0, 5, gsize))).cpu()
+    err = (got - ref).abs().max().item()
+    # 53 batch-normalised layers whose statistics come from as few as 49 samples: the fp32 features themselves
+    # are conditioned to a few 1e-4 (relative to the largest feature); the 1e-4 bar of north_star is on the
+    # importance SCORES and is checked end to end in test_pipeline_end_to_end_fp32
+    assert err < 5e-4 * max(1.0, ref.abs().max().item()), err
+
+
+def test_conv_bnstats_epilogue_matches_separate_pass(dev):
+    from avsum_amd import ops
+    g = torch.Generator().manual_seed(6)
+    for dtype, tol in ((torch.float32, 1e-5), (torch.bfloat16, 2e-3)):
+        for hw, cin, cout, k in ((7, 64, 128, 3), (14, 32, 64, 1), (5, 64, 192, 1)):
+            n = 6
+            x = (torch.randn(n, hw, hw, cin, generator=g) + 0.5).to(dtype).to(dev)
+            wt = (torch.randn(cout, k * k * cin, generator=g) / (k * k * cin) ** 0.5).to(dtype).to(dev)
+            gamma = (torch.rand(cout, generator=g) + 0.5).to(dev)
+            beta = torch.randn(cout, generator=g).to(dev)
+            y1 = torch.empty((n, hw, hw, cout), dtype=dtype, device=dev)
+            sc1, sh1 = ops.conv2d(x, wt, k, k, 1, k // 2, y1, bnstats=(2 * hw * hw, gamma, beta, 1e-5))
+            y2 = torch.empty_like(y1)
+            ops.conv2d(x, wt, k, k, 1, k // 2, y2)
+            rows = torch.arange(0, n + 1, 2, dtype=torch.int64, device=dev) * hw * hw
+            sc2, sh2 = ops.bn_batch_stats(y2.view(-1, cout), rows, gamma, beta, 1e-5)
+            assert torch.equal(y1, y2)
+            assert (sc1 - sc2).abs().max().item() < tol * sc2.abs().max().item()
+            assert (sh1 - sh2).abs().max().item() < tol * max(1.0, sh2.abs().max().item())
+
+
+@pytest.mark.parametrize("groups", [[0, 4, 8], [0, 4, 7, 8]])
+def test_resnet50_bf16_close_to_fp32(dev, groups):
+    """bf16 throughput mode (equal groups: statistics fused into the convolution epilogue; ragged groups:
+    separate statistics pass) against the fp32 parity mode."""
     from avsum_amd.cnn import ResNet50Runner, resnet50_trunk
     torch.manual_seed(22)
     trunk = resnet50_trunk().to(dev)
     frames = torch.from_numpy(_frames(8, 2)).to(dev)
-    f32 = ResNet50Runner(trunk, torch.float32).forward(frames, [0, 4, 8]).cpu()
-    bf = ResNet50Runner(trunk, torch.bfloat16).forward(frames, [0, 4, 8]).cpu()
+    f32 = ResNet50Runner(trunk, torch.float32).forward(frames, groups).cpu()
+    bf = ResNet50Runner(trunk, torch.bfloat16).forward(frames, groups).cpu()
     # bf16 activations through 53 batch-normalised layers of a RANDOM-weight network: the feature vectors
     # stay strongly aligned but not close element-wise (measured ~0.11 relative L2)
     rel = ((bf - f32).norm() / f32.norm()).item()
@@ -156,6 +202,38 @@ def test_visual_extractor_api(dev):
     assert p.shape == (1, 3, 224, 224) and torch.equal(p, ocnn.preprocess_frame(frames[0]))
     pi = ext._preprocess_inception(frames[0])
     assert pi.shape == (1, 3, 299, 299) and torch.equal(pi, ocnn.preprocess_inception(frames[0]))
+
+
+def test_pipeline_end_to_end_fp32(dev):
+    """frames -> ResNet-50 (per-frame batch-stat BN) | Inception-v3 -> AVBiLSTM scorer -> selection, fp32 parity
+    mode, against the oracle end to end: scores within 1e-4, selected indices identical (guard-banded)."""
+    from avsum_amd.features.extractors import VisualFeatureExtractor
+    from avsum_amd.pipeline import FrameScoringPipeline
+    from oracle import cnn as ocnn, scorer as osc
+    torch.manual_seed(51)
+    ext = VisualFeatureExtractor(torch.float32, "batch")
+    model = _seeded_scorer(52)
+    frames = _frames(7, 9)
+    offsets = [0, 4, 7]  # two videos
+    rsd, isd, ssd = ext.resnet.state_dict(), ext.inception.state_dict(), model.state_dict()
+    with torch.no_grad():
+        feats = []
+        for f in frames:
+            r = ocnn.resnet50_trunk_forward(rsd, ocnn.preprocess_frame(f))
+            i = ocnn.inception_v3_forward(isd, ocnn.preprocess_inception(f))
+            feats.append(torch.cat([r, i], 1))
+        feats = torch.cat(feats)
+        ref = torch.cat([osc.av_bilstm_forward(ssd, feats[a:b].unsqueeze(0), torch.zeros(1, b - a, 296)).reshape(-1)
+                         for a, b in zip(offsets[:-1], offsets[1:])])
+    pipe = FrameScoringPipeline(ext.to(dev), model.to(dev), use_inception=True, chunk_frames=4, frames_per_group=1)
+    scores = pipe.score(torch.from_numpy(frames).to(dev), offsets)
+    got = scores.cpu()
+    assert (got - ref).abs().max().item() < 1e-4
+    sel = pipe.select(scores, offsets)
+    for (a, b), idx in zip(zip(offsets[:-1], offsets[1:]), sel):
+        dropped, sel_ref = _guarded_equal_selection(got[a:b].numpy(), ref[a:b].numpy(), 2e-6)
+        if dropped == 0:
+            assert np.array_equal(idx, sel_ref)
 
 
 def test_audio_extractor_api(dev):
