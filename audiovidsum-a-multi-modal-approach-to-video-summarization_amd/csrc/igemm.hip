@@ -56,24 +56,43 @@ struct IgemmParams {
   float* stat_sum;
   float* stat_sq;
   int rows_per_group;
+  long long lin_stride;  // >= 0: output row m reads input row m at x + m*lin_stride (no (n,ho,wo) decode needed)
+  int debug;  // ablation switches for kernel studies (0 in production): 1 = skip output stores, 2 = skip A/B loads
 };
 
 #define AVS_GLDS16(src, dst)                                                                        \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),            \
                                    (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
-template <int ES, int BN, bool ACC64, bool SPATIAL>
-__global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
-  static_assert(!ACC64 || (ES == 4 && BN == 64), "fp64 slice accumulation: fp32 operands, narrow tile only");
-  constexpr int CE = 16 / ES;    // elements per 16-byte chunk
-  constexpr int BKE = 128 / ES;  // elements per LDS row (one reduction step)
-  constexpr int NA = 4;          // A rows staged per thread (128 rows / 32)
-  constexpr int NB = BN / 32;    // B rows staged per thread
-  constexpr int NT = BN / 64;    // 32-wide column tiles per wave
-  constexpr int A_ROWS = 128;
-  constexpr int BUF = (A_ROWS + BN) * 8;  // uint4 slots per buffer
+// ROWB = bytes of reduction per LDS row and step: 128 (fewer barriers per MAC; 64 KB of LDS, 2 workgroups per
+// CU) for the long reductions, 64 (32 KB, 3 workgroups per CU: more DMA in flight) for the short ones, whose
+// cost is the latency of their few loads and their stores rather than the matrix work.
+// EPI: the epilogue is what a tile of a short reduction costs, so its common forms are compiled separately:
+//   EPI_PLAIN  alpha == 1, no bias, no activation, no statistics (ResNet convolutions, projections)
+//   EPI_STATS  EPI_PLAIN + fused BatchNorm batch statistics
+//   EPI_ANY    everything decided at run time (bias per column / row, ReLU, alpha)
+enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_ANY = 2 };
 
-  __shared__ uint4 lds[2 * BUF];
+template <int ES, int BN, bool ACC64, bool SPATIAL, int ROWB, int EPI>
+__global__ __launch_bounds__(256, (ROWB == 64 && !ACC64) ? 3 : 2) void igemm_kernel(IgemmParams p) {
+  static_assert(!ACC64 || (ES == 4 && BN == 64), "fp64 slice accumulation: fp32 operands, narrow tile only");
+  static_assert(ROWB == 64 || ROWB == 128, "row bytes");
+  constexpr int CE = 16 / ES;        // elements per 16-byte chunk
+  constexpr int BKE = ROWB / ES;     // elements per LDS row (one reduction step)
+  constexpr int CPRR = ROWB / 16;    // 16-byte slots per LDS row
+  constexpr int RPP = 256 / CPRR;    // rows staged per pass of the 256 threads
+  constexpr int SH = ROWB == 128 ? 1 : 2;  // rows sharing one 256-byte bank row = 1 << SH
+  constexpr int KS = ROWB / 32;      // MFMA sub-steps per row (two chunks each)
+  constexpr int A_ROWS = 128;
+  constexpr int NA = A_ROWS / RPP;   // A rows staged per thread
+  constexpr int NB = BN / RPP;       // B rows staged per thread
+  constexpr int NT = BN / 64;        // 32-wide column tiles per wave
+  constexpr int BUF = (A_ROWS + BN) * CPRR;  // uint4 slots per buffer
+  constexpr int CT_PITCH = BN * 2 + 16;      // bf16 epilogue staging tile: row pitch in bytes (16 bytes of padding)
+  constexpr int CT_SLOTS = ES == 2 ? (A_ROWS * CT_PITCH) / 16 : 0;
+  constexpr int LDS_SLOTS = 2 * BUF > CT_SLOTS ? 2 * BUF : CT_SLOTS;
+
+  __shared__ uint4 lds[LDS_SLOTS];
 
   // XCD-aware, bijective block remap: blocks that share an XCD (orig % 8)
   // take consecutive tiles, so neighbouring column tiles reuse A rows in L2.
@@ -94,17 +113,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 
   const int t = threadIdx.x;
   const int wave = t >> 6, lane = t & 63;
-  const int c = t & 7;
-  const int rb = t >> 3;                  // 0..31
-  const int cq = c ^ ((rb >> 1) & 7);     // the k-chunk this thread fetches into slot c
+  const int c = t & (CPRR - 1);
+  const int rb = t / CPRR;                          // 0..RPP-1
+  const int cq = c ^ ((rb >> SH) & (CPRR - 1));     // the k-chunk this thread fetches into slot c
 
   // ---- per-thread row bases (rows rb + 32*i of the A tile, and of the B tile) ----
   const char* a_base[NA];
   int hi0[NA], wi0[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    const int m = m0 + rb + 32 * i;
-    if (m < p.M) {
+    const int m = m0 + rb + RPP * i;
+    if (m < p.M && p.lin_stride >= 0) {
+      hi0[i] = 0;
+      wi0[i] = 0;
+      a_base[i] = x + (long long)m * p.lin_stride * ES;
+    } else if (m < p.M) {
       const int n = m / p.HoWo;
       const int rem = m - n * p.HoWo;
       const int ho = rem / p.Wo;
@@ -122,7 +145,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   const char* b_base[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
-    const int n = n0 + rb + 32 * i;
+    const int n = n0 + rb + RPP * i;
     b_base[i] = n < p.N ? w + (long long)n * p.ldb * ES : nullptr;
   }
 
@@ -134,7 +157,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 
   auto stage = [&](int buf) {
     uint4* abuf = lds + buf * BUF + wave * 64;        // wave-uniform; lane l lands at +l
-    uint4* bbuf = abuf + A_ROWS * 8;
+    uint4* bbuf = abuf + A_ROWS * CPRR;
     const bool kval = kc < p.K;
     const long long koff = ((long long)kh * p.x_row_stride + (long long)kw * p.x_px_stride + ci) * ES;
 #pragma unroll
@@ -185,28 +208,34 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   }
 
   const int steps = (p.K + BKE - 1) / BKE;
+  if (p.debug & 2) {
+    a_base[0] = a_base[1] = nullptr;
+    if constexpr (NA > 2) a_base[NA - 2] = a_base[NA - 1] = nullptr;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) b_base[i] = nullptr;
+  }
   stage(0);
   __syncthreads();  // drains the DMA (vmcnt) and makes every wave's part of the tile visible
 
   for (int s = 0; s < steps; ++s) {
     const int buf = s & 1;
     const uint4* abuf = lds + buf * BUF;
-    const uint4* bbuf = abuf + A_ROWS * 8;
+    const uint4* bbuf = abuf + A_ROWS * CPRR;
     // 1. all fragments of this step into registers (the compiler orders every LDS read behind the
     //    outstanding LDS-DMA, so the reads must come BEFORE the next tile's DMA is issued)
-    uint4 fa[4][2], fb[4][NT];
+    uint4 fa[KS][2], fb[KS][NT];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       const int chunk = 2 * ks + lh;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         const int row = wr * 64 + mt * 32 + lr;
-        fa[ks][mt] = abuf[row * 8 + (chunk ^ ((row >> 1) & 7))];
+        fa[ks][mt] = abuf[row * CPRR + (chunk ^ ((row >> SH) & (CPRR - 1)))];
       }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int row = wc * (BN / 2) + nt * 32 + lr;
-        fb[ks][nt] = bbuf[row * 8 + (chunk ^ ((row >> 1) & 7))];
+        fb[ks][nt] = bbuf[row * CPRR + (chunk ^ ((row >> SH) & (CPRR - 1)))];
       }
     }
     // 2. DMA of the next tile into the other buffer: every wave finished reading it before the barrier
@@ -214,7 +243,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     if (s + 1 < steps) stage(buf ^ 1);
     // 3. matrix cores
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -251,10 +280,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 
   // ---- epilogue ----
   // Register e of a 32x32 tile is row (e&3) + 8*(e>>2) + 4*lh, column lr.
-  if (p.stat_sum != nullptr) {
-    // Fused batch statistics (no bias / activation on this path).  A lane owns one column of each 32-wide
-    // tile: it sums its 2 x 16 rows per group, the two lane halves are folded by one shuffle, and lanes
-    // 0..31 issue one atomic pair per (group, column).  Rows past M hold exact zeros and add nothing.
+  if constexpr (EPI == EPI_STATS) {
+    // Fused batch statistics.  A lane owns one column of each 32-wide tile: it sums its 2 x 16 rows per
+    // group, the two lane halves are folded by one shuffle, and lanes 0..31 issue one atomic pair per
+    // (group, column).  Rows past M hold exact zeros and add nothing.
     const int r_first = m0 + wr * 64;
     if (r_first < p.M) {
       const int r_last = (r_first + 63 < p.M ? r_first + 63 : p.M - 1);
@@ -262,65 +291,105 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int col = n0 + wc * (BN / 2) + nt * 32 + lr;
-        for (int g = g0; g <= g1; ++g) {
-          const int lo = g * p.rows_per_group, hi = lo + p.rows_per_group;
+        if (g0 == g1) {
           float s1 = 0.f, s2 = 0.f;
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-              const int row = r_first + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-              float v = acc[mt][nt][e] * p.alpha;
-              if constexpr (ES == 2) v = avs_bf16_to_f32(avs_f32_to_bf16(v));
-              const bool in = (g0 == g1) || (row >= lo && row < hi);
-              v = in ? v : 0.f;
+              const float v = acc[mt][nt][e];
               s1 += v;
               s2 = fmaf(v, v, s2);
             }
           s1 += __shfl_xor(s1, 32, 64);
           s2 += __shfl_xor(s2, 32, 64);
           if (lh == 0 && col < p.N) {
-            atomicAdd(p.stat_sum + (long long)g * p.N + col, s1);
-            atomicAdd(p.stat_sq + (long long)g * p.N + col, s2);
+            atomicAdd(p.stat_sum + (long long)g0 * p.N + col, s1);
+            atomicAdd(p.stat_sq + (long long)g0 * p.N + col, s2);
+          }
+        } else {
+          for (int g = g0; g <= g1; ++g) {
+            const int lo = g * p.rows_per_group - r_first - 4 * lh, hi = lo + p.rows_per_group;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+              for (int e = 0; e < 16; ++e) {
+                const int roff = mt * 32 + (e & 3) + 8 * (e >> 2);  // row - r_first - 4*lh
+                const float v = (roff >= lo && roff < hi) ? acc[mt][nt][e] : 0.f;
+                s1 += v;
+                s2 = fmaf(v, v, s2);
+              }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lh == 0 && col < p.N) {
+              atomicAdd(p.stat_sum + (long long)g * p.N + col, s1);
+              atomicAdd(p.stat_sq + (long long)g * p.N + col, s2);
+            }
           }
         }
       }
     }
   }
   if constexpr (ES == 2) {
-    // bf16: through LDS, then 16-byte row-major stores.  Row pitch BN*2 + 16 bytes.
-    constexpr int PITCH = BN * 2 + 16;
+    // bf16: through LDS, then 16-byte row-major stores.  Every per-element LDS address is a per-lane base plus
+    // a compile-time offset (padded pitch, no swizzle arithmetic): for the short reductions this epilogue,
+    // not the matrix work, is what a tile costs.
+    constexpr int CPRW = BN / 8;          // 16-byte chunks per tile row
+    constexpr int RSTEP = 256 / CPRW;     // tile rows covered by one pass of the 256 threads
     char* ct = reinterpret_cast<char*>(lds);
+    {
+      char* cbase = ct + (wr * 64 + 4 * lh) * CT_PITCH + (wc * (BN / 2) + lr) * 2;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int lcol = wc * (BN / 2) + nt * 32 + lr;
-        const int col = n0 + lcol;
-        const float bcol = (p.bias_mode == AVS_BIAS_COL && col < p.N) ? bias[col] : 0.f;
+        for (int nt = 0; nt < NT; ++nt) {
+          float bcol = 0.f;
+          if constexpr (EPI == EPI_ANY) {
+            const int col = n0 + wc * (BN / 2) + nt * 32 + lr;
+            bcol = (p.bias_mode == AVS_BIAS_COL && col < p.N) ? bias[col] : 0.f;
+          }
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int lrow = wr * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-          float v = acc[mt][nt][e] * p.alpha + bcol;
-          if (p.bias_mode == AVS_BIAS_ROW && m0 + lrow < p.M) v += bias[m0 + lrow];
-          if (p.act == AVS_ACT_RELU) v = fmaxf(v, 0.f);
-          *reinterpret_cast<unsigned short*>(ct + lrow * PITCH + lcol * 2) = avs_f32_to_bf16(v);
+          for (int e = 0; e < 16; ++e) {
+            const int roff = mt * 32 + (e & 3) + 8 * (e >> 2);
+            float v = acc[mt][nt][e];
+            if constexpr (EPI == EPI_ANY) {
+              v = fmaf(v, p.alpha, bcol);
+              if (p.bias_mode == AVS_BIAS_ROW) {
+                const int row = m0 + wr * 64 + 4 * lh + roff;
+                if (row < p.M) v += bias[row];
+              }
+              if (p.act == AVS_ACT_RELU) v = fmaxf(v, 0.f);
+            }
+            *reinterpret_cast<unsigned short*>(cbase + roff * CT_PITCH + nt * 64) = avs_f32_to_bf16(v);
+          }
         }
-      }
+    }
     __syncthreads();
-    constexpr int CPRW = BN / 8;  // 16-byte chunks per tile row
-    const bool vec_ok = ((p.ldc * 2) % 16 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) && (n0 % 8 == 0);
-    for (int idx = t; idx < A_ROWS * CPRW; idx += 256) {
-      const int lrow = idx / CPRW, ch = idx - lrow * CPRW;
-      const int row = m0 + lrow, col = n0 + ch * 8;
-      if (row >= p.M || col >= p.N) continue;
-      const char* srcp = ct + lrow * PITCH + ch * 16;
-      char* dst = y + ((long long)row * p.ldc + col) * 2;
-      if (vec_ok && col + 8 <= p.N) {
-        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(srcp);
+    const int srow = t / CPRW, sch = t - srow * CPRW;
+    const char* srcp = ct + srow * CT_PITCH + sch * 16;
+    const int col = n0 + sch * 8;
+    char* dst = y + ((long long)(m0 + srow) * p.ldc + col) * 2;
+    const long long dstep = (long long)RSTEP * p.ldc * 2;
+    const bool vec_ok = ((p.ldc * 2) % 16 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+    if (!(p.debug & 1)) {
+      if (vec_ok && m0 + A_ROWS <= p.M && n0 + BN <= p.N) {
+#pragma unroll
+        for (int it = 0; it < A_ROWS / RSTEP; ++it)
+          *reinterpret_cast<uint4*>(dst + it * dstep) = *reinterpret_cast<const uint4*>(srcp + it * RSTEP * CT_PITCH);
       } else {
-        for (int j = 0; j < 8 && col + j < p.N; ++j)
-          reinterpret_cast<unsigned short*>(dst)[j] = reinterpret_cast<const unsigned short*>(srcp)[j];
+        for (int it = 0; it < A_ROWS / RSTEP; ++it) {
+          const int row = m0 + srow + it * RSTEP;
+          if (row >= p.M || col >= p.N) continue;
+          const char* sp = srcp + it * RSTEP * CT_PITCH;
+          char* dp = dst + it * dstep;
+          if (vec_ok && col + 8 <= p.N) {
+            *reinterpret_cast<uint4*>(dp) = *reinterpret_cast<const uint4*>(sp);
+          } else {
+            for (int j = 0; j < 8 && col + j < p.N; ++j)
+              reinterpret_cast<unsigned short*>(dp)[j] = reinterpret_cast<const unsigned short*>(sp)[j];
+          }
+        }
       }
     }
   } else {
@@ -330,7 +399,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
       for (int nt = 0; nt < NT; ++nt) {
         const int col = n0 + wc * (BN / 2) + nt * 32 + lr;
         if (col >= p.N) continue;
-        const float bcol = (p.bias_mode == AVS_BIAS_COL) ? bias[col] : 0.f;
+        float bcol = 0.f;
+        if constexpr (EPI == EPI_ANY) bcol = (p.bias_mode == AVS_BIAS_COL) ? bias[col] : 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int row = m0 + wr * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
@@ -338,22 +408,58 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
           float v;
           if constexpr (ACC64)
             v = (float)(acc64[mt][nt][e] * (double)p.alpha) + bcol;
+          else if constexpr (EPI == EPI_ANY)
+            v = fmaf(acc[mt][nt][e], p.alpha, bcol);
           else
-            v = acc[mt][nt][e] * p.alpha + bcol;
-          if (p.bias_mode == AVS_BIAS_ROW) v += bias[row];
-          if (p.act == AVS_ACT_RELU) v = fmaxf(v, 0.f);
+            v = acc[mt][nt][e];
+          if constexpr (EPI == EPI_ANY) {
+            if (p.bias_mode == AVS_BIAS_ROW) v += bias[row];
+            if (p.act == AVS_ACT_RELU) v = fmaxf(v, 0.f);
+          }
           *reinterpret_cast<float*>(y + ((long long)row * p.ldc + col) * 4) = v;
         }
       }
   }
 }
 
+static int g_debug_flags = 0;
+extern "C" void avs_debug_flags(int flags) { g_debug_flags = flags; }
+static int g_rowb_threshold_bytes = 100000;  // reductions of at most this many bytes per row use 64-byte steps
+
+extern "C" void avs_tune_short_reduction_bytes(int bytes) { g_rowb_threshold_bytes = bytes; }
+
+template <int ES, int BN, bool ACC64, bool SP, int ROWB>
+static void igemm_dispatch_epi(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p) {
+  if constexpr (ACC64) {
+    hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_ANY>), grid, dim3(256), 0, stream, p);
+  } else {
+    if (epi == EPI_PLAIN)
+      hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_PLAIN>), grid, dim3(256), 0, stream, p);
+    else if (epi == EPI_STATS)
+      hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS>), grid, dim3(256), 0, stream, p);
+    else
+      hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_ANY>), grid, dim3(256), 0, stream, p);
+  }
+}
+
 template <int ES, int BN, bool ACC64>
 static void igemm_dispatch(bool spatial, dim3 grid, hipStream_t stream, const IgemmParams& p) {
-  if (spatial)
-    hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, true>), grid, dim3(256), 0, stream, p);
-  else
-    hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, false>), grid, dim3(256), 0, stream, p);
+  const_cast<IgemmParams&>(p).debug = g_debug_flags;
+  const bool short_k = (long long)p.K * ES <= g_rowb_threshold_bytes;
+  int epi = EPI_ANY;
+  if (p.bias_mode == AVS_BIAS_NONE && p.act == AVS_ACT_NONE && p.alpha == 1.0f)
+    epi = p.stat_sum ? EPI_STATS : EPI_PLAIN;
+  if (short_k) {
+    if (spatial)
+      igemm_dispatch_epi<ES, BN, ACC64, true, 64>(epi, grid, stream, p);
+    else
+      igemm_dispatch_epi<ES, BN, ACC64, false, 64>(epi, grid, stream, p);
+  } else {
+    if (spatial)
+      igemm_dispatch_epi<ES, BN, ACC64, true, 128>(epi, grid, stream, p);
+    else
+      igemm_dispatch_epi<ES, BN, ACC64, false, 128>(epi, grid, stream, p);
+  }
 }
 
 static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream, const char* who) {
@@ -384,6 +490,14 @@ static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream
   // the per-tap bounds tests are only needed when a tap can leave the image
   const bool spatial = !(p.ph == 0 && p.pw == 0 && (p.HoWo / p.Wo - 1) * p.sh + (p.K / (p.cin * p.KW)) - 1 < p.H &&
                          (p.Wo - 1) * p.sw + p.KW - 1 < p.W);
+  // dense 1x1 / stride-1 input (and every plain GEMM): output row m reads input row m
+  p.lin_stride = -1;
+  if (!spatial && p.KW == 1 && p.K == p.cin && p.sh == 1 && p.sw == 1) {
+    if (p.HoWo == 1)
+      p.lin_stride = p.x_img_stride;
+    else if (p.x_row_stride == (long long)p.Wo * p.x_px_stride && p.x_img_stride == (long long)p.HoWo * p.x_px_stride)
+      p.lin_stride = p.x_px_stride;
+  }
   dim3 grid((unsigned)total, 1, (unsigned)batch);
   if (dtype == AVS_BF16) {
     if (narrow)

@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=1024)
     ap.add_argument("--cpu-sample", type=int, default=48, help="frames for the CPU baseline (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--short-k-bytes", type=int, default=None, help="tuning: avs_tune_short_reduction_bytes")
     args = ap.parse_args()
 
     from avsum_amd import dist as avd, ops
@@ -107,6 +108,9 @@ def main():
     from avsum_amd.models.av_model import AVBiLSTMModel
     from avsum_amd.pipeline import FrameScoringPipeline
 
+    if args.short_k_bytes is not None:
+        from avsum_amd import _abi
+        _abi.lib().avs_tune_short_reduction_bytes(args.short_k_bytes)
     rank, world, local = avd.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")

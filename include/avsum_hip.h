@@ -96,6 +96,13 @@ int avs_bn_finalize(const float* d_sum, const float* d_sumsq, int groups, int c,
                     const float* d_gamma, const float* d_beta, float eps, float* d_scale, float* d_shift,
                     avs_stream_t stream);
 
+/* Tuning knob (process-wide, not thread-safe): reductions of at most `bytes` bytes per output row run with
+ * 64-byte LDS rows / 3 workgroups per CU instead of 128-byte rows / 2 workgroups per CU.  Default: always. */
+void avs_tune_short_reduction_bytes(int bytes);
+/* Kernel-study ablation switches for the contraction kernel (0 = production): bit 0 skips the output
+ * stores, bit 1 skips the operand loads.  Results are wrong while set; tools/ only.                       */
+void avs_debug_flags(int flags);
+
 /* Batched C[b] = act(alpha * A[b] . B[b]^T + bias):  A [M,K] (row stride lda),
  * B [N,K] (row stride ldb; the nn.Linear weight layout), C [M,N] (ldc).
  * Replaces nn.Linear (models/av_model.py:10-15,29-31; models/attention.py:8-11;

@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""Run one convolution shape a few times (for rocprofv3 --pmc studies). usage: conv_one.py n hw cin cout k"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from avsum_amd import ops
+n, hw, cin, cout, k = [int(v) for v in sys.argv[1:6]]
+dev = torch.device("cuda", 0)
+dt = torch.bfloat16
+x = torch.randn(n, hw, hw, cin, device=dev).to(dt)
+w = (torch.randn(cout, k * k * cin, device=dev) / (k * k * cin) ** 0.5).to(dt)
+y = torch.empty(n, hw, hw, cout, device=dev, dtype=dt)
+for _ in range(3):
+    ops.conv2d(x, w, k, k, 1, k // 2, y)
+torch.cuda.synchronize()
