@@ -1,0 +1,291 @@
+// 1x1 convolution + BatchNorm in batch-statistics mode (+ residual, + ReLU) in ONE kernel, bf16.
+//
+// Why: with per-micro-batch statistics the normalisation cannot ride in a convolution's epilogue —
+// every output of the group must exist before its mean/variance do — so the plain path writes the
+// raw convolution, reads it back (statistics), and reads + rewrites it (apply): 8 bytes of HBM per
+// element for a 1x1 layer that computes almost nothing.  Here one workgroup owns ALL rows of one
+// group for a slab of output channels and walks them twice:
+//   pass 1  tiles of 128 rows x BN channels on the matrix cores, only column sums / sums of squares kept
+//           (registers -> one shuffle -> LDS across the two row-waves): deterministic, no atomics;
+//   pass 2  the same tiles again (operands now come from L2), epilogue = scale/shift from pass 1,
+//           residual add, ReLU, bf16, LDS-staged 16-byte stores of the FINAL activations.
+// HBM per element: one write (+ one residual read).  The second pass doubles the matrix work of
+// layers whose cost is their memory traffic, not their FLOPs.
+//
+// Tile machinery = igemm.hip's (LDS-DMA staging, 64-byte rows, XOR-swizzled slots, 2 x 2 waves of
+// 64 x BN/2 outputs, v_mfma_f32_32x32x16_bf16); rows are linear (output row m reads input row m).
+#include "avs_internal.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+extern __device__ unsigned int avs_zero16[4];  // igemm.hip
+
+struct ConvBnParams {
+  const char* x;
+  const char* w;
+  char* y;
+  const char* res;
+  const float* gamma;
+  const float* beta;
+  float eps;
+  int N, K;
+  long long lin_stride, ldb, ldc, ldr;
+  int rows_per_group, groups, tiles_n;
+  int relu;
+};
+
+#define AVS_GLDS16(src, dst)                                                                        \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),            \
+                                   (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+
+template <int BN>
+__global__ __launch_bounds__(256, 3) void conv1x1_bn_kernel(ConvBnParams p) {
+  constexpr int ES = 2, ROWB = 64;
+  constexpr int CE = 16 / ES, BKE = ROWB / ES, CPRR = ROWB / 16, RPP = 256 / CPRR, SH = 2, KS = ROWB / 32;
+  constexpr int A_ROWS = 128, NA = A_ROWS / RPP, NB = BN / RPP, NT = BN / 64;
+  constexpr int BUF = (A_ROWS + BN) * CPRR;
+  constexpr int CT_PITCH = BN * 2 + 16;
+  constexpr int CT_SLOTS = (A_ROWS * CT_PITCH) / 16;
+  constexpr int LDS_SLOTS = 2 * BUF > CT_SLOTS ? 2 * BUF : CT_SLOTS;
+  constexpr int CPRW = BN / 8, RSTEP = 256 / CPRW;
+
+  __shared__ uint4 lds[LDS_SLOTS];
+  __shared__ float red[2][BN][2];
+
+  const unsigned nwg = gridDim.x, orig = blockIdx.x;
+  const unsigned q = nwg >> 3, rr = nwg & 7, xcd = orig & 7;
+  const unsigned wg = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
+  const int tn = wg % p.tiles_n;
+  const int g = wg / p.tiles_n;
+  const int n0 = tn * BN;
+  const long long m_lo = (long long)g * p.rows_per_group;
+  const long long m_hi = m_lo + p.rows_per_group;
+  const int tiles_m = (p.rows_per_group + A_ROWS - 1) / A_ROWS;
+
+  const char* __restrict__ x = p.x;
+  const char* __restrict__ w = p.w;
+  const char* zsrc = reinterpret_cast<const char*>(avs_zero16);
+
+  const int t = threadIdx.x;
+  const int wave = t >> 6, lane = t & 63;
+  const int c = t & (CPRR - 1);
+  const int rb = t / CPRR;
+  const int cq = c ^ ((rb >> SH) & (CPRR - 1));
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  const char* b_base[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int n = n0 + rb + RPP * i;
+    b_base[i] = n < p.N ? w + (long long)n * p.ldb * ES : nullptr;
+  }
+
+  const int steps = (p.K + BKE - 1) / BKE;
+  float s1[NT], s2[NT], scale[NT], shift[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) s1[nt] = s2[nt] = scale[nt] = shift[nt] = 0.f;
+
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int tm = 0; tm < tiles_m; ++tm) {
+      const long long m0 = m_lo + (long long)tm * A_ROWS;
+      const char* a_base[NA];
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const long long m = m0 + rb + RPP * i;
+        a_base[i] = m < m_hi ? x + m * p.lin_stride * ES : nullptr;
+      }
+      int kc = cq * CE;
+      auto stage = [&](int buf) {
+        uint4* abuf = lds + buf * BUF + wave * 64;
+        uint4* bbuf = abuf + A_ROWS * CPRR;
+        const bool kval = kc < p.K;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+          const char* src = (kval && a_base[i] != nullptr) ? a_base[i] + (long long)kc * ES : zsrc;
+          AVS_GLDS16(src, abuf + 256 * i);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          const char* src = (kval && b_base[i] != nullptr) ? b_base[i] + (long long)kc * ES : zsrc;
+          AVS_GLDS16(src, bbuf + 256 * i);
+        }
+        kc += BKE;
+      };
+
+      f32x16 acc[2][NT];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+      stage(0);
+      __syncthreads();
+      for (int s = 0; s < steps; ++s) {
+        const int buf = s & 1;
+        const uint4* abuf = lds + buf * BUF;
+        const uint4* bbuf = abuf + A_ROWS * CPRR;
+        uint4 fa[KS][2], fb[KS][NT];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int chunk = 2 * ks + lh;
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {
+            const int row = wr * 64 + mt * 32 + lr;
+            fa[ks][mt] = abuf[row * CPRR + (chunk ^ ((row >> SH) & (CPRR - 1)))];
+          }
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int row = wc * (BN / 2) + nt * 32 + lr;
+            fb[ks][nt] = bbuf[row * CPRR + (chunk ^ ((row >> SH) & (CPRR - 1)))];
+          }
+        }
+        if (s + 1 < steps) stage(buf ^ 1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[ks][mt]),
+                                                                    __builtin_bit_cast(bf16x8, fb[ks][nt]),
+                                                                    acc[mt][nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+      }
+
+      if (pass == 0) {
+        // rows past the group's end were staged as zeros: they add nothing
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const float v = acc[mt][nt][e];
+              s1[nt] += v;
+              s2[nt] = fmaf(v, v, s2[nt]);
+            }
+      } else {
+        char* ct = reinterpret_cast<char*>(lds);
+        char* cbase = ct + (wr * 64 + 4 * lh) * CT_PITCH + (wc * (BN / 2) + lr) * 2;
+        const bool relu_now = p.relu && p.res == nullptr;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int roff = mt * 32 + (e & 3) + 8 * (e >> 2);
+              float v = fmaf(acc[mt][nt][e], scale[nt], shift[nt]);
+              if (relu_now) v = fmaxf(v, 0.f);
+              *reinterpret_cast<unsigned short*>(cbase + roff * CT_PITCH + nt * 64) = avs_f32_to_bf16(v);
+            }
+        __syncthreads();
+        const int srow = t / CPRW, sch = t - srow * CPRW;
+        const int col = n0 + sch * 8;
+        if (col < p.N) {  // N is a multiple of 8 (checked on the host)
+#pragma unroll
+          for (int it = 0; it < A_ROWS / RSTEP; ++it) {
+            const long long row = m0 + srow + it * RSTEP;
+            if (row >= m_hi) break;
+            uint4 v = *reinterpret_cast<const uint4*>(ct + (srow + it * RSTEP) * CT_PITCH + sch * 16);
+            if (p.res != nullptr) {
+              const uint4 rv = *reinterpret_cast<const uint4*>(p.res + (row * p.ldr + col) * 2);
+              unsigned vv[4] = {v.x, v.y, v.z, v.w};
+              const unsigned rw[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                float a0 = __uint_as_float(vv[j] << 16) + __uint_as_float(rw[j] << 16);
+                float a1 = __uint_as_float(vv[j] & 0xffff0000u) + __uint_as_float(rw[j] & 0xffff0000u);
+                if (p.relu) {
+                  a0 = fmaxf(a0, 0.f);
+                  a1 = fmaxf(a1, 0.f);
+                }
+                vv[j] = (unsigned)avs_f32_to_bf16(a0) | ((unsigned)avs_f32_to_bf16(a1) << 16);
+              }
+              v = make_uint4(vv[0], vv[1], vv[2], vv[3]);
+            }
+            *reinterpret_cast<uint4*>(p.y + (row * p.ldc + col) * 2) = v;
+          }
+        }
+        __syncthreads();  // the staging tile aliases the operand buffers of the next tile
+      }
+    }
+
+    if (pass == 0) {
+      // fold the two lane halves, then the two row-waves through LDS; every lane then holds the group's
+      // statistics of its own column(s)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        s1[nt] += __shfl_xor(s1[nt], 32, 64);
+        s2[nt] += __shfl_xor(s2[nt], 32, 64);
+        if (lh == 0) {
+          const int lc = wc * (BN / 2) + nt * 32 + lr;
+          red[wr][lc][0] = s1[nt];
+          red[wr][lc][1] = s2[nt];
+        }
+      }
+      __syncthreads();
+      const float inv_n = 1.f / (float)p.rows_per_group;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int lc = wc * (BN / 2) + nt * 32 + lr;
+        const int col = n0 + lc;
+        const float mean = (red[0][lc][0] + red[1][lc][0]) * inv_n;
+        const float var = fmaxf((red[0][lc][1] + red[1][lc][1]) * inv_n - mean * mean, 0.f);
+        const float ga = col < p.N ? p.gamma[col] : 0.f;
+        const float be = col < p.N ? p.beta[col] : 0.f;
+        scale[nt] = ga / sqrtf(var + p.eps);
+        shift[nt] = be - mean * scale[nt];
+      }
+      __syncthreads();
+    }
+  }
+}
+
+extern "C" int avs_conv1x1_bn_bf16(const void* d_x, int64_t lin_stride, int k, const void* d_w, int64_t ldb, int n,
+                                   int64_t rows_per_group, int groups, const float* d_gamma, const float* d_beta,
+                                   float eps, const void* d_residual, int64_t ldr, int relu, void* d_y, int64_t ldc,
+                                   avs_stream_t stream) {
+  AVS_REQUIRE(k > 0 && n > 0 && groups >= 0 && rows_per_group > 0 && rows_per_group < (1ll << 30), AVS_E_SHAPE,
+              "avs_conv1x1_bn_bf16: k=%d n=%d groups=%d rows_per_group=%lld", k, n, groups, (long long)rows_per_group);
+  if (groups == 0) return AVS_OK;
+  AVS_REQUIRE(d_x && d_w && d_gamma && d_beta && d_y, AVS_E_ARG, "avs_conv1x1_bn_bf16: null pointer");
+  AVS_REQUIRE(k % 8 == 0 && n % 8 == 0 && lin_stride % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && ldb >= k &&
+                  ldc >= n && (!d_residual || (ldr % 8 == 0 && ldr >= n)),
+              AVS_E_SHAPE, "avs_conv1x1_bn_bf16: k, n and every stride must be multiples of 8 elements (16 bytes)");
+  AVS_REQUIRE(avs_aligned16(d_x) && avs_aligned16(d_w) && avs_aligned16(d_y) && avs_aligned16(d_residual),
+              AVS_E_ALIGN, "avs_conv1x1_bn_bf16: operands must be 16-byte aligned");
+  ConvBnParams p{};
+  p.x = (const char*)d_x;
+  p.w = (const char*)d_w;
+  p.y = (char*)d_y;
+  p.res = (const char*)d_residual;
+  p.gamma = d_gamma;
+  p.beta = d_beta;
+  p.eps = eps;
+  p.N = n;
+  p.K = k;
+  p.lin_stride = lin_stride;
+  p.ldb = ldb;
+  p.ldc = ldc;
+  p.ldr = ldr;
+  p.rows_per_group = (int)rows_per_group;
+  p.groups = groups;
+  p.relu = relu;
+  const bool narrow = n <= 64;
+  const int bn = narrow ? 64 : 128;
+  p.tiles_n = (n + bn - 1) / bn;
+  const long long total = (long long)groups * p.tiles_n;
+  AVS_REQUIRE(total < (1ll << 31), AVS_E_SHAPE, "avs_conv1x1_bn_bf16: too many workgroups");
+  if (narrow)
+    hipLaunchKernelGGL(conv1x1_bn_kernel<64>, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(conv1x1_bn_kernel<128>, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, p);
+  AVS_CHECK_LAUNCH("avs_conv1x1_bn_bf16");
+  return AVS_OK;
+}

@@ -27,7 +27,7 @@ class LaunchProfiler:
     events are recorded on the stream the kernel is launched on, read back after a synchronize."""
 
     def __init__(self):
-        self.records = []  # (kind, dtype_code, algorithmic_flops, start_event, end_event)
+        self.records = []  # (kind, dtype_code, algorithmic work: FLOPs for conv/gemm, bytes for bn_apply, start, end)
 
     def summary(self):
         torch.cuda.synchronize()
@@ -231,10 +231,13 @@ def bn_apply(x2d, scale, shift, group_rows=None, max_group_rows=0, residual=None
     if out is None:
         out = torch.empty((rows, c), dtype=x2d.dtype, device=x2d.device)
     g = group_rows.numel() - 1 if group_rows is not None else 0
-    check(lib().avs_bn_apply(dtype_code(x2d.dtype), _p(x2d), rows, c, x2d.stride(0), _p(group_rows), g,
-                             int(max_group_rows), _p(scale), _p(shift), _p(residual),
-                             residual.stride(0) if residual is not None else 0, act, _p(out), out.stride(0),
-                             _stream()), "avs_bn_apply")
+    # algorithmic bytes: read x (+ residual), write y
+    nbytes = float(rows) * c * x2d.element_size() * (3 if residual is not None else 2)
+    _timed("bn_apply", dtype_code(x2d.dtype), nbytes, lambda: check(
+        lib().avs_bn_apply(dtype_code(x2d.dtype), _p(x2d), rows, c, x2d.stride(0), _p(group_rows), g,
+                           int(max_group_rows), _p(scale), _p(shift), _p(residual),
+                           residual.stride(0) if residual is not None else 0, act, _p(out), out.stride(0),
+                           _stream()), "avs_bn_apply"))
     return out
 
 

@@ -33,6 +33,8 @@ if ROOT not in sys.path:
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_F32_PEAK_TFLOPS = 157.3
+HBM_PEAK_GBS = 8000.0
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
 RESNET50_FLOP_PER_FRAME = 2 * 4.0878e9
 
 
@@ -98,7 +100,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--extractor", default="resnet50", choices=["resnet50", "resnet50+inception3"])
     ap.add_argument("--chunk", type=int, default=1024)
-    ap.add_argument("--cpu-sample", type=int, default=48, help="frames for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=512, help="frames for the CPU baseline (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--short-k-bytes", type=int, default=None, help="tuning: avs_tune_short_reduction_bytes")
     args = ap.parse_args()
@@ -193,12 +195,30 @@ def main():
             if conv and conv["ms"] > 0:
                 achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
                 peak = MFMA_BF16_PEAK_TFLOPS if dtype == torch.bfloat16 else MFMA_F32_PEAK_TFLOPS
-                roofline = {"bound": "mfma", "kernel": "igemm_kernel (avs_conv2d_nhwc)", "achieved": round(achieved, 2),
-                            "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                # HBM bytes per launch from the separate rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
+                # KiB -> bytes), summarised by profiles/summarize_pmc.py; null when no such summary is committed
+                traffic = None
+                if os.path.exists(PMC_TRAFFIC_FILE):
+                    try:
+                        traffic = json.load(open(PMC_TRAFFIC_FILE)).get("igemm_kernel", {}).get("hbm_bytes_per_launch")
+                    except (OSError, ValueError):
+                        traffic = None
+                roofline = {"bound": "mfma", "kernel": "igemm_kernel (avs_conv2d_nhwc[_bnstats])",
+                            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                            "frac": round(achieved / peak, 4), "traffic": traffic,
                             "launches": conv["launches"],
                             "avg_launch_us": round(conv["ms"] * 1e3 / conv["launches"], 2),
                             "algorithmic_flop_per_launch": round(conv["flops"] / conv["launches"], 1),
-                            "conv_share_of_step": round(conv["ms"] * 1e-3 / elapsed, 3)}
+                            "share_of_step": round(conv["ms"] * 1e-3 / elapsed, 3)}
+            bn = summ.get(("bn_apply", code))
+            if roofline is not None and bn and bn["ms"] > 0:
+                gbs = bn["flops"] / (bn["ms"] * 1e-3) / 1e9
+                roofline["second_kernel"] = {"bound": "hbm", "kernel": "bn_apply_kernel (avs_bn_apply)",
+                                             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": round(gbs / HBM_PEAK_GBS, 4), "launches": bn["launches"],
+                                             "avg_launch_us": round(bn["ms"] * 1e3 / bn["launches"], 2),
+                                             "algorithmic_bytes_per_launch": round(bn["flops"] / bn["launches"], 1),
+                                             "share_of_step": round(bn["ms"] * 1e-3 / elapsed, 3)}
         cpu = None
         if sd_cpu is not None:
             log(f"timed region {elapsed:.2f}s; CPU baseline on {args.cpu_sample} frames")

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Summarise the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; --output-format csv) into HBM bytes per
+launch per kernel, with the gfx950 corrections of /opt/skills/guides/MI355X_MICROARCH.md (HBM section):
+FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads => x2; both counters are in KiB.
+
+    python profiles/summarize_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+"""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def load(path, counter):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = re.sub(r"<.*", "", r["Kernel_Name"].replace("void ", "")).split("(")[0]
+        agg[name][0] += 1
+        agg[name][1] += float(r["Counter_Value"])
+    return agg
+
+
+def main():
+    fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in sorted(fetch, key=lambda k: -fetch[k][1]):
+        n = fetch[k][0]
+        w = write.get(k, [0, 0.0])[1]
+        out[k] = {"launches": n, "fetch_kib_raw": round(fetch[k][1], 1), "write_kib": round(w, 1),
+                  "hbm_bytes_per_launch": round((2.0 * fetch[k][1] + w) * 1024.0 / n, 1)}
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    for k, v in list(out.items())[:10]:
+        print(k, v)
+
+
+if __name__ == "__main__":
+    main()
