@@ -42,6 +42,8 @@ _SIGNATURES = {
     "avs_conv2d_nhwc": (c_int, [POINTER(ConvDesc), P, P, P, P, P]),
     "avs_conv2d_nhwc_bnstats": (c_int, [POINTER(ConvDesc), P, P, P, c_int64, P, P, P]),
     "avs_bn_finalize": (c_int, [P, P, c_int, c_int, c_int64, P, P, c_float, P, P, P]),
+    "avs_conv1x1_bn_bf16": (c_int, [P, c_int64, c_int, P, c_int64, c_int, c_int64, c_int, P, P, c_float, P, c_int64,
+                                    c_int, P, c_int64, P]),
     "avs_tune_short_reduction_bytes": (None, [c_int]),
     "avs_debug_flags": (None, [c_int]),
     "avs_gemm_nt": (c_int, [c_int, c_int, c_int, c_int, P, c_int64, c_int64, P, c_int64, c_int64, P, c_int64,

@@ -97,6 +97,8 @@ class ResNet50Runner:
         if bn_mode not in ("batch", "folded"):
             raise ValueError("bn_mode must be 'batch' (reference-faithful) or 'folded'")
         self.trunk, self.dtype, self.bn_mode = trunk, dtype, bn_mode
+        self.fuse_conv_bn = True
+        self.fuse_min_rows, self.fuse_ratio_num, self.fuse_ratio_den = 128, 2, 1
         self._key = None
         self._w = None
 
@@ -124,6 +126,27 @@ class ResNet50Runner:
                 w["blocks"].append(d)
         self._w, self._key = w, key
         return w
+
+    def _conv1x1_bn(self, x, wt, cout, bnp, groups, hw, residual=None, relu=True):
+        """1x1 / stride-1 convolution + BatchNorm.  bf16 with equal-sized groups of >= 128 rows: one kernel
+        (statistics and normalised output in two passes over L2-resident operands, nothing raw in HBM);
+        otherwise the generic convolution + statistics + apply sequence."""
+        n, h, w_, cin = x.shape
+        grows, gmax, uniform = groups[hw]
+        # measured on MI355X: the one-kernel form wins where the layer is write-heavy (cout >= 2*cin: the conv3 /
+        # downsample layers) and a group is several row tiles long; it ties or loses on the wide-input conv1s
+        if (self.bn_mode == "batch" and uniform and self.dtype == torch.bfloat16 and self.fuse_conv_bn
+                and gmax >= self.fuse_min_rows and cout * self.fuse_ratio_den >= cin * self.fuse_ratio_num):
+            gamma, beta, eps, _, _ = bnp
+            y = torch.empty((n, h, w_, cout), dtype=self.dtype, device=x.device)
+            ops.conv1x1_bn(x.view(-1, cin), wt, gmax, gamma, beta, eps, y.view(-1, cout), residual, relu)
+            return y
+
+        def run(bnstats):
+            y = torch.empty((n, h, w_, cout), dtype=self.dtype, device=x.device)
+            r = ops.conv2d(x, wt, 1, 1, 1, 0, y, bnstats=bnstats)
+            return y, (r if bnstats is not None else None)
+        return self._conv_bn(run, cout, bnp, groups, hw, residual, relu)
 
     def _conv_bn(self, conv, c, bnp, groups, hw, residual=None, relu=True):
         """Convolution `conv(bnstats) -> raw NHWC output` followed by BatchNorm (+residual, +ReLU), in place.
@@ -201,16 +224,18 @@ class ResNet50Runner:
             s, planes = blk["stride"], blk["planes"]
             cin = x.shape[3]
             hout = hcur // s
-            t1 = self._conv_bn(conv_op(x, blk["c1"], 1, 1, 0, planes, hcur), planes, blk["b1"], groups, hcur * hcur)
+            t1 = self._conv1x1_bn(x, blk["c1"], planes, blk["b1"], groups, hcur * hcur)
             t2 = self._conv_bn(conv_op(t1, blk["c2"], 3, s, 1, planes, hout), planes, blk["b2"], groups, hout * hout)
             del t1
-            if "cd" in blk:
+            if "cd" in blk and s == 1:
+                idn = self._conv1x1_bn(x, blk["cd"], planes * 4, blk["bd"], groups, hout * hout,
+                                       relu=False).view(-1, planes * 4)
+            elif "cd" in blk:
                 idn = self._conv_bn(conv_op(x, blk["cd"], 1, s, 0, planes * 4, hout), planes * 4, blk["bd"], groups,
                                     hout * hout, relu=False).view(-1, planes * 4)
             else:
                 idn = x.view(-1, cin)
-            x = self._conv_bn(conv_op(t2, blk["c3"], 1, 1, 0, planes * 4, hout), planes * 4, blk["b3"], groups,
-                              hout * hout, residual=idn, relu=True)
+            x = self._conv1x1_bn(t2, blk["c3"], planes * 4, blk["b3"], groups, hout * hout, residual=idn, relu=True)
             del t2, idn
             hcur = hout
         return ops.global_avgpool(x, out)

@@ -19,7 +19,7 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-extern __device__ unsigned int avs_zero16[4];  // igemm.hip
+__device__ __attribute__((aligned(16))) unsigned int avs_zero16_cb[4];  // zero source for padded lanes
 
 struct ConvBnParams {
   const char* x;
@@ -50,6 +50,9 @@ __global__ __launch_bounds__(256, 3) void conv1x1_bn_kernel(ConvBnParams p) {
   constexpr int LDS_SLOTS = 2 * BUF > CT_SLOTS ? 2 * BUF : CT_SLOTS;
   constexpr int CPRW = BN / 8, RSTEP = 256 / CPRW;
 
+  // (A variant that kept the (tile, step) sequence as one continuous pipeline — next tile's first DMA issued
+  // before the current epilogue, staging area not aliased — needed > 168 VGPRs and lost more to the drop
+  // from 3 to 2 workgroups per CU than it won: 29.9 k vs 32.1 k frames/s end to end.)
   __shared__ uint4 lds[LDS_SLOTS];
   __shared__ float red[2][BN][2];
 
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(256, 3) void conv1x1_bn_kernel(ConvBnParams p) {
 
   const char* __restrict__ x = p.x;
   const char* __restrict__ w = p.w;
-  const char* zsrc = reinterpret_cast<const char*>(avs_zero16);
+  const char* zsrc = reinterpret_cast<const char*>(avs_zero16_cb);
 
   const int t = threadIdx.x;
   const int wave = t >> 6, lane = t & 63;

@@ -11,7 +11,7 @@ from . import _abi
 from ._abi import ACT_NONE, ACT_RELU, AVS_BF16, AVS_F32, BIAS_COL, BIAS_NONE, BIAS_ROW, check, lib
 
 __all__ = [
-    "ACT_NONE", "ACT_RELU", "linear", "gemm_nt_batched", "conv2d", "conv2d_raw", "frames_normalize", "resize_bilinear",
+    "ACT_NONE", "ACT_RELU", "linear", "gemm_nt_batched", "conv2d", "conv2d_raw", "conv1x1_bn", "frames_normalize", "resize_bilinear",
     "bn_batch_stats", "bn_apply", "pool2d", "global_avgpool", "segment_mean", "reflect_pad", "stft_f64", "power_mel",
     "clamp_topdb", "fill", "lstm", "mha_batchaxis", "score_head", "softmax_rows", "cdist", "dtw_path",
     "gather_scale", "dtype_code",
@@ -157,6 +157,30 @@ def conv2d_raw(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x, x_i
     check(lib().avs_bn_finalize(_p(ssum), _p(ssq), groups, cout, rpg, _p(gamma), _p(beta), float(eps), _p(scale),
                                 _p(shift), _stream()), "avs_bn_finalize")
     return scale, shift
+
+
+def conv1x1_bn(x2d, wt, rows_per_group, gamma, beta, eps, out2d, residual=None, relu=True):
+    """Fused 1x1 convolution + batch-statistics BatchNorm (+residual, +ReLU), bf16.  x2d [rows, K] (rows =
+    groups * rows_per_group), wt [N, K], out2d [rows, N]; every tensor row-major with unit column stride."""
+    _dev(x2d, wt, out2d, residual, gamma, beta)
+    _rowmajor2d(x2d, "x")
+    _rowmajor2d(wt, "w")
+    _rowmajor2d(out2d, "out")
+    rows, k = x2d.shape
+    n = wt.shape[0]
+    if x2d.dtype != torch.bfloat16 or wt.dtype != torch.bfloat16 or out2d.dtype != torch.bfloat16:
+        raise TypeError("conv1x1_bn is the bf16 throughput path")
+    if rows % rows_per_group or wt.shape[1] != k or out2d.shape != (rows, n):
+        raise ValueError("conv1x1_bn: shapes do not match")
+    if residual is not None:
+        _rowmajor2d(residual, "residual")
+    groups = rows // rows_per_group
+    _timed("conv", AVS_BF16, 2.0 * rows * n * k, lambda: check(
+        lib().avs_conv1x1_bn_bf16(_p(x2d), x2d.stride(0), k, _p(wt), wt.stride(0), n, rows_per_group, groups,
+                                  _p(gamma), _p(beta), float(eps), _p(residual),
+                                  residual.stride(0) if residual is not None else 0, 1 if relu else 0, _p(out2d),
+                                  out2d.stride(0), _stream()), "avs_conv1x1_bn_bf16"))
+    return out2d
 
 
 def conv2d(x, wt, kh, kw, stride, pad, out, bias=None, act=ACT_NONE, bnstats=None):

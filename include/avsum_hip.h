@@ -96,6 +96,18 @@ int avs_bn_finalize(const float* d_sum, const float* d_sumsq, int groups, int c,
                     const float* d_gamma, const float* d_beta, float eps, float* d_scale, float* d_shift,
                     avs_stream_t stream);
 
+/* 1x1 convolution + batch-statistics BatchNorm (+ residual, + ReLU) in one kernel, bf16, for equal-sized
+ * groups of rows_per_group consecutive rows (a micro-batch of frames at one resolution):
+ *   y[m,:] = act( bn_g(x[m,:] . w^T) + residual[m,:] ),  statistics of group g = m / rows_per_group.
+ * One workgroup owns a whole group for a slab of channels and walks it twice (statistics, then the
+ * normalised output), so the raw convolution never goes to HBM: replaces avs_conv2d_nhwc_bnstats +
+ * avs_bn_finalize + avs_bn_apply for the 1x1 layers of the train-mode ResNet trunk
+ * (features/extractors.py:65).  x rows at stride lin_stride; k, n and strides multiples of 8 elements.    */
+int avs_conv1x1_bn_bf16(const void* d_x, int64_t lin_stride, int k, const void* d_w, int64_t ldb, int n,
+                        int64_t rows_per_group, int groups, const float* d_gamma, const float* d_beta,
+                        float eps, const void* d_residual, int64_t ldr, int relu, void* d_y, int64_t ldc,
+                        avs_stream_t stream);
+
 /* Tuning knob (process-wide, not thread-safe): reductions of at most `bytes` bytes per output row run with
  * 64-byte LDS rows / 3 workgroups per CU instead of 128-byte rows / 2 workgroups per CU.  Default: always. */
 void avs_tune_short_reduction_bytes(int bytes);

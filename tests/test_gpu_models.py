@@ -146,6 +146,37 @@ def test_conv_bnstats_epilogue_matches_separate_pass(dev):
             assert (sh1 - sh2).abs().max().item() < tol * max(1.0, sh2.abs().max().item())
 
 
+@pytest.mark.parametrize("rpg,k,n,with_res,relu", [(196, 256, 1024, True, True), (3136, 64, 256, True, True),
+                                                     (784, 512, 128, False, True), (300, 64, 64, False, False),
+                                                     (128, 128, 200, True, False)])
+def test_conv1x1_bn_one_kernel(dev, rpg, k, n, with_res, relu):
+    """The one-kernel 1x1 conv + batch-stat BN (+residual, +ReLU) against the same arithmetic in fp32 on the
+    bf16-rounded operands; bf16 output => compare to ~2 bf16 ulps of the output scale."""
+    from avsum_amd import ops
+    g = torch.Generator().manual_seed(rpg + k)
+    groups = 3
+    rows = groups * rpg
+    x = (torch.randn(rows, k, generator=g) + 0.3).bfloat16()
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).bfloat16()
+    gamma, beta = torch.rand(n, generator=g) + 0.5, torch.randn(n, generator=g)
+    res = torch.randn(rows, n, generator=g).bfloat16() if with_res else None
+    raw = x.float() @ w.float().t()
+    ref = torch.empty(rows, n)
+    for gi in range(groups):
+        blk = raw[gi * rpg:(gi + 1) * rpg]
+        mean, var = blk.mean(0), blk.var(0, unbiased=False)
+        ref[gi * rpg:(gi + 1) * rpg] = (blk - mean) / torch.sqrt(var + 1e-5) * gamma + beta
+    if with_res:
+        ref = ref + res.float()
+    if relu:
+        ref = torch.relu(ref)
+    out = torch.empty(rows, n, dtype=torch.bfloat16, device=dev)
+    ops.conv1x1_bn(x.to(dev), w.to(dev), rpg, gamma.to(dev), beta.to(dev), 1e-5, out,
+                   res.to(dev) if with_res else None, relu)
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert err < 0.03 * max(1.0, ref.abs().max().item()), err
+
+
 @pytest.mark.parametrize("groups", [[0, 4, 8], [0, 4, 7, 8]])
 def test_resnet50_bf16_close_to_fp32(dev, groups):
     """bf16 throughput mode (equal groups: statistics fused into the convolution epilogue; ragged groups:
