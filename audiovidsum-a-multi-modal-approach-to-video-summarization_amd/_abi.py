@@ -67,6 +67,13 @@ _SIGNATURES = {
     "avs_mha_batchaxis_f32": (c_int, [P, c_int, c_int, c_int, c_int, P, P]),
     "avs_score_head_f32": (c_int, [P, c_int64, c_int, c_int64, P, P, P, P]),
     "avs_softmax_rows_f32": (c_int, [P, c_int64, c_int, c_int64, P]),
+    "avs_transpose_f32": (c_int, [P, c_int, c_int, c_int64, P, c_int64, P]),
+    "avs_colsum_f32": (c_int, [P, c_int64, c_int, c_int64, P, P, P]),
+    "avs_relu_dropout_bwd_f32": (c_int, [P, P, P, c_int64, P, P]),
+    "avs_mul_f32": (c_int, [P, P, c_int64, P, P]),
+    "avs_score_head_bwd_f32": (c_int, [P, P, P, c_int64, c_int, c_int64, P, P, P, P]),
+    "avs_lstm_train_fwd_f32": (c_int, [P, P, c_int, c_int, c_uint, P, c_int, P, c_int64, c_int, P, P, P]),
+    "avs_lstm_bwd_f32": (c_int, [P, c_int64, c_int, P, P, P, c_int, c_int, c_uint, P, c_int, P, P]),
     "avs_cdist_f64": (c_int, [P, c_int, P, c_int, c_int, P, P]),
     "avs_dtw_workspace_bytes": (c_int64, [c_int, c_int]),
     "avs_dtw_path_f64": (c_int, [P, c_int, c_int, P, c_int64, P, P, P, P]),

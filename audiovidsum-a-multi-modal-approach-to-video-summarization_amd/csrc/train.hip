@@ -1,0 +1,353 @@
+// Backward-pass kernels of the importance scorer (scripts/train_av_model.py:86-96).
+// The dense parts of the backward (dX = dY.W, dW = dY^T.X) reuse avs_gemm_nt on transposed copies made by
+// avs_transpose_f32; this file holds the rest: transposes, column sums (bias gradients), the element-wise
+// gradient gates and the LSTM backward-through-time recurrence.
+#include "avs_internal.h"
+#include <math.h>
+
+// ---------------------------------------------------------------------------
+// dst[c, r] = src[r, c]  (32x32 LDS tile, padded against bank conflicts).  Columns r >= rows of dst are left
+// untouched: the caller zero-fills a buffer whose row stride is padded to 16 bytes.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, int rows, int cols,
+                                                        long long lds_, float* __restrict__ dst, long long ldd) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    if (r < rows && c < cols) tile[ty + 8 * i][tx] = src[(long long)r * lds_ + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (r < rows && c < cols) dst[(long long)c * ldd + r] = tile[tx][ty + 8 * i];
+  }
+}
+
+extern "C" int avs_transpose_f32(const float* d_src, int rows, int cols, int64_t ld_src, float* d_dst, int64_t ld_dst,
+                                 avs_stream_t stream) {
+  AVS_REQUIRE(rows >= 0 && cols >= 0 && ld_src >= cols && ld_dst >= rows, AVS_E_SHAPE,
+              "avs_transpose_f32: rows=%d cols=%d ld_src=%lld ld_dst=%lld", rows, cols, (long long)ld_src,
+              (long long)ld_dst);
+  if (rows == 0 || cols == 0) return AVS_OK;
+  AVS_REQUIRE(d_src && d_dst, AVS_E_ARG, "avs_transpose_f32: null pointer");
+  dim3 grid((unsigned)avs_cdiv(cols, 32), (unsigned)avs_cdiv(rows, 32));
+  AVS_REQUIRE(grid.y <= 65535, AVS_E_SHAPE, "avs_transpose_f32: too many rows");
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_src, rows, cols, (long long)ld_src,
+                     d_dst, (long long)ld_dst);
+  AVS_CHECK_LAUNCH("avs_transpose_f32");
+  return AVS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// out[c] = sum_r x[r, c] * (w ? w[r] : 1): one block per 64 columns, 4 row-waves, fixed summation order
+// (deterministic).  Bias gradients and the weighted sum of the scoring head.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long long rows, int cols,
+                                                     long long ld, const float* __restrict__ w,
+                                                     float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  float a = 0.f;
+  if (c < cols)
+    for (long long r = wave; r < rows; r += 4) a = fmaf(x[r * ld + c], w ? w[r] : 1.f, a);
+  red[wave][lane] = a;
+  __syncthreads();
+  if (wave == 0 && c < cols) out[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+extern "C" int avs_colsum_f32(const float* d_x, int64_t rows, int cols, int64_t ld, const float* d_row_weight,
+                              float* d_out, avs_stream_t stream) {
+  AVS_REQUIRE(rows >= 0 && cols > 0 && ld >= cols, AVS_E_SHAPE, "avs_colsum_f32: rows=%lld cols=%d ld=%lld",
+              (long long)rows, cols, (long long)ld);
+  AVS_REQUIRE(d_x && d_out, AVS_E_ARG, "avs_colsum_f32: null pointer");
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)avs_cdiv(cols, 64)), dim3(256), 0, (hipStream_t)stream, d_x,
+                     (long long)rows, cols, (long long)ld, d_row_weight, d_out);
+  AVS_CHECK_LAUNCH("avs_colsum_f32");
+  return AVS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Gradient gate of Linear -> ReLU -> Dropout:  dpre = dy * (keep ? keep[i] : 1) * (y_relu[i] > 0)
+// (keep = the inverted-dropout multiplier mask/(1-p) that the forward applied).  Also the forward
+// y = x * keep when dy == nullptr is not needed: dropout forward is avs_mul_f32.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void relu_drop_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ yr,
+                                                            const float* __restrict__ keep, long long n,
+                                                            float* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float g = dy[i];
+    if (keep) g *= keep[i];
+    out[i] = yr[i] > 0.f ? g : 0.f;
+  }
+}
+
+extern "C" int avs_relu_dropout_bwd_f32(const float* d_dy, const float* d_relu_out, const float* d_keep, int64_t n,
+                                        float* d_out, avs_stream_t stream) {
+  AVS_REQUIRE(n >= 0, AVS_E_SHAPE, "avs_relu_dropout_bwd_f32: negative size");
+  if (n == 0) return AVS_OK;
+  AVS_REQUIRE(d_dy && d_relu_out && d_out, AVS_E_ARG, "avs_relu_dropout_bwd_f32: null pointer");
+  long long gx = avs_cdiv(n, 256);
+  if (gx > 8192) gx = 8192;
+  hipLaunchKernelGGL(relu_drop_bwd_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, d_dy, d_relu_out,
+                     d_keep, (long long)n, d_out);
+  AVS_CHECK_LAUNCH("avs_relu_dropout_bwd_f32");
+  return AVS_OK;
+}
+
+__global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  long long n, float* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    out[i] = a[i] * b[i];
+}
+
+extern "C" int avs_mul_f32(const float* d_a, const float* d_b, int64_t n, float* d_out, avs_stream_t stream) {
+  AVS_REQUIRE(n >= 0, AVS_E_SHAPE, "avs_mul_f32: negative size");
+  if (n == 0) return AVS_OK;
+  AVS_REQUIRE(d_a && d_b && d_out, AVS_E_ARG, "avs_mul_f32: null pointer");
+  long long gx = avs_cdiv(n, 256);
+  if (gx > 8192) gx = 8192;
+  hipLaunchKernelGGL(mul_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, d_a, d_b, (long long)n, d_out);
+  AVS_CHECK_LAUNCH("avs_mul_f32");
+  return AVS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Scoring head backward: s = sigmoid(hid . w2 + b2).  dz[r] = ds[r] * s[r] * (1 - s[r]);
+// dhid_pre[r, k] = dz[r] * w2[k] * (hid[r, k] > 0)   (hid is the ReLU output of scorer.0).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void score_head_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ s,
+                                                             const float* __restrict__ hid, long long rows, int d,
+                                                             long long ldh, const float* __restrict__ w2,
+                                                             float* __restrict__ dz, float* __restrict__ dhid_pre) {
+  const long long total = rows * d;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / d;
+    const int k = (int)(i - r * d);
+    const float sv = s[r];
+    const float z = ds[r] * sv * (1.f - sv);
+    if (k == 0) dz[r] = z;
+    dhid_pre[r * d + k] = hid[r * ldh + k] > 0.f ? z * w2[k] : 0.f;
+  }
+}
+
+extern "C" int avs_score_head_bwd_f32(const float* d_dscores, const float* d_scores, const float* d_hid, int64_t rows,
+                                      int d, int64_t ldh, const float* d_w2, float* d_dz, float* d_dhid_pre,
+                                      avs_stream_t stream) {
+  AVS_REQUIRE(rows >= 0 && d > 0 && ldh >= d, AVS_E_SHAPE, "avs_score_head_bwd_f32: bad extents");
+  if (rows == 0) return AVS_OK;
+  AVS_REQUIRE(d_dscores && d_scores && d_hid && d_w2 && d_dz && d_dhid_pre, AVS_E_ARG,
+              "avs_score_head_bwd_f32: null pointer");
+  long long gx = avs_cdiv(rows * d, 256);
+  if (gx > 8192) gx = 8192;
+  hipLaunchKernelGGL(score_head_bwd_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, d_dscores,
+                     d_scores, d_hid, (long long)rows, d, (long long)ldh, d_w2, d_dz, d_dhid_pre);
+  AVS_CHECK_LAUNCH("avs_score_head_bwd_f32");
+  return AVS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// LSTM forward that also saves what the backward needs (post-activation gates i,f,g,o and the cell state).
+// Same thread layout as lstm_kernel (scorer.hip).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(1024) void lstm_train_fwd_kernel(const float* __restrict__ xproj,
+                                                              const float* __restrict__ whh_t, int H, int ndir,
+                                                              unsigned reverse_mask,
+                                                              const int64_t* __restrict__ seq_rows,
+                                                              float* __restrict__ out, long long ldo, int out_col0,
+                                                              float* __restrict__ gates, float* __restrict__ cell,
+                                                              int KQ, int kpq) {
+  extern __shared__ float sm[];
+  const int G = 4 * H, RV = H;
+  float* h_s = sm;
+  float* part = sm + H;
+  const int seq = blockIdx.x, dir = blockIdx.y;
+  const long long r0 = seq_rows[seq], r1 = seq_rows[seq + 1];
+  const long long T = r1 - r0;
+  const bool rev = (reverse_mask >> dir) & 1u;
+  const float* __restrict__ W = whh_t + (long long)dir * H * G;
+  const long long ldx = (long long)ndir * G;
+  const float* __restrict__ xp = xproj + (long long)dir * G;
+  const int tid = threadIdx.x;
+  const int kq = tid / RV, jv = tid - kq * RV;
+  const bool mv = kq < KQ;
+  const int k0 = kq * kpq;
+  const int k1 = (k0 + kpq) < H ? (k0 + kpq) : H;
+  float c_state = 0.f;
+  if (tid < H) h_s[tid] = 0.f;
+  __syncthreads();
+  for (long long s = 0; s < T; ++s) {
+    const long long row = rev ? (r1 - 1 - s) : (r0 + s);
+    float xi = 0.f, xf = 0.f, xg = 0.f, xo = 0.f;
+    if (tid < H) {
+      const float* xr = xp + row * ldx;
+      xi = xr[tid];
+      xf = xr[H + tid];
+      xg = xr[2 * H + tid];
+      xo = xr[3 * H + tid];
+    }
+    if (mv) {
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4* wp = reinterpret_cast<const float4*>(W) + (long long)k0 * RV + jv;
+#pragma unroll 8
+      for (int k = k0; k < k1; ++k) {
+        const float4 wv = *wp;
+        wp += RV;
+        const float hk = h_s[k];
+        a.x = fmaf(wv.x, hk, a.x);
+        a.y = fmaf(wv.y, hk, a.y);
+        a.z = fmaf(wv.z, hk, a.z);
+        a.w = fmaf(wv.w, hk, a.w);
+      }
+      reinterpret_cast<float4*>(part + (long long)kq * G)[jv] = a;
+    }
+    __syncthreads();
+    if (tid < H) {
+      float gi = xi, gf = xf, gg = xg, go = xo;
+      for (int q = 0; q < KQ; ++q) {
+        const float* pq = part + q * G;
+        gi += pq[tid];
+        gf += pq[H + tid];
+        gg += pq[2 * H + tid];
+        go += pq[3 * H + tid];
+      }
+      const float ig = sigm(gi), fg = sigm(gf), cg = tanhf(gg), og = sigm(go);
+      c_state = fg * c_state + ig * cg;
+      const float hv = og * tanhf(c_state);
+      h_s[tid] = hv;
+      out[row * ldo + out_col0 + dir * H + tid] = hv;
+      float* gr = gates + row * ldx + (long long)dir * G;
+      gr[tid] = ig;
+      gr[H + tid] = fg;
+      gr[2 * H + tid] = cg;
+      gr[3 * H + tid] = og;
+      cell[row * ((long long)ndir * H) + dir * H + tid] = c_state;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int avs_lstm_train_fwd_f32(const float* d_xproj, const float* d_whh_t, int hidden, int ndir,
+                                      unsigned reverse_mask, const int64_t* d_seq_rows, int nseq, float* d_out,
+                                      int64_t ldo, int out_col0, float* d_gates, float* d_cell, avs_stream_t stream) {
+  AVS_REQUIRE(hidden > 0 && hidden <= 1024 && ndir > 0 && ndir <= 32 && nseq >= 0 && out_col0 >= 0 &&
+                  ldo >= out_col0 + (int64_t)ndir * hidden,
+              AVS_E_SHAPE, "avs_lstm_train_fwd_f32: bad extents");
+  if (nseq == 0) return AVS_OK;
+  AVS_REQUIRE(d_xproj && d_whh_t && d_seq_rows && d_out && d_gates && d_cell, AVS_E_ARG,
+              "avs_lstm_train_fwd_f32: null pointer");
+  int KQ = 1024 / hidden;
+  if (KQ > hidden) KQ = hidden;
+  if (KQ < 1) KQ = 1;
+  const int kpq = (hidden + KQ - 1) / KQ;
+  const size_t shmem = ((size_t)hidden + (size_t)KQ * 4 * hidden) * sizeof(float);
+  hipLaunchKernelGGL(lstm_train_fwd_kernel, dim3(nseq, ndir), dim3(1024), shmem, (hipStream_t)stream, d_xproj,
+                     d_whh_t, hidden, ndir, reverse_mask, d_seq_rows, d_out, (long long)ldo, out_col0, d_gates, d_cell,
+                     KQ, kpq);
+  AVS_CHECK_LAUNCH("avs_lstm_train_fwd_f32");
+  return AVS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// LSTM backward through time.  One workgroup per (sequence, direction), steps in reverse processing order.
+//   dh = dout[t] + W_hh^T . da_{next};  do = dh*tanh(c);  dc = dh*o*(1-tanh(c)^2) + dc_next;
+//   di = dc*g; dg = dc*i; df = dc*c_prev;  dc_next = dc*f;
+//   da = [di*i(1-i), df*f(1-f), dg*(1-g^2), do*o(1-o)]   -> d_dxproj[t]
+// W_hh in its ORIGINAL layout [dir][4H][H]: dh_next[k] = sum_j W_hh[j][k] * da[j] reads rows j with lanes over k.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void lstm_bwd_kernel(const float* __restrict__ dout, long long ldo, int out_col0,
+                                                        const float* __restrict__ gates,
+                                                        const float* __restrict__ cell,
+                                                        const float* __restrict__ whh, int H, int ndir,
+                                                        unsigned reverse_mask,
+                                                        const int64_t* __restrict__ seq_rows,
+                                                        float* __restrict__ dxproj, int JQ, int jpq) {
+  extern __shared__ float sm[];
+  const int G = 4 * H;
+  float* da_s = sm;          // [G]
+  float* part = sm + G;      // [JQ][H]
+  const int seq = blockIdx.x, dir = blockIdx.y;
+  const long long r0 = seq_rows[seq], r1 = seq_rows[seq + 1];
+  const long long T = r1 - r0;
+  const bool rev = (reverse_mask >> dir) & 1u;
+  const float* __restrict__ W = whh + (long long)dir * G * H;
+  const long long ldg = (long long)ndir * G, ldc = (long long)ndir * H;
+  const int tid = threadIdx.x;
+  // matvec layout: thread = (slice jq of the 4H gate rows, hidden unit k)
+  const int jq = tid / H, kk = tid - jq * H;
+  const bool mv = jq < JQ;
+  const int j0 = jq * jpq;
+  const int j1 = (j0 + jpq) < G ? (j0 + jpq) : G;
+  float dc_next = 0.f, dh_next = 0.f;
+  for (long long s = T - 1; s >= 0; --s) {
+    const long long row = rev ? (r1 - 1 - s) : (r0 + s);
+    if (tid < H) {
+      const long long prow = rev ? row + 1 : row - 1;  // the step processed just before this one in the forward
+      const float c_prev = s > 0 ? cell[prow * ldc + dir * H + tid] : 0.f;
+      const float* gr = gates + row * ldg + (long long)dir * G;
+      const float ig = gr[tid], fg = gr[H + tid], cg = gr[2 * H + tid], og = gr[3 * H + tid];
+      const float c = cell[row * ldc + dir * H + tid];
+      const float tc = tanhf(c);
+      const float dh = dout[row * ldo + out_col0 + dir * H + tid] + dh_next;
+      const float d_o = dh * tc;
+      const float dc = dh * og * (1.f - tc * tc) + dc_next;
+      const float d_i = dc * cg, d_g = dc * ig, d_f = dc * c_prev;
+      dc_next = dc * fg;
+      const float ai = d_i * ig * (1.f - ig), af = d_f * fg * (1.f - fg), ag = d_g * (1.f - cg * cg),
+                  ao = d_o * og * (1.f - og);
+      da_s[tid] = ai;
+      da_s[H + tid] = af;
+      da_s[2 * H + tid] = ag;
+      da_s[3 * H + tid] = ao;
+      float* dx = dxproj + row * ldg + (long long)dir * G;
+      dx[tid] = ai;
+      dx[H + tid] = af;
+      dx[2 * H + tid] = ag;
+      dx[3 * H + tid] = ao;
+    }
+    __syncthreads();
+    if (mv) {
+      float a = 0.f;
+      const float* wp = W + (long long)j0 * H + kk;
+#pragma unroll 8
+      for (int j = j0; j < j1; ++j) {
+        a = fmaf(*wp, da_s[j], a);
+        wp += H;
+      }
+      part[jq * H + kk] = a;
+    }
+    __syncthreads();
+    if (tid < H) {
+      float a = 0.f;
+      for (int q = 0; q < JQ; ++q) a += part[q * H + tid];
+      dh_next = a;
+    }
+    // part / da_s are rewritten only after the next barrier pair
+  }
+}
+
+extern "C" int avs_lstm_bwd_f32(const float* d_dout, int64_t ldo, int out_col0, const float* d_gates,
+                                const float* d_cell, const float* d_whh, int hidden, int ndir, unsigned reverse_mask,
+                                const int64_t* d_seq_rows, int nseq, float* d_dxproj, avs_stream_t stream) {
+  AVS_REQUIRE(hidden > 0 && hidden <= 1024 && ndir > 0 && ndir <= 32 && nseq >= 0 && out_col0 >= 0 &&
+                  ldo >= out_col0 + (int64_t)ndir * hidden,
+              AVS_E_SHAPE, "avs_lstm_bwd_f32: bad extents");
+  if (nseq == 0) return AVS_OK;
+  AVS_REQUIRE(d_dout && d_gates && d_cell && d_whh && d_seq_rows && d_dxproj, AVS_E_ARG, "avs_lstm_bwd_f32: null pointer");
+  int JQ = 1024 / hidden;
+  if (JQ < 1) JQ = 1;
+  if (JQ > 4 * hidden) JQ = 4 * hidden;
+  const int jpq = (4 * hidden + JQ - 1) / JQ;
+  const size_t shmem = ((size_t)4 * hidden + (size_t)JQ * hidden) * sizeof(float);
+  hipLaunchKernelGGL(lstm_bwd_kernel, dim3(nseq, ndir), dim3(1024), shmem, (hipStream_t)stream, d_dout, (long long)ldo,
+                     out_col0, d_gates, d_cell, d_whh, hidden, ndir, reverse_mask, d_seq_rows, d_dxproj, JQ, jpq);
+  AVS_CHECK_LAUNCH("avs_lstm_bwd_f32");
+  return AVS_OK;
+}

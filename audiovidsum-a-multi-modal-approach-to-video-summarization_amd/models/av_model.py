@@ -77,9 +77,7 @@ class AVBiLSTMModel(nn.Module):
         Returns fp32 [R].
         """
         if self.training:
-            raise NotImplementedError(
-                "AVBiLSTMModel HIP path: training-mode forward (Dropout + autograd) is not implemented yet; "
-                "call .eval()")
+            raise NotImplementedError("score_rows is the inference entry; training goes through forward() (B = 1)")
         p = self._prepare()
         vfc, afc = self.visual_fc[0], self.audio_fc[0]
         rows = visual_rows.shape[0]
@@ -116,6 +114,25 @@ class AVBiLSTMModel(nn.Module):
         b, t = visual.shape[:2]
         v = visual.reshape(b * t, -1).float().contiguous()
         a = audio.reshape(b * t, -1).float().contiguous()
+        needs_grad = torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters())
+                                                  or visual.requires_grad or audio.requires_grad)
+        if self.training or (needs_grad and b == 1):
+            # scripts/train_av_model.py:86-96: one video per step, Dropout active, autograd through the HIP path
+            if b != 1:
+                raise NotImplementedError("the HIP training path takes one sequence per call (B = 1), as the "
+                                          "reference's training loop does")
+            if t == 0:
+                raise ValueError("empty sequence")
+            from ._scorer_train import ScorerTrainFunction, dropout_keep
+            hidden = self.visual_fc[0].out_features
+            if self.training:
+                masks = getattr(self, "_dropout_keep", None)  # tests inject fixed masks here
+                keep_v, keep_a = masks if masks is not None else (dropout_keep((t, hidden), v.device),
+                                                                  dropout_keep((t, hidden), v.device))
+            else:
+                keep_v = keep_a = torch.ones((t, hidden), dtype=torch.float32, device=v.device)
+            scores = ScorerTrainFunction.apply(self, v, a, keep_v, keep_a, *[p for _, p in self.named_parameters()])
+            return scores.view(b, t, 1).squeeze()
         seq_rows = torch.arange(0, (b + 1) * t, max(t, 1), dtype=torch.int64, device=v.device)[: b + 1] if t > 0 \
             else torch.zeros(b + 1, dtype=torch.int64, device=v.device)
         scores = self.score_rows(v, a, seq_rows, attn_batch=b)

@@ -377,6 +377,94 @@ def softmax_rows(x, rows, n, ldx):
     return x
 
 
+# --------------------------------------------------------------------------- scorer backward
+def transpose_padded(x2d, pad=4):
+    """[rows, cols] fp32 -> [cols, rows_p] with rows_p = rows rounded up to `pad`, the tail columns zero."""
+    _f32(x2d, "x")
+    _rowmajor2d(x2d, "x")
+    rows, cols = x2d.shape
+    rp = (rows + pad - 1) // pad * pad
+    out = torch.zeros((cols, rp), dtype=torch.float32, device=x2d.device)
+    check(lib().avs_transpose_f32(_p(x2d), rows, cols, x2d.stride(0) if rows > 1 else cols, _p(out), rp, _stream()),
+          "avs_transpose_f32")
+    return out
+
+
+def colsum(x2d, row_weight=None):
+    _f32(x2d, "x")
+    _rowmajor2d(x2d, "x")
+    rows, cols = x2d.shape
+    out = torch.empty(cols, dtype=torch.float32, device=x2d.device)
+    check(lib().avs_colsum_f32(_p(x2d), rows, cols, x2d.stride(0) if rows > 1 else cols, _p(row_weight), _p(out),
+                               _stream()), "avs_colsum_f32")
+    return out
+
+
+def relu_dropout_bwd(dy, relu_out, keep=None):
+    out = torch.empty_like(dy)
+    check(lib().avs_relu_dropout_bwd_f32(_p(dy), _p(relu_out), _p(keep), dy.numel(), _p(out), _stream()),
+          "avs_relu_dropout_bwd_f32")
+    return out
+
+
+def mul(a, b):
+    out = torch.empty_like(a)
+    check(lib().avs_mul_f32(_p(a), _p(b), a.numel(), _p(out), _stream()), "avs_mul_f32")
+    return out
+
+
+def score_head_bwd(dscores, scores, hid, w2):
+    rows, d = hid.shape
+    dz = torch.empty(rows, dtype=torch.float32, device=hid.device)
+    dpre = torch.empty((rows, d), dtype=torch.float32, device=hid.device)
+    check(lib().avs_score_head_bwd_f32(_p(dscores), _p(scores), _p(hid), rows, d, hid.stride(0), _p(w2), _p(dz),
+                                       _p(dpre), _stream()), "avs_score_head_bwd_f32")
+    return dz, dpre
+
+
+def lstm_train_fwd(xproj, whh_t, hidden, ndir, reverse_mask, seq_rows, out, out_col0):
+    rows = xproj.shape[0]
+    gates = torch.empty((rows, ndir * 4 * hidden), dtype=torch.float32, device=xproj.device)
+    cell = torch.empty((rows, ndir * hidden), dtype=torch.float32, device=xproj.device)
+    nseq = seq_rows.numel() - 1
+    check(lib().avs_lstm_train_fwd_f32(_p(xproj), _p(whh_t), hidden, ndir, reverse_mask, _p(seq_rows), nseq, _p(out),
+                                       out.stride(0), out_col0, _p(gates), _p(cell), _stream()),
+          "avs_lstm_train_fwd_f32")
+    return gates, cell
+
+
+def lstm_bwd(dout, out_col0, gates, cell, whh, hidden, ndir, reverse_mask, seq_rows):
+    rows = gates.shape[0]
+    dxproj = torch.empty((rows, ndir * 4 * hidden), dtype=torch.float32, device=gates.device)
+    nseq = seq_rows.numel() - 1
+    check(lib().avs_lstm_bwd_f32(_p(dout), dout.stride(0), out_col0, _p(gates), _p(cell), _p(whh), hidden, ndir,
+                                 reverse_mask, _p(seq_rows), nseq, _p(dxproj), _stream()), "avs_lstm_bwd_f32")
+    return dxproj
+
+
+def grad_weight(dy, x):
+    """dW [N, K] = dy[T, N]^T . x[T, K]  (NT GEMM on transposed, zero-padded copies)."""
+    dyt = transpose_padded(dy)
+    xt = transpose_padded(x)
+    n, tp = dyt.shape
+    k = xt.shape[0]
+    out = torch.empty((n, k), dtype=torch.float32, device=dy.device)
+    gemm_nt_batched(AVS_F32, n, k, tp, dyt, 0, tp, 0, xt, 0, tp, 0, out, 0, k, 0)
+    return out
+
+
+def grad_input(dy, w):
+    """dx [T, K] = dy[T, N] . w[N, K]  (NT GEMM against w^T)."""
+    wt = transpose_padded(w)  # [K, Np]
+    t, n = dy.shape
+    k, npad = wt.shape
+    if n % 4:
+        raise ValueError("grad_input needs the output width to be a multiple of 4")
+    out = torch.empty((t, k), dtype=torch.float32, device=dy.device)
+    gemm_nt_batched(AVS_F32, t, k, n, dy, 0, dy.stride(0) if t > 1 else n, 0, wt, 0, npad, 0, out, 0, k, 0)
+    return out
+
+
 # --------------------------------------------------------------------------- fusion
 def cdist(v, a):
     _f32(v, "v")

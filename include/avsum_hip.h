@@ -251,6 +251,37 @@ int avs_score_head_f32(const float* d_hid, int64_t rows, int d, int64_t ldh,
 int avs_softmax_rows_f32(float* d_x, int64_t rows, int n, int64_t ldx,
                          avs_stream_t stream);
 
+/* ---- scorer backward (K22; scripts/train_av_model.py:86-96) ------------------ */
+/* The dense parts of the backward reuse avs_gemm_nt on transposed copies (dX = dY.W uses W^T as the [N,K]
+ * operand, dW = dY^T.X uses dY^T and X^T); the entry points below are the rest.                           */
+
+/* dst[c, r] = src[r, c]; dst row stride ld_dst >= rows (pad columns are left untouched).                  */
+int avs_transpose_f32(const float* d_src, int rows, int cols, int64_t ld_src, float* d_dst, int64_t ld_dst,
+                      avs_stream_t stream);
+/* out[c] = sum_r x[r,c] * (row_weight ? row_weight[r] : 1): bias gradients; deterministic order.          */
+int avs_colsum_f32(const float* d_x, int64_t rows, int cols, int64_t ld, const float* d_row_weight,
+                   float* d_out, avs_stream_t stream);
+/* out = dy * (keep ? keep : 1) * (relu_out > 0): gradient through Dropout(keep = mask/(1-p)) and ReLU
+ * (models/av_model.py:10-15).                                                                             */
+int avs_relu_dropout_bwd_f32(const float* d_dy, const float* d_relu_out, const float* d_keep, int64_t n,
+                             float* d_out, avs_stream_t stream);
+int avs_mul_f32(const float* d_a, const float* d_b, int64_t n, float* d_out, avs_stream_t stream);
+/* dz[r] = ds[r]*s[r]*(1-s[r]);  dhid_pre[r,k] = dz[r]*w2[k]*(hid[r,k] > 0)   (scorer.2 + Sigmoid and the
+ * ReLU of scorer.0 backwards, models/av_model.py:29-31).                                                  */
+int avs_score_head_bwd_f32(const float* d_dscores, const float* d_scores, const float* d_hid, int64_t rows,
+                           int d, int64_t ldh, const float* d_w2, float* d_dz, float* d_dhid_pre,
+                           avs_stream_t stream);
+/* avs_lstm_f32 that also saves the post-activation gates [rows, ndir*4H] (i,f,g,o) and the cell state
+ * [rows, ndir*H] for the backward.                                                                        */
+int avs_lstm_train_fwd_f32(const float* d_xproj, const float* d_whh_t, int hidden, int ndir,
+                           unsigned reverse_mask, const int64_t* d_seq_rows, int nseq, float* d_out,
+                           int64_t ldo, int out_col0, float* d_gates, float* d_cell, avs_stream_t stream);
+/* Backward through time: from dL/dh_t (d_dout, same layout as the forward's d_out) to the gradient of the
+ * pre-activations d_dxproj [rows, ndir*4H].  d_whh is W_hh in its ORIGINAL layout [ndir, 4H, H].           */
+int avs_lstm_bwd_f32(const float* d_dout, int64_t ldo, int out_col0, const float* d_gates,
+                     const float* d_cell, const float* d_whh, int hidden, int ndir, unsigned reverse_mask,
+                     const int64_t* d_seq_rows, int nseq, float* d_dxproj, avs_stream_t stream);
+
 /* ---- fusion (K13-K15) --------------------------------------------------- */
 
 /* out[i,j] = sqrt(sum_d (double(v[i,d]) - double(a[j,d]))^2), float64 out

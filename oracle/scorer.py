@@ -34,7 +34,7 @@ def lstm_direction(x, w_ih, w_hh, b_ih, b_hh, reverse=False):
     hid = w_hh.shape[1]
     h = torch.zeros(hid, dtype=x.dtype)
     c = torch.zeros(hid, dtype=x.dtype)
-    out = torch.zeros((t_len, hid), dtype=x.dtype)
+    outs = [None] * t_len
     xp = x @ w_ih.t() + b_ih
     order = range(t_len - 1, -1, -1) if reverse else range(t_len)
     for t in order:
@@ -45,8 +45,8 @@ def lstm_direction(x, w_ih, w_hh, b_ih, b_hh, reverse=False):
         o = torch.sigmoid(g[3 * hid:4 * hid])
         c = f * c + i * gg
         h = o * torch.tanh(c)
-        out[t] = h
-    return out
+        outs[t] = h
+    return torch.stack(outs) if t_len else torch.zeros((0, hid), dtype=x.dtype)
 
 
 def bilstm(x, sd, prefix):
@@ -83,6 +83,22 @@ def av_bilstm_forward(sd, visual, audio, heads=4):
     a_out = bilstm(a_emb, sd, "audio_bilstm.")
     fused = torch.cat([v_out, a_out], -1)
     # fed as (L=B, N=T, E): the module attends across the batch axis
+    attn = mha_seq_first(fused, sd["attention.in_proj_weight"], sd["attention.in_proj_bias"],
+                         sd["attention.out_proj.weight"], sd["attention.out_proj.bias"], heads)
+    hid = torch.relu(linear(attn, sd["scorer.0.weight"], sd["scorer.0.bias"]))
+    return torch.sigmoid(linear(hid, sd["scorer.2.weight"], sd["scorer.2.bias"])).squeeze()
+
+
+def av_bilstm_forward_train(sd, visual, audio, keep_v, keep_a, heads=4):
+    """Training-mode forward (models/av_model.py:33-46 with Dropout(0.3) active, as scripts/train_av_model.py:71
+    runs it): identical to av_bilstm_forward except that the two embeddings are multiplied by the inverted-
+    dropout masks keep_* (0 or 1/(1-p)); the masks are inputs so that both sides of a test use the same draw.
+    Differentiable with torch autograd (the oracle for the backward kernels)."""
+    v_emb = torch.relu(linear(visual, sd["visual_fc.0.weight"], sd["visual_fc.0.bias"])) * keep_v
+    a_emb = torch.relu(linear(audio, sd["audio_fc.0.weight"], sd["audio_fc.0.bias"])) * keep_a
+    v_out = bilstm(v_emb, sd, "visual_bilstm.")
+    a_out = bilstm(a_emb, sd, "audio_bilstm.")
+    fused = torch.cat([v_out, a_out], -1)
     attn = mha_seq_first(fused, sd["attention.in_proj_weight"], sd["attention.in_proj_bias"],
                          sd["attention.out_proj.weight"], sd["attention.out_proj.bias"], heads)
     hid = torch.relu(linear(attn, sd["scorer.0.weight"], sd["scorer.0.bias"]))

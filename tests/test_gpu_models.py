@@ -59,12 +59,92 @@ def test_av_bilstm_small_dims_random_audio(dev):
     assert (got - ref).abs().max().item() < 1e-5
 
 
-def test_av_bilstm_train_mode_fails_loudly(dev):
+def test_av_bilstm_unsupported_calls_fail_loudly(dev):
     m = _seeded_scorer(1, visual_dim=64, audio_dim=24, hidden_dim=32).to(dev).train()
-    with pytest.raises(NotImplementedError):
-        m(torch.zeros(1, 4, 64, device=dev), torch.zeros(1, 4, 24, device=dev))
+    with pytest.raises(NotImplementedError):  # the training path is one sequence per call, like the reference's loop
+        m(torch.zeros(2, 4, 64, device=dev), torch.zeros(2, 4, 24, device=dev))
     with pytest.raises(RuntimeError):
         m.eval()(torch.zeros(1, 4, 64), torch.zeros(1, 4, 24))  # host tensors: no CPU fallback
+
+
+def _train_case(dev, dims, t, seed):
+    """Gradients of the train-mode forward (Dropout masks injected on both sides) vs torch autograd over the
+    oracle restatement."""
+    from avsum_amd.models._scorer_train import dropout_keep
+    from oracle import scorer as osc
+    m = _seeded_scorer(seed, **dims)
+    hidden = m.visual_fc[0].out_features
+    g = torch.Generator().manual_seed(seed + 1)
+    v = torch.randn(1, t, m.visual_fc[0].in_features, generator=g)
+    a = torch.randn(1, t, m.audio_fc[0].in_features, generator=g)
+    keep_v = (torch.rand(t, hidden, generator=g) >= 0.3).float() / 0.7
+    keep_a = (torch.rand(t, hidden, generator=g) >= 0.3).float() / 0.7
+    target = torch.rand(1, generator=g)
+    sd = {k: p.detach().clone().requires_grad_(True) for k, p in m.named_parameters()}
+    ref = osc.av_bilstm_forward_train(sd, v, a, keep_v, keep_a)
+    loss_ref = torch.nn.functional.mse_loss(ref, target.squeeze().expand_as(ref))
+    names = list(sd.keys())
+    grads_ref = torch.autograd.grad(loss_ref, [sd[k] for k in names], allow_unused=True)
+    md = m.to(dev).train()
+    md._dropout_keep = (keep_v.to(dev), keep_a.to(dev))
+    out = md(v.to(dev), a.to(dev))
+    assert out.shape == ref.shape and (out.detach().cpu() - ref.detach()).abs().max().item() < 1e-5
+    loss = torch.nn.functional.mse_loss(out, target.to(dev).squeeze().expand_as(out))
+    assert abs(loss.item() - loss_ref.item()) < 1e-6
+    loss.backward()
+    for k, gr in zip(names, grads_ref):
+        got = dict(md.named_parameters())[k].grad
+        assert got is not None, k
+        gr = torch.zeros_like(got.cpu()) if gr is None else gr
+        scale = max(gr.abs().max().item(), 1e-8)
+        assert (got.cpu() - gr).abs().max().item() <= 1e-4 * scale + 1e-9, (k, (got.cpu() - gr).abs().max().item(), scale)
+    return md
+
+
+def test_av_bilstm_backward_small(dev):
+    _train_case(dev, dict(visual_dim=64, audio_dim=24, hidden_dim=32), 23, 5)
+    _train_case(dev, dict(visual_dim=64, audio_dim=24, hidden_dim=32), 1, 6)
+
+
+def test_av_bilstm_backward_full_dims(dev):
+    _train_case(dev, {}, 61, 9)
+
+
+def test_training_loop_matches_oracle(dev):
+    """The reference's loop (scripts/train_av_model.py:70-96: AdamW lr 1e-4, one video per step, one broadcast
+    target, MSE) for 6 steps: same loss trajectory on the HIP path and on the CPU restatement."""
+    from avsum_amd.models.av_model import AVBiLSTMModel
+    from oracle import scorer as osc
+    dims = dict(visual_dim=128, audio_dim=40, hidden_dim=64)
+    torch.manual_seed(77)
+    m = AVBiLSTMModel(**dims)
+    ref_params = {k: p.detach().clone().requires_grad_(True) for k, p in m.named_parameters()}
+    opt_ref = torch.optim.AdamW(list(ref_params.values()), lr=1e-4)
+    md = m.to(dev).train()
+    opt = torch.optim.AdamW(md.parameters(), lr=1e-4)
+    g = torch.Generator().manual_seed(3)
+    losses, losses_ref = [], []
+    for step in range(6):
+        t = 20 + 3 * step
+        v, a = torch.randn(1, t, 128, generator=g), torch.randn(1, t, 40, generator=g)
+        kv = (torch.rand(t, 64, generator=g) >= 0.3).float() / 0.7
+        ka = (torch.rand(t, 64, generator=g) >= 0.3).float() / 0.7
+        target = torch.rand(1, generator=g) * 4 + 1
+        out_ref = osc.av_bilstm_forward_train(ref_params, v, a, kv, ka)
+        lr_ = torch.nn.functional.mse_loss(out_ref, target.expand_as(out_ref))
+        opt_ref.zero_grad()
+        lr_.backward()
+        opt_ref.step()
+        md._dropout_keep = (kv.to(dev), ka.to(dev))
+        out = md(v.to(dev), a.to(dev))
+        loss = torch.nn.functional.mse_loss(out, target.to(dev).expand_as(out))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+        losses_ref.append(lr_.item())
+    rel = max(abs(x - y) / abs(y) for x, y in zip(losses, losses_ref))
+    assert rel < 1e-4, (losses, losses_ref)  # SURVEY cfg5: loss trajectory <= 1e-4 relative
 
 
 @pytest.mark.parametrize("e,h,b,t", [(1024, 4, 1, 300), (512, 8, 2, 77), (64, 4, 3, 1), (1024, 4, 1, 1801)])

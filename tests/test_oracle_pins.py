@@ -99,6 +99,18 @@ def test_against_reference_classes_directly():
                 ref = m(v, a)
             out = osc.av_bilstm_forward(m.state_dict(), v, a)
             assert out.shape == ref.shape and (out - ref).abs().max().item() < 1e-6
+        # backward: torch autograd through the restatement == autograd through the reference module
+        m.zero_grad()
+        vg, ag = torch.randn(1, 13, 32, generator=g), torch.randn(1, 13, 12, generator=g)
+        m(vg, ag).sum().backward()
+        sd = {k: p.detach().clone().requires_grad_(True) for k, p in m.named_parameters()}
+        ones = torch.ones(13, 16)
+        grads = torch.autograd.grad(osc.av_bilstm_forward_train(sd, vg, ag, ones, ones).sum(), list(sd.values()),
+                                    allow_unused=True)
+        for (k, p), gr in zip(m.named_parameters(), grads):
+            want = p.grad if p.grad is not None else torch.zeros_like(p)
+            got = gr if gr is not None else torch.zeros_like(p)
+            assert (got - want).abs().max().item() < 1e-6, k
         at = MultiHeadSelfAttention(48, 6).eval()
         x = torch.randn(3, 21, 48, generator=g)
         with torch.no_grad():
