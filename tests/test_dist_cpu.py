@@ -34,6 +34,12 @@ def _worker(rank, world, port, ret):
     out = avd.gather_video_scores(local, mine, [lengths[v] for v in mine], len(lengths))
     for v, ln in enumerate(lengths):
         assert torch.equal(out[v], torch.full((ln,), float(v)) + torch.arange(ln) / 100)
+    # C3: gradient all-reduce (averaged) of a module whose grads differ per rank
+    for i, p_ in enumerate(mod.parameters()):
+        p_.grad = torch.full_like(p_, float(rank + 1 + i))
+    avd.allreduce_gradients(mod)
+    for i, p_ in enumerate(mod.parameters()):
+        assert torch.allclose(p_.grad, torch.full_like(p_, 1.5 + i))
     ret[rank] = True
     dist.destroy_process_group()
 

@@ -381,3 +381,31 @@ def test_fusion_api(dev):
     assert torch.equal(out, ofu.interpolate_features(v, path, 50))
     with pytest.raises(ValueError):
         fusion.compute_dtw(v, torch.randn(5, 7))
+
+
+def test_train_synthetic_and_evaluate_scripts(dev, tmp_path):
+    """BASELINE config 5 harness (reference loop on synthetic labels) runs on the HIP path and learns; then the
+    reference's evaluate() loop over a dataset of the on-disk feature format."""
+    from avsum_amd.data.dataset import BaseDataset, save_features
+    from avsum_amd.scripts.evaluate import evaluate
+    from avsum_amd.scripts.train_av_model import SyntheticShotDataset, train_on_dataset
+    torch.manual_seed(1)
+    ds = SyntheticShotDataset(num_videos=8, shots=(6, 12), seed=11)
+    before = None
+    losses = []
+    model = train_on_dataset(ds, epochs=6, lr=1e-3, on_step=losses.append)
+    assert len(losses) == 6 and all(np.isfinite(losses))
+    assert losses[-1] < losses[0]  # targets ~U[1,5] vs sigmoid outputs: the loss falls as the bias saturates
+    rng = np.random.default_rng(0)
+    for i in range(3):
+        s = 9 + i
+        save_features(str(tmp_path), f"vid{i}", rng.standard_normal((s, 4096)).astype(np.float32),
+                      np.zeros((s, 296), np.float32))
+        np.save(tmp_path / f"vid{i}" / "scores.npy", rng.random(s).astype(np.float32))
+    # a fresh model for the evaluation loop: the over-trained one above saturates to a constant score, for which
+    # the reference's unguarded precision / correlation are NaN (scripts/evaluate.py:29-36)
+    out = evaluate(_seeded_scorer(4).to(dev), BaseDataset(str(tmp_path)))
+    assert set(out) == {"f1", "spearman", "kendall"} and all(np.isfinite(list(out.values())))
+    assert 0.0 <= out["f1"] <= 1.0
+    with pytest.raises(ValueError):
+        save_features(str(tmp_path), "bad", np.zeros((3, 100), np.float32), np.zeros((3, 296), np.float32))
