@@ -45,6 +45,10 @@ class AVBiLSTMModel(nn.Module):
             return self._prepared
         with torch.no_grad():
             prep = {}
+            # all four recurrences (visual fwd/rev, audio fwd/rev) as ONE launch: direction d writes fused[:, d*H:]
+            prep["whh_t4"] = torch.cat([torch.stack([l.weight_hh_l0.t().contiguous(),
+                                                     l.weight_hh_l0_reverse.t().contiguous()])
+                                        for l in (self.visual_bilstm, self.audio_bilstm)]).contiguous()
             for name, lstm in (("v", self.visual_bilstm), ("a", self.audio_bilstm)):
                 hid = lstm.hidden_size
                 # input projection of both directions as one GEMM: rows [fwd 4H | rev 4H]
@@ -86,12 +90,11 @@ class AVBiLSTMModel(nn.Module):
         v_emb = ops.linear(visual_rows, vfc.weight, vfc.bias, ops.ACT_RELU)
         a_emb = ops.linear(audio_rows, afc.weight, afc.bias, ops.ACT_RELU)
         fused = torch.empty((rows, 2 * hidden), dtype=torch.float32, device=dev)
-        col = 0
-        for name, emb in (("v", v_emb), ("a", a_emb)):
-            hid = p[name + "_hid"]
-            xproj = ops.linear(emb, p[name + "_wih"], p[name + "_bih"])
-            ops.lstm(xproj, p[name + "_whh_t"], hid, 2, 0b10, seq_rows, fused, col)
-            col += 2 * hid
+        hid = p["v_hid"]
+        xproj = torch.empty((rows, 16 * hid), dtype=torch.float32, device=dev)  # [v fwd | v rev | a fwd | a rev] x 4H
+        ops.linear(v_emb, p["v_wih"], p["v_bih"], out=xproj[:, :8 * hid])
+        ops.linear(a_emb, p["a_wih"], p["a_bih"], out=xproj[:, 8 * hid:])
+        ops.lstm(xproj, p["whh_t4"], hid, 4, 0b1010, seq_rows, fused, 0)
         e = self.attention.embed_dim
         if attn_batch == 1:
             # softmax over a single key is exactly 1: attention == out_proj(v_proj(x))
