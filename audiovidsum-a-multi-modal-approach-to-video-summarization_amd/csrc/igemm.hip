@@ -73,8 +73,19 @@ struct IgemmParams {
 //   EPI_ANY    everything decided at run time (bias per column / row, ReLU, alpha)
 enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_ANY = 2 };
 
-template <int ES, int BN, bool ACC64, bool SPATIAL, int ROWB, int EPI>
+// PIPE: three operand buffers, the DMA of step s+2 is issued in step s; fragment reads are inline-asm
+// ds_read_b128 and the waits are hand-counted (s_waitcnt vmcnt(N) + raw s_barrier), because hipcc orders every
+// LDS read it can see behind ALL outstanding LDS-DMA (vmcnt(0)), which caps a plain-HIP loop at one step of
+// prefetch.  Order per step: wait for this step's DMA -> barrier -> issue step s+2 -> read fragments -> MFMA.
+__device__ __forceinline__ uint4 avs_lds_read_b128(unsigned byte_addr) {
+  uint4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(byte_addr));
+  return v;
+}
+
+template <int ES, int BN, bool ACC64, bool SPATIAL, int ROWB, int EPI, bool PIPE>
 __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64) ? 3 : 2) void igemm_kernel(IgemmParams p) {
+  static_assert(!PIPE || (ROWB == 64 && !ACC64), "the 3-buffer pipeline is built for the 64-byte-row variants");
   static_assert(!ACC64 || (ES == 4 && BN == 64), "fp64 slice accumulation: fp32 operands, narrow tile only");
   static_assert(ROWB == 64 || ROWB == 128, "row bytes");
   constexpr int CE = 16 / ES;        // elements per 16-byte chunk
@@ -90,7 +101,8 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64) ? 3 : 2) void igemm_ker
   constexpr int BUF = (A_ROWS + BN) * CPRR;  // uint4 slots per buffer
   constexpr int CT_PITCH = BN * 2 + 16;      // bf16 epilogue staging tile: row pitch in bytes (16 bytes of padding)
   constexpr int CT_SLOTS = ES == 2 ? (A_ROWS * CT_PITCH) / 16 : 0;
-  constexpr int LDS_SLOTS = 2 * BUF > CT_SLOTS ? 2 * BUF : CT_SLOTS;
+  constexpr int NBUF = PIPE ? 3 : 2;
+  constexpr int LDS_SLOTS = NBUF * BUF > CT_SLOTS ? NBUF * BUF : CT_SLOTS;
 
   __shared__ uint4 lds[LDS_SLOTS];
 
@@ -165,12 +177,19 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64) ? 3 : 2) void igemm_ker
       bool ok = kval && a_base[i] != nullptr;
       if constexpr (SPATIAL)
         ok = ok && (unsigned)(hi0[i] + kh) < (unsigned)p.H && (unsigned)(wi0[i] + kw) < (unsigned)p.W;
-      const char* src = ok ? a_base[i] + koff : zsrc;
+      // branch-free select: exactly one DMA instruction per chunk (the counted waits rely on it)
+      const unsigned long long am = ok ? ~0ull : 0ull;
+      const char* src = reinterpret_cast<const char*>(
+          (reinterpret_cast<unsigned long long>(a_base[i] + koff) & am) |
+          (reinterpret_cast<unsigned long long>(zsrc) & ~am));
       AVS_GLDS16(src, abuf + 256 * i);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const char* src = (kval && b_base[i] != nullptr) ? b_base[i] + (long long)kc * ES : zsrc;
+      const unsigned long long bm = (kval && b_base[i] != nullptr) ? ~0ull : 0ull;
+      const char* src = reinterpret_cast<const char*>(
+          (reinterpret_cast<unsigned long long>(b_base[i] + (long long)kc * ES) & bm) |
+          (reinterpret_cast<unsigned long long>(zsrc) & ~bm));
       AVS_GLDS16(src, bbuf + 256 * i);
     }
     kc += BKE;
@@ -214,68 +233,132 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64) ? 3 : 2) void igemm_ker
 #pragma unroll
     for (int i = 0; i < NB; ++i) b_base[i] = nullptr;
   }
-  stage(0);
-  __syncthreads();  // drains the DMA (vmcnt) and makes every wave's part of the tile visible
-
-  for (int s = 0; s < steps; ++s) {
-    const int buf = s & 1;
-    const uint4* abuf = lds + buf * BUF;
-    const uint4* bbuf = abuf + A_ROWS * CPRR;
-    // 1. all fragments of this step into registers (the compiler orders every LDS read behind the
-    //    outstanding LDS-DMA, so the reads must come BEFORE the next tile's DMA is issued)
-    uint4 fa[KS][2], fb[KS][NT];
+  if constexpr (PIPE) {
+    constexpr int NDMA = NA + NB;  // DMA instructions one stage() issues per wave
+    const unsigned lds_base = (unsigned)(unsigned long long)((__attribute__((address_space(3))) char*)lds);
+    // per-lane fragment byte offsets inside a buffer (ks = 0; ks = 1 flips bit 1 of the chunk)
+    unsigned fa_off[2][KS], fb_off[NT][KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int chunk = 2 * ks + lh;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         const int row = wr * 64 + mt * 32 + lr;
-        fa[ks][mt] = abuf[row * CPRR + (chunk ^ ((row >> SH) & (CPRR - 1)))];
+        fa_off[mt][ks] = (unsigned)(row * CPRR + (chunk ^ ((row >> SH) & (CPRR - 1)))) * 16u;
       }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int row = wc * (BN / 2) + nt * 32 + lr;
-        fb[ks][nt] = bbuf[row * CPRR + (chunk ^ ((row >> SH) & (CPRR - 1)))];
+        fb_off[nt][ks] = (unsigned)((A_ROWS + row) * CPRR + (chunk ^ ((row >> SH) & (CPRR - 1)))) * 16u;
       }
     }
-    // 2. DMA of the next tile into the other buffer: every wave finished reading it before the barrier
-    //    that ended the previous step.  It is in flight during the MFMAs below.
-    if (s + 1 < steps) stage(buf ^ 1);
-    // 3. matrix cores
+    stage(0);
+    if (steps > 1) stage(1);
+    int cur = 0;  // buffer holding step s
+    for (int s = 0; s < steps; ++s) {
+      if (s + 1 < steps)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (s + 2 < steps) stage(cur == 0 ? 2 : cur - 1);  // (s+2) % 3 == (cur + 2) % 3
+      const unsigned bbase = lds_base + (unsigned)cur * (BUF * 16u);
+      uint4 fa[KS][2], fb[KS][NT];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
+      for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt) fa[ks][mt] = avs_lds_read_b128(bbase + fa_off[mt][ks]);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          if constexpr (ES == 2) {
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                __builtin_bit_cast(bf16x8, fa[ks][mt]), __builtin_bit_cast(bf16x8, fb[ks][nt]),
-                acc[mt][nt], 0, 0, 0);
-          } else {
-            const float4 a4 = __builtin_bit_cast(float4, fa[ks][mt]);
-            const float4 b4 = __builtin_bit_cast(float4, fb[ks][nt]);
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[mt][nt], 0, 0, 0);
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[mt][nt], 0, 0, 0);
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[mt][nt], 0, 0, 0);
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[mt][nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt) fb[ks][nt] = avs_lds_read_b128(bbase + fb_off[nt][ks]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            if constexpr (ES == 2) {
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                  __builtin_bit_cast(bf16x8, fa[ks][mt]), __builtin_bit_cast(bf16x8, fb[ks][nt]),
+                  acc[mt][nt], 0, 0, 0);
+            } else {
+              const float4 a4 = __builtin_bit_cast(float4, fa[ks][mt]);
+              const float4 b4 = __builtin_bit_cast(float4, fb[ks][nt]);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[mt][nt], 0, 0, 0);
+            }
           }
-        }
-    if constexpr (ACC64) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            acc64[i][j][e] += (double)acc[i][j][e];
-            acc[i][j][e] = 0.f;
-          }
+      cur = cur == 2 ? 0 : cur + 1;
     }
-    // keep the MFMAs ahead of the wait: without this the scheduler hoists the barrier (and its vmcnt(0))
-    // above them and the DMA latency is no longer covered by the matrix work of this step
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
+    __syncthreads();  // every wave is done with the operand buffers before the epilogue reuses the LDS
+  } else {
+    stage(0);
+    __syncthreads();  // drains the DMA (vmcnt) and makes every wave's part of the tile visible
+
+    for (int s = 0; s < steps; ++s) {
+      const int buf = s & 1;
+      const uint4* abuf = lds + buf * BUF;
+      const uint4* bbuf = abuf + A_ROWS * CPRR;
+      // 1. all fragments of this step into registers (the compiler orders every LDS read behind the
+      //    outstanding LDS-DMA, so the reads must come BEFORE the next tile's DMA is issued)
+      uint4 fa[KS][2], fb[KS][NT];
+  #pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int chunk = 2 * ks + lh;
+  #pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const int row = wr * 64 + mt * 32 + lr;
+          fa[ks][mt] = abuf[row * CPRR + (chunk ^ ((row >> SH) & (CPRR - 1)))];
+        }
+  #pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int row = wc * (BN / 2) + nt * 32 + lr;
+          fb[ks][nt] = bbuf[row * CPRR + (chunk ^ ((row >> SH) & (CPRR - 1)))];
+        }
+      }
+      // 2. DMA of the next tile into the other buffer: every wave finished reading it before the barrier
+      //    that ended the previous step.  It is in flight during the MFMAs below.
+      if (s + 1 < steps) stage(buf ^ 1);
+      // 3. matrix cores
+  #pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+  #pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+  #pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            if constexpr (ES == 2) {
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                  __builtin_bit_cast(bf16x8, fa[ks][mt]), __builtin_bit_cast(bf16x8, fb[ks][nt]),
+                  acc[mt][nt], 0, 0, 0);
+            } else {
+              const float4 a4 = __builtin_bit_cast(float4, fa[ks][mt]);
+              const float4 b4 = __builtin_bit_cast(float4, fb[ks][nt]);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[mt][nt], 0, 0, 0);
+            }
+          }
+      if constexpr (ACC64) {
+  #pragma unroll
+        for (int i = 0; i < 2; ++i)
+  #pragma unroll
+          for (int j = 0; j < NT; ++j)
+  #pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              acc64[i][j][e] += (double)acc[i][j][e];
+              acc[i][j][e] = 0.f;
+            }
+      }
+      // keep the MFMAs ahead of the wait: without this the scheduler hoists the barrier (and its vmcnt(0))
+      // above them and the DMA latency is no longer covered by the matrix work of this step
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue ----
@@ -424,22 +507,36 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64) ? 3 : 2) void igemm_ker
 
 static int g_debug_flags = 0;
 extern "C" void avs_debug_flags(int flags) { g_debug_flags = flags; }
-static int g_rowb_threshold_bytes = 100000;  // reductions of at most this many bytes per row use 64-byte steps
+static int g_rowb_threshold_bytes = 2048;  // reductions of at most this many bytes per row use 64-byte steps
 
 extern "C" void avs_tune_short_reduction_bytes(int bytes) { g_rowb_threshold_bytes = bytes; }
 
-template <int ES, int BN, bool ACC64, bool SP, int ROWB>
-static void igemm_dispatch_epi(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p) {
+static int g_pipe3 = 1;  // 1: the 3-buffer hand-counted pipeline for the 64-byte-row variants
+extern "C" void avs_tune_pipeline(int enabled) { g_pipe3 = enabled; }
+
+template <int ES, int BN, bool ACC64, bool SP, int ROWB, bool PIPE>
+static void igemm_dispatch_epi2(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p) {
   if constexpr (ACC64) {
-    hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_ANY>), grid, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_ANY, false>), grid, dim3(256), 0, stream, p);
   } else {
     if (epi == EPI_PLAIN)
-      hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_PLAIN>), grid, dim3(256), 0, stream, p);
+      hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_PLAIN, PIPE>), grid, dim3(256), 0, stream, p);
     else if (epi == EPI_STATS)
-      hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS>), grid, dim3(256), 0, stream, p);
+      hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE>), grid, dim3(256), 0, stream, p);
     else
-      hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_ANY>), grid, dim3(256), 0, stream, p);
+      hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_ANY, PIPE>), grid, dim3(256), 0, stream, p);
   }
+}
+
+template <int ES, int BN, bool ACC64, bool SP, int ROWB>
+static void igemm_dispatch_epi(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p) {
+  if constexpr (ROWB == 64 && !ACC64) {
+    if (g_pipe3 && p.K * ES > 2 * ROWB) {  // at least three steps, else there is nothing to pipeline
+      igemm_dispatch_epi2<ES, BN, ACC64, SP, ROWB, true>(epi, grid, stream, p);
+      return;
+    }
+  }
+  igemm_dispatch_epi2<ES, BN, ACC64, SP, ROWB, false>(epi, grid, stream, p);
 }
 
 template <int ES, int BN, bool ACC64>

@@ -109,8 +109,11 @@ int avs_conv1x1_bn_bf16(const void* d_x, int64_t lin_stride, int k, const void* 
                         avs_stream_t stream);
 
 /* Tuning knob (process-wide, not thread-safe): reductions of at most `bytes` bytes per output row run with
- * 64-byte LDS rows / 3 workgroups per CU instead of 128-byte rows / 2 workgroups per CU.  Default: always. */
+ * 64-byte LDS rows / 3 workgroups per CU instead of 128-byte rows / 2 workgroups per CU.  Default 2048.    */
 void avs_tune_short_reduction_bytes(int bytes);
+/* Tuning knob: 1 selects the 3-buffer, hand-counted-wait pipeline of the contraction kernel (DMA two steps
+ * ahead) for reductions of three or more 64-byte steps.  Default on.                                     */
+void avs_tune_pipeline(int enabled);
 /* Kernel-study ablation switches for the contraction kernel (0 = production): bit 0 skips the output
  * stores, bit 1 skips the operand loads.  Results are wrong while set; tools/ only.                       */
 void avs_debug_flags(int flags);

@@ -25,9 +25,11 @@ for name, n, hw, cin, cout, k, s in shapes:
     flops = 2.0 * n * ho * ho * cout * k * k * cin
     byts = (x.numel() + y.numel() + w.numel()) * 2
     line = f"{name:26s}"
-    for tag, flags, rowb in (("base", 0, 100000), ("rowb128", 0, 0), ("nostore", 1, 100000), ("noload", 2, 100000), ("neither", 3, 100000)):
+    for tag, flags, rowb, pipe in (("base", 0, 100000, 0), ("pipe3", 0, 100000, 1), ("rowb128", 0, 0, 0),
+                                   ("nostore", 1, 100000, 0)):
         L.avs_debug_flags(flags)
         L.avs_tune_short_reduction_bytes(rowb)
+        L.avs_tune_pipeline(pipe)
         for _ in range(2):
             ops.conv2d(x, w, k, k, s, k // 2, y)
         torch.cuda.synchronize()
@@ -41,3 +43,4 @@ for name, n, hw, cin, cout, k, s in shapes:
         line += f" | {tag} {us:7.1f}us {flops / us / 1e6:6.0f}TF {byts / us / 1e6:5.2f}TB/s"
     print(line, flush=True)
 L.avs_debug_flags(0)
+L.avs_tune_pipeline(0)
