@@ -175,7 +175,9 @@ def conv1x1_bn(x2d, wt, rows_per_group, gamma, beta, eps, out2d, residual=None, 
     if residual is not None:
         _rowmajor2d(residual, "residual")
     groups = rows // rows_per_group
-    _timed("conv", AVS_BF16, 2.0 * rows * n * k, lambda: check(
+    # algorithmic HBM bytes: read x once, write y once (+ read the residual); the second pass re-reads from L2
+    nbytes = 2.0 * rows * (k + n * (2 if residual is not None else 1))
+    _timed("convbn", AVS_BF16, nbytes, lambda: check(
         lib().avs_conv1x1_bn_bf16(_p(x2d), x2d.stride(0), k, _p(wt), wt.stride(0), n, rows_per_group, groups,
                                   _p(gamma), _p(beta), float(eps), _p(residual),
                                   residual.stride(0) if residual is not None else 0, 1 if relu else 0, _p(out2d),

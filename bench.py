@@ -214,15 +214,19 @@ def main():
                             "avg_launch_us": round(conv["ms"] * 1e3 / conv["launches"], 2),
                             "algorithmic_flop_per_launch": round(conv["flops"] / conv["launches"], 1),
                             "share_of_step": round(conv["ms"] * 1e-3 / elapsed, 3)}
-            bn = summ.get(("bn_apply", code))
-            if roofline is not None and bn and bn["ms"] > 0:
-                gbs = bn["flops"] / (bn["ms"] * 1e-3) / 1e9
-                roofline["second_kernel"] = {"bound": "hbm", "kernel": "bn_apply_kernel (avs_bn_apply)",
-                                             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                             "frac": round(gbs / HBM_PEAK_GBS, 4), "launches": bn["launches"],
-                                             "avg_launch_us": round(bn["ms"] * 1e3 / bn["launches"], 2),
-                                             "algorithmic_bytes_per_launch": round(bn["flops"] / bn["launches"], 1),
-                                             "share_of_step": round(bn["ms"] * 1e-3 / elapsed, 3)}
+            others = []
+            for kind, label in (("convbn", "conv1x1_bn_kernel (avs_conv1x1_bn_bf16)"),
+                                ("bn_apply", "bn_apply_kernel (avs_bn_apply)")):
+                rec = summ.get((kind, code))
+                if rec and rec["ms"] > 0:
+                    gbs = rec["flops"] / (rec["ms"] * 1e-3) / 1e9
+                    others.append({"bound": "hbm", "kernel": label, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "launches": rec["launches"],
+                                   "avg_launch_us": round(rec["ms"] * 1e3 / rec["launches"], 2),
+                                   "algorithmic_bytes_per_launch": round(rec["flops"] / rec["launches"], 1),
+                                   "share_of_step": round(rec["ms"] * 1e-3 / elapsed, 3)})
+            if roofline is not None and others:
+                roofline["other_kernels"] = others
         cpu = None
         if sd_cpu is not None:
             log(f"timed region {elapsed:.2f}s; CPU baseline on {args.cpu_sample} frames")
