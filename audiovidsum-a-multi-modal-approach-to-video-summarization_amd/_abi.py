@@ -47,6 +47,7 @@ _SIGNATURES = {
     "avs_tune_short_reduction_bytes": (None, [c_int]),
     "avs_debug_flags": (None, [c_int]),
     "avs_tune_pipeline": (None, [c_int]),
+    "avs_tune_convbn_narrow": (None, [c_int]),
     "avs_gemm_nt": (c_int, [c_int, c_int, c_int, c_int, P, c_int64, c_int64, P, c_int64, c_int64, P, c_int64,
                             c_int64, P, c_int, c_int64, c_float, c_int, c_int, P]),
     "avs_frames_normalize_u8": (c_int, [c_int, P, c_int, c_int, c_int, c_float, POINTER(c_float), POINTER(c_float),
@@ -109,6 +110,8 @@ def lib():
         fn.argtypes = args
     if handle.avs_abi_version() != 1:
         raise AvsError(f"ABI version mismatch: library reports {handle.avs_abi_version()}, binding expects 1")
+    if os.environ.get("AVS_TUNE_CONVBN_NARROW") is not None:
+        handle.avs_tune_convbn_narrow(int(os.environ["AVS_TUNE_CONVBN_NARROW"]))
     if os.environ.get("AVS_TUNE_PIPELINE") is not None:  # kernel-study override of the library default
         handle.avs_tune_pipeline(int(os.environ["AVS_TUNE_PIPELINE"]))
     _lib = handle

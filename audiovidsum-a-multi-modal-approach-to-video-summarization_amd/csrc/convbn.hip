@@ -250,6 +250,9 @@ __global__ __launch_bounds__(256, 3) void conv1x1_bn_kernel(ConvBnParams p) {
   }
 }
 
+static int g_convbn_narrow = 0;
+extern "C" void avs_tune_convbn_narrow(int enabled) { g_convbn_narrow = enabled; }
+
 extern "C" int avs_conv1x1_bn_bf16(const void* d_x, int64_t lin_stride, int k, const void* d_w, int64_t ldb, int n,
                                    int64_t rows_per_group, int groups, const float* d_gamma, const float* d_beta,
                                    float eps, const void* d_residual, int64_t ldr, int relu, void* d_y, int64_t ldc,
@@ -280,7 +283,7 @@ extern "C" int avs_conv1x1_bn_bf16(const void* d_x, int64_t lin_stride, int k, c
   p.rows_per_group = (int)rows_per_group;
   p.groups = groups;
   p.relu = relu;
-  const bool narrow = n <= 64;
+  const bool narrow = n <= 64 || g_convbn_narrow;
   const int bn = narrow ? 64 : 128;
   p.tiles_n = (n + bn - 1) / bn;
   const long long total = (long long)groups * p.tiles_n;

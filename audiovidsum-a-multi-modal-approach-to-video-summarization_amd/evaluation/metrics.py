@@ -35,3 +35,13 @@ def binary_f1(pred, target):
     precision = tp / bp.sum()
     recall = tp / bt.sum()
     return 2 * (precision * recall) / (precision + recall + 1e-8)
+
+
+def summarize_scores(pairs):
+    """Mean over videos of the mean-threshold F1, Spearman and Kendall correlations (scripts/evaluate.py:21-42).
+    Like the reference it does not guard a constant prediction (NaN precision / correlation)."""
+    from scipy.stats import kendalltau, spearmanr
+    f1 = [binary_f1(p, t) for p, t in pairs]
+    rho = [spearmanr(p, t).correlation for p, t in pairs]
+    tau = [kendalltau(p, t).correlation for p, t in pairs]
+    return {"f1": np.mean(f1), "spearman": np.mean(rho), "kendall": np.mean(tau)}

@@ -1,28 +1,21 @@
-"""Mirror of the reference's scripts/evaluate.py:6-42: per-video mean-threshold F1 + Spearman + Kendall.
-The model call runs on the MI355X (AVBiLSTMModel HIP path); the metrics stay on the host (numpy/scipy)."""
-import numpy as np
+"""Counterpart of the reference's scripts/evaluate.py:6-42: score every video of a dataset with the model (one
+video per call, B = 1, on the MI355X), then the per-video mean-threshold F1 and rank correlations, averaged.
+Same signature and return keys as the reference; the metric arithmetic lives in evaluation.metrics."""
 import torch
-from scipy.stats import kendalltau, spearmanr
+
+from ..evaluation.metrics import summarize_scores
+
+
+def predict_dataset(model, dataset):
+    """[(pred [S], target [S])] as numpy arrays, model in eval mode, no autograd."""
+    model.eval()
+    pairs = []
+    with torch.no_grad():
+        for features, scores in dataset:
+            inputs = [features[k].unsqueeze(0).cuda() for k in ("visual", "audio")]
+            pairs.append((model(*inputs).cpu().squeeze().numpy(), scores.numpy()))
+    return pairs
 
 
 def evaluate(model, dataset):
-    model.eval()
-    all_preds, all_targets = [], []
-    with torch.no_grad():
-        for features, scores in dataset:
-            visual = features["visual"].unsqueeze(0).cuda()
-            audio = features["audio"].unsqueeze(0).cuda()
-            preds = model(visual, audio).cpu().squeeze()
-            all_preds.append(preds.numpy())
-            all_targets.append(scores.numpy())
-    f1_scores, spearmans, kendalls = [], [], []
-    for pred, target in zip(all_preds, all_targets):
-        binary_pred = (pred > np.mean(pred)).astype(int)
-        binary_target = (target > np.mean(target)).astype(int)
-        tp = np.logical_and(binary_pred, binary_target).sum()
-        precision = tp / binary_pred.sum()
-        recall = tp / binary_target.sum()
-        f1_scores.append(2 * (precision * recall) / (precision + recall + 1e-8))
-        spearmans.append(spearmanr(pred, target).correlation)
-        kendalls.append(kendalltau(pred, target).correlation)
-    return {"f1": np.mean(f1_scores), "spearman": np.mean(spearmans), "kendall": np.mean(kendalls)}
+    return summarize_scores(predict_dataset(model, dataset))

@@ -108,6 +108,9 @@ int avs_conv1x1_bn_bf16(const void* d_x, int64_t lin_stride, int k, const void* 
                         float eps, const void* d_residual, int64_t ldr, int relu, void* d_y, int64_t ldc,
                         avs_stream_t stream);
 
+/* Tuning knob: 1 = 64-channel slabs (4 workgroups per CU) in avs_conv1x1_bn_bf16 whatever n is.          */
+void avs_tune_convbn_narrow(int enabled);
+
 /* Tuning knob (process-wide, not thread-safe): reductions of at most `bytes` bytes per output row run with
  * 64-byte LDS rows / 3 workgroups per CU instead of 128-byte rows / 2 workgroups per CU.  Default 2048.    */
 void avs_tune_short_reduction_bytes(int bytes);

@@ -92,3 +92,41 @@ def test_config2_audio_visual_fusion(dev):
     path = fusion.compute_optimal_path(cost_ref)
     assert np.array_equal(path, ofu.compute_optimal_path(cost_ref))
     assert torch.equal(fusion.interpolate_features(v_dev.cpu(), path, 40), ofu.interpolate_features(v_dev.cpu(), path, 40))
+
+
+def test_batch_and_chunk_invariance_fp32(dev):
+    """Size-independent properties of the sharded path (configs[3]): a video's scores do not depend on which
+    other videos share the batch, nor on how the frames are cut into CNN chunks — bitwise in the fp32 parity
+    mode (every stage is per-frame / per-video and deterministic there)."""
+    from avsum_amd.features.extractors import VisualFeatureExtractor
+    from avsum_amd.models.av_model import AVBiLSTMModel
+    from avsum_amd.pipeline import FrameScoringPipeline
+    torch.manual_seed(61)
+    ext = VisualFeatureExtractor(torch.float32, "batch").to(dev)
+    model = AVBiLSTMModel().eval().to(dev)
+    rng = np.random.default_rng(4004)
+    frames = torch.from_numpy(rng.integers(0, 256, (11, 224, 224, 3), dtype=np.uint8)).to(dev)
+    offsets = [0, 3, 8, 11]
+    ref = FrameScoringPipeline(ext, model, use_inception=False, chunk_frames=1024).score(frames, offsets).cpu()
+    small = FrameScoringPipeline(ext, model, use_inception=False, chunk_frames=2).score(frames, offsets).cpu()
+    assert torch.equal(ref, small)
+    alone = FrameScoringPipeline(ext, model, use_inception=False).score(frames[3:8].contiguous(), [0, 5]).cpu()
+    assert torch.equal(alone, ref[3:8])
+    sel = FrameScoringPipeline.select(ref, offsets)
+    assert [len(s) for s in sel] and all((np.diff(s) > 0).all() for s in sel if len(s) > 1)  # sorted indices
+
+
+def test_bf16_batch_invariance_is_close(dev):
+    """Same property in the bf16 throughput mode: the fused-statistics float atomics reorder sums, so equality is
+    to bf16 noise, not bitwise."""
+    from avsum_amd.features.extractors import VisualFeatureExtractor
+    from avsum_amd.models.av_model import AVBiLSTMModel
+    from avsum_amd.pipeline import FrameScoringPipeline
+    torch.manual_seed(62)
+    ext = VisualFeatureExtractor(torch.bfloat16, "batch").to(dev)
+    model = AVBiLSTMModel().eval().to(dev)
+    rng = np.random.default_rng(5)
+    frames = torch.from_numpy(rng.integers(0, 256, (9, 224, 224, 3), dtype=np.uint8)).to(dev)
+    a = FrameScoringPipeline(ext, model, use_inception=False, chunk_frames=1024).score(frames, [0, 4, 9]).cpu()
+    b = FrameScoringPipeline(ext, model, use_inception=False, chunk_frames=3).score(frames, [0, 4, 9]).cpu()
+    assert (a - b).abs().max().item() < 2e-3
