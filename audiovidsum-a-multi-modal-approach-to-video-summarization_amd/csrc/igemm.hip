@@ -71,7 +71,8 @@ struct IgemmParams {
 //   EPI_PLAIN  alpha == 1, no bias, no activation, no statistics (ResNet convolutions, projections)
 //   EPI_STATS  EPI_PLAIN + fused BatchNorm batch statistics
 //   EPI_ANY    everything decided at run time (bias per column / row, ReLU, alpha)
-enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_ANY = 2 };
+//   EPI_BRELU  alpha == 1, bias per column, ReLU (the folded-BatchNorm convolutions of Inception-v3; Linear+ReLU)
+enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_ANY = 2, EPI_BRELU = 3 };
 
 // PIPE: three operand buffers, the DMA of step s+2 is issued in step s; fragment reads are inline-asm
 // ds_read_b128 and the waits are hand-counted (s_waitcnt vmcnt(N) + raw s_barrier), because hipcc orders every
@@ -432,6 +433,10 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64) ? 3 : 2) void igemm_ker
             const int col = n0 + wc * (BN / 2) + nt * 32 + lr;
             bcol = (p.bias_mode == AVS_BIAS_COL && col < p.N) ? bias[col] : 0.f;
           }
+          if constexpr (EPI == EPI_BRELU) {
+            const int col = n0 + wc * (BN / 2) + nt * 32 + lr;
+            bcol = col < p.N ? bias[col] : 0.f;
+          }
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int roff = mt * 32 + (e & 3) + 8 * (e >> 2);
@@ -444,6 +449,7 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64) ? 3 : 2) void igemm_ker
               }
               if (p.act == AVS_ACT_RELU) v = fmaxf(v, 0.f);
             }
+            if constexpr (EPI == EPI_BRELU) v = fmaxf(v + bcol, 0.f);
             *reinterpret_cast<unsigned short*>(cbase + roff * CT_PITCH + nt * 64) = avs_f32_to_bf16(v);
           }
         }
@@ -484,6 +490,7 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64) ? 3 : 2) void igemm_ker
         if (col >= p.N) continue;
         float bcol = 0.f;
         if constexpr (EPI == EPI_ANY) bcol = (p.bias_mode == AVS_BIAS_COL) ? bias[col] : 0.f;
+        if constexpr (EPI == EPI_BRELU) bcol = bias[col];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int row = m0 + wr * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
@@ -493,6 +500,8 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64) ? 3 : 2) void igemm_ker
             v = (float)(acc64[mt][nt][e] * (double)p.alpha) + bcol;
           else if constexpr (EPI == EPI_ANY)
             v = fmaf(acc[mt][nt][e], p.alpha, bcol);
+          else if constexpr (EPI == EPI_BRELU)
+            v = fmaxf(acc[mt][nt][e] + bcol, 0.f);
           else
             v = acc[mt][nt][e];
           if constexpr (EPI == EPI_ANY) {
@@ -523,6 +532,8 @@ static void igemm_dispatch_epi2(int epi, dim3 grid, hipStream_t stream, const Ig
       hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_PLAIN, PIPE>), grid, dim3(256), 0, stream, p);
     else if (epi == EPI_STATS)
       hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE>), grid, dim3(256), 0, stream, p);
+    else if (epi == EPI_BRELU)
+      hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BRELU, PIPE>), grid, dim3(256), 0, stream, p);
     else
       hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_ANY, PIPE>), grid, dim3(256), 0, stream, p);
   }
@@ -546,6 +557,8 @@ static void igemm_dispatch(bool spatial, dim3 grid, hipStream_t stream, const Ig
   int epi = EPI_ANY;
   if (p.bias_mode == AVS_BIAS_NONE && p.act == AVS_ACT_NONE && p.alpha == 1.0f)
     epi = p.stat_sum ? EPI_STATS : EPI_PLAIN;
+  else if (p.bias_mode == AVS_BIAS_COL && p.act == AVS_ACT_RELU && p.alpha == 1.0f && !p.stat_sum)
+    epi = EPI_BRELU;
   if (short_k) {
     if (spatial)
       igemm_dispatch_epi<ES, BN, ACC64, true, 64>(epi, grid, stream, p);
