@@ -13,7 +13,7 @@ from ._abi import ACT_NONE, ACT_RELU, AVS_BF16, AVS_F32, BIAS_COL, BIAS_NONE, BI
 __all__ = [
     "ACT_NONE", "ACT_RELU", "linear", "gemm_nt_batched", "conv2d", "conv2d_raw", "conv1x1_bn", "frames_normalize", "resize_bilinear",
     "bn_batch_stats", "bn_apply", "pool2d", "global_avgpool", "segment_mean", "reflect_pad", "stft_f64", "power_mel",
-    "clamp_topdb", "fill", "lstm", "mha_batchaxis", "score_head", "softmax_rows", "cdist", "dtw_path",
+    "clamp_topdb", "fill", "lstm", "mha_batchaxis", "score_head", "mhsa_flash", "softmax_rows", "cdist", "dtw_path",
     "gather_scale", "dtype_code",
 ]
 
@@ -371,6 +371,20 @@ def score_head(hid, w2, b2):
     check(lib().avs_score_head_f32(_p(hid), rows, d, hid.stride(0), _p(w2), _p(b2), _p(out), _stream()),
           "avs_score_head_f32")
     return out
+
+
+def mhsa_flash(q, k, v, b, t, heads):
+    """q, k, v: fp32 [b*t, E] (projected); returns ctx [b*t, E].  Head dim E/heads must be 64, 128 or 256."""
+    for name, x in (("q", q), ("k", k), ("v", v)):
+        _f32(x, name)
+        _rowmajor2d(x, name)
+    e = q.shape[1]
+    ctx = torch.empty((b * t, e), dtype=torch.float32, device=q.device)
+    if not (q.stride(0) == k.stride(0) == v.stride(0)):
+        raise ValueError("q, k, v must share a row stride")
+    check(lib().avs_mhsa_flash_f32(_p(q), _p(k), _p(v), q.stride(0), b, t, heads, e // heads, _p(ctx), e, _stream()),
+          "avs_mhsa_flash_f32")
+    return ctx
 
 
 def softmax_rows(x, rows, n, ldx):

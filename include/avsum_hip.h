@@ -252,6 +252,13 @@ int avs_score_head_f32(const float* d_hid, int64_t rows, int d, int64_t ldh,
                        const float* d_w2, const float* d_b2, float* d_scores,
                        avs_stream_t stream);
 
+/* Fused attention core of models/attention.py:21-24 (flash style: the [T,T] scores never reach memory):
+ *   ctx[b,q,h*D+:] = softmax_k( Q[b,q,h,:] . K[b,k,h,:] / sqrt(D) ) . V[b,k,h,:]
+ * d_q / d_k / d_v are the projected [b*t, heads*D] matrices (row stride ld), head_dim D in {64, 128, 256}.
+ * fp32 MFMA for both products, per-query online softmax folded with one wave shuffle.                      */
+int avs_mhsa_flash_f32(const float* d_q, const float* d_k, const float* d_v, int64_t ld, int b, int t,
+                       int heads, int head_dim, float* d_ctx, int64_t ldo, avs_stream_t stream);
+
 /* Row softmax in place: x[r, 0:n] for `rows` rows of stride ldx
  * (torch.softmax(dim=-1) at models/attention.py:22).                         */
 int avs_softmax_rows_f32(float* d_x, int64_t rows, int n, int64_t ldx,

@@ -147,7 +147,8 @@ def test_training_loop_matches_oracle(dev):
     assert rel < 1e-4, (losses, losses_ref)  # SURVEY cfg5: loss trajectory <= 1e-4 relative
 
 
-@pytest.mark.parametrize("e,h,b,t", [(1024, 4, 1, 300), (512, 8, 2, 77), (64, 4, 3, 1), (1024, 4, 1, 1801)])
+@pytest.mark.parametrize("e,h,b,t", [(1024, 4, 1, 300), (512, 8, 2, 77), (64, 4, 3, 1), (1024, 4, 1, 1801),
+                                     (512, 4, 2, 33), (256, 4, 1, 129), (1024, 4, 2, 1)])
 def test_mhsa(dev, e, h, b, t):
     from avsum_amd.models.attention import MultiHeadSelfAttention
     from oracle import scorer as osc
@@ -155,10 +156,15 @@ def test_mhsa(dev, e, h, b, t):
     m = MultiHeadSelfAttention(e, h).eval()
     x = torch.randn(b, t, e, generator=torch.Generator().manual_seed(t))
     ref = osc.mhsa_forward(m.state_dict(), x, h)
+    md = m.to(dev)
     with torch.no_grad():
-        got = m.to(dev)(x.to(dev)).cpu()
+        md.use_flash = True   # fused kernel (head dims 64/128/256; silently the GEMM path otherwise)
+        got = md(x.to(dev)).cpu()
+        md.use_flash = False  # the materialised-score path must agree too
+        got2 = md(x.to(dev)).cpu()
     assert got.shape == ref.shape
     assert (got - ref).abs().max().item() < 1e-4
+    assert (got2 - ref).abs().max().item() < 1e-4
 
 
 def _frames(n, seed, h=224, w=224):
