@@ -60,6 +60,7 @@ _SIGNATURES = {
                                 c_int, c_int64, P]),
     "avs_global_avgpool_nhwc": (c_int, [c_int, P, c_int, c_int, c_int, P, c_int64, P]),
     "avs_segment_mean_f32": (c_int, [P, c_int64, c_int, P, c_int, P, c_int64, P]),
+    "avs_hsv_frame_diff_u8": (c_int, [P, c_int, c_int, c_int, c_int, P, P]),
     "avs_reflect_pad_f32": (c_int, [P, c_int64, c_int, P, c_int64, P]),
     "avs_stft_f64": (c_int, [P, c_int64, c_int64, c_int, c_int, P, c_int, c_int, P, P]),
     "avs_power_mel_f32": (c_int, [P, c_int64, c_int, P, P, P, c_int, c_int, P, P, P]),

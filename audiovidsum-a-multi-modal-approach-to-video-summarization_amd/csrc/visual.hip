@@ -503,3 +503,91 @@ extern "C" int avs_segment_mean_f32(const float* d_x, int64_t ldx, int d, const 
   AVS_CHECK_LAUNCH("avs_segment_mean_f32");
   return AVS_OK;
 }
+
+
+// ---------------------------------------------------------------------------
+// Shot-boundary scan (features/extractors.py:388-393 calls PySceneDetect's ContentDetector):
+// per frame, the sum over pixels of |H - H_prev|, |S - S_prev|, |V - V_prev| with OpenCV's 8-bit BGR->HSV
+// (H in [0,180), 12-bit fixed-point division tables) [3P-memory: cv2 / scenedetect sources absent here].
+// Integer arithmetic end to end (block reduction by wave shuffle, one integer atomic per block), so the sums are
+// exact and order-independent.  `step` = PySceneDetect's downscale stride (frame[::step, ::step]).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int cv_round_div(int num_shifted, double den) { return (int)rint((double)num_shifted / den); }
+
+__device__ __forceinline__ void bgr2hsv_u8(int b, int g, int r, int& h, int& s, int& v) {
+  v = max(b, max(g, r));
+  const int vmin = min(b, min(g, r));
+  const int diff = v - vmin;
+  const int sdiv = v > 0 ? cv_round_div(255 << 12, 1.0 * v) : 0;
+  const int hdiv = diff > 0 ? cv_round_div(180 << 12, 6.0 * diff) : 0;
+  s = (diff * sdiv + (1 << 11)) >> 12;
+  int hh;
+  if (v == r)
+    hh = g - b;
+  else if (v == g)
+    hh = b - r + 2 * diff;
+  else
+    hh = r - g + 4 * diff;
+  hh = (hh * hdiv + (1 << 11)) >> 12;
+  if (hh < 0) hh += 180;
+  h = hh;
+}
+
+__global__ __launch_bounds__(256) void hsv_frame_diff_kernel(const uint8_t* __restrict__ frames, int h, int w,
+                                                             int step, int ph, int pw, unsigned* __restrict__ sums) {
+  __shared__ unsigned red[4][3];
+  const long long f = blockIdx.y + 1;  // frame f against frame f-1
+  const uint8_t* cur = frames + f * h * (long long)w * 3;
+  const uint8_t* prv = cur - (long long)h * w * 3;
+  unsigned a0 = 0, a1 = 0, a2 = 0;
+  const int npx = ph * pw;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+    const int y = (i / pw) * step, x = (i % pw) * step;
+    const long long o = ((long long)y * w + x) * 3;
+    int h1, s1, v1, h0, s0, v0;
+    bgr2hsv_u8(cur[o], cur[o + 1], cur[o + 2], h1, s1, v1);
+    bgr2hsv_u8(prv[o], prv[o + 1], prv[o + 2], h0, s0, v0);
+    a0 += (unsigned)abs(h1 - h0);
+    a1 += (unsigned)abs(s1 - s0);
+    a2 += (unsigned)abs(v1 - v0);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a0 += __shfl_xor(a0, o, 64);
+    a1 += __shfl_xor(a1, o, 64);
+    a2 += __shfl_xor(a2, o, 64);
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[wave][0] = a0;
+    red[wave][1] = a1;
+    red[wave][2] = a2;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3)
+    atomicAdd(sums + f * 3 + threadIdx.x,
+              red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+extern "C" int avs_hsv_frame_diff_u8(const uint8_t* d_frames, int n, int h, int w, int step, uint32_t* d_sums,
+                                     avs_stream_t stream) {
+  AVS_REQUIRE(n >= 0 && h > 0 && w > 0 && step > 0, AVS_E_SHAPE, "avs_hsv_frame_diff_u8: bad extents");
+  if (n == 0) return AVS_OK;
+  AVS_REQUIRE(d_frames && d_sums, AVS_E_ARG, "avs_hsv_frame_diff_u8: null pointer");
+  const int ph = (h + step - 1) / step, pw = (w + step - 1) / step;  // len(range(0, h, step))
+  AVS_REQUIRE((long long)ph * pw * 255 < (1ll << 32), AVS_E_SHAPE, "avs_hsv_frame_diff_u8: frame too large for u32 sums");
+  hipError_t e = hipMemsetAsync(d_sums, 0, sizeof(uint32_t) * 3 * (size_t)n, (hipStream_t)stream);
+  if (e != hipSuccess) {
+    avs_set_error("avs_hsv_frame_diff_u8: memset failed: %s", hipGetErrorString(e));
+    return AVS_E_HIP;
+  }
+  if (n == 1) return AVS_OK;
+  AVS_REQUIRE(n - 1 <= 65535, AVS_E_SHAPE, "avs_hsv_frame_diff_u8: at most 65536 frames per call");
+  int bx = (int)avs_cdiv((long long)ph * pw, 256 * 8);
+  if (bx < 1) bx = 1;
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(hsv_frame_diff_kernel, dim3(bx, n - 1), dim3(256), 0, (hipStream_t)stream, d_frames, h, w, step, ph,
+                     pw, d_sums);
+  AVS_CHECK_LAUNCH("avs_hsv_frame_diff_u8");
+  return AVS_OK;
+}

@@ -200,10 +200,17 @@ class AVProcessor:
         self.audio_extractor = AudioFeatureExtractor(strict_reference=strict_reference)
         self.sr = self.audio_extractor.sr
 
-    def process_decoded(self, frames, waveform, fps, shots):
+    def _detect_shots_decoded(self, frames):
+        """extractors.py:388-393 on decoded frames: ContentDetector restated on the GPU (features/shots.py)."""
+        from .shots import detect_shots
+        return detect_shots(np.stack([_as_bgr_u8(f) for f in frames]))
+
+    def process_decoded(self, frames, waveform, fps, shots=None):
         """The per-shot loop of process_video (extractors.py:344-362) on already-decoded input:
         frames = indexable of uint8 HxWx3 for the whole video, waveform = mono float array at self.sr,
-        shots = [(start_frame, end_frame)]."""
+        shots = [(start_frame, end_frame)] or None to run the shot detector on the frames."""
+        if shots is None:
+            shots = self._detect_shots_decoded(frames)
         visual, audio = [], []
         for start, end in shots:
             picked = [frames[i] for i in sample_shot_indices(start, min(end, len(frames)))]

@@ -12,7 +12,7 @@ from ._abi import ACT_NONE, ACT_RELU, AVS_BF16, AVS_F32, BIAS_COL, BIAS_NONE, BI
 
 __all__ = [
     "ACT_NONE", "ACT_RELU", "linear", "gemm_nt_batched", "conv2d", "conv2d_raw", "conv1x1_bn", "frames_normalize", "resize_bilinear",
-    "bn_batch_stats", "bn_apply", "pool2d", "global_avgpool", "segment_mean", "reflect_pad", "stft_f64", "power_mel",
+    "bn_batch_stats", "bn_apply", "pool2d", "global_avgpool", "segment_mean", "hsv_frame_diff", "reflect_pad", "stft_f64", "power_mel",
     "clamp_topdb", "fill", "lstm", "mha_batchaxis", "score_head", "mhsa_flash", "softmax_rows", "cdist", "dtw_path",
     "gather_scale", "dtype_code",
 ]
@@ -298,6 +298,17 @@ def segment_mean(x2d, seg, out=None):
     check(lib().avs_segment_mean_f32(_p(x2d), x2d.stride(0), d, _p(seg), nseg, _p(out), out.stride(0), _stream()),
           "avs_segment_mean_f32")
     return out
+
+
+def hsv_frame_diff(frames_u8, step=1):
+    """frames uint8 [n,h,w,3] on device -> int64 [n,3] sums of |dH|,|dS|,|dV| against the previous frame."""
+    _dev(frames_u8)
+    if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or frames_u8.shape[3] != 3 or not frames_u8.is_contiguous():
+        raise ValueError("frames must be contiguous uint8 [n,h,w,3]")
+    n, h, w, _ = frames_u8.shape
+    sums = torch.empty((n, 3), dtype=torch.int32, device=frames_u8.device)
+    check(lib().avs_hsv_frame_diff_u8(_p(frames_u8), n, h, w, step, _p(sums), _stream()), "avs_hsv_frame_diff_u8")
+    return sums.to(torch.int64) & 0xFFFFFFFF
 
 
 # --------------------------------------------------------------------------- audio front end

@@ -190,6 +190,12 @@ int avs_global_avgpool_nhwc(int dtype, const void* d_x, int n, int hw, int c,
 int avs_segment_mean_f32(const float* d_x, int64_t ldx, int d, const int64_t* d_seg,
                          int nseg, float* d_out, int64_t ldo, avs_stream_t stream);
 
+/* Shot-boundary scan: d_sums[f, 0..2] = sum over the (strided) pixels of |H|,|S|,|V| differences
+ * between frame f and f-1 in OpenCV's 8-bit HSV (d_sums[0,:] = 0): the per-frame content score of PySceneDetect's
+ * ContentDetector is (sums / pixels).mean(), thresholded on the host (features/extractors.py:388-393).          */
+int avs_hsv_frame_diff_u8(const uint8_t* d_frames, int n, int h, int w, int step, uint32_t* d_sums,
+                          avs_stream_t stream);
+
 /* ---- audio front end (K8-K12) ------------------------------------------- */
 
 /* Reflect-pad a mono waveform by `pad` samples each side (torch.stft

@@ -380,3 +380,36 @@ def test_cdist_dtw_gather(dev):
     w = counts / counts.sum()
     goti = ops.gather_scale(feats.to(dev), torch.from_numpy(uniq).to(dev), torch.from_numpy(w).to(dev)).cpu()[:40]
     assert torch.equal(goti, refi)
+
+
+def _synthetic_video(n, h, w, cut_at, seed):
+    """Slowly drifting noise scenes with abrupt content changes at `cut_at`."""
+    rng = np.random.default_rng(seed)
+    frames = np.zeros((n, h, w, 3), dtype=np.uint8)
+    base = rng.integers(0, 256, (h, w, 3))
+    for f in range(n):
+        if f in cut_at:
+            base = rng.integers(0, 256, (h, w, 3))
+        frames[f] = np.clip(base + rng.integers(-3, 4, (h, w, 3)), 0, 255).astype(np.uint8)
+    return frames
+
+
+def test_shot_scan_vs_oracle(dev):
+    """HSV frame-difference sums are integer work: bit exact against the oracle; cuts and scenes identical."""
+    ops = _ops()
+    from avsum_amd.features import shots as gshots
+    from oracle import shots as oshots
+    video = _synthetic_video(70, 36, 52, {20, 27, 48}, 7)   # 27 is < min_scene_len after 20: suppressed
+    d = torch.from_numpy(video).to(dev)
+    sums = ops.hsv_frame_diff(d, 1).cpu().numpy()
+    ref = np.zeros((70, 3), dtype=np.int64)
+    hsv = [oshots.bgr2hsv_u8(f).astype(np.int64) for f in video]
+    for f in range(1, 70):
+        ref[f] = np.abs(hsv[f] - hsv[f - 1]).reshape(-1, 3).sum(0)
+    assert np.array_equal(sums, ref)
+    assert np.array_equal(gshots.content_scores(d, 1), oshots.content_scores(video, 1))
+    assert gshots.detect_shots(d) == oshots.detect_shots(video) == [(0, 20), (20, 48), (48, 70)]
+    wide = _synthetic_video(20, 40, 600, {16}, 8)            # 600 px wide: PySceneDetect strides by 2
+    assert gshots.downscale_factor(600) == 2
+    assert np.array_equal(gshots.content_scores(torch.from_numpy(wide).to(dev)), oshots.content_scores(wide, 2))
+    assert gshots.detect_shots(torch.from_numpy(_synthetic_video(30, 16, 16, set(), 9)).to(dev)) == []

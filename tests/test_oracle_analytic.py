@@ -123,3 +123,18 @@ def test_cv_resize_identity_and_constant():
     fr = ocnn.preprocess_frame(img)
     assert fr.shape == (1, 3, 224, 224) and fr.max() > 100  # NOT divided by 255
     assert ocnn.preprocess_inception(img).abs().max() < 3
+
+
+def test_shot_detector_restatement_known_answers():
+    from oracle import shots
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [128, 128, 128], [0, 0, 0], [255, 255, 255]]], np.uint8)
+    assert shots.bgr2hsv_u8(px)[0].tolist() == [[120, 255, 255], [60, 255, 255], [0, 255, 255], [0, 0, 128],
+                                                [0, 0, 0], [0, 0, 255]]   # OpenCV: blue 120, green 60, red 0
+    rng = np.random.default_rng(0)
+    a, b = rng.integers(0, 256, (24, 24, 3)).astype(np.uint8), rng.integers(0, 256, (24, 24, 3)).astype(np.uint8)
+    video = [a] * 20 + [b] * 20 + [a] * 5          # the last change comes 5 frames before the end
+    sc = shots.content_scores(video)
+    assert sc[0] == 0 and sc[1] == 0 and sc[20] > 27 and sc[40] > 27
+    assert shots.detect_shots(video) == [(0, 20), (20, 40), (40, 45)]
+    assert shots.detect_shots([a] * 30) == []      # no cut -> empty scene list, as scenedetect.detect returns
+    assert shots.detect_shots([a] * 10 + [b] * 30) == []  # a change before min_scene_len frames is not a cut
