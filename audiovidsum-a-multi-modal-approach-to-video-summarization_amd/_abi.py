@@ -15,6 +15,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "avsum_hip.h")
 AVS_F32, AVS_BF16, AVS_F32_ACC64 = 0, 1, 2
 ACT_NONE, ACT_RELU = 0, 1
 BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
+E_UNSUPPORTED = -6
 
 
 class AvsError(RuntimeError):
@@ -44,6 +45,11 @@ _SIGNATURES = {
     "avs_bn_finalize": (c_int, [P, P, c_int, c_int, c_int64, P, P, c_float, P, P, P]),
     "avs_conv1x1_bn_bf16": (c_int, [P, c_int64, c_int, P, c_int64, c_int, c_int64, c_int, P, P, c_float, P, c_int64,
                                     c_int, P, c_int64, P]),
+    "avs_conv2d_bnsync_workspace_bytes": (c_int64, [POINTER(ConvDesc), c_int64]),
+    "avs_conv2d_nhwc_bnsync": (c_int, [POINTER(ConvDesc), P, P, P, c_int64, P, P, c_float, P, c_int64, P, c_int64,
+                                       P, P]),
+    "avs_tune_bnsync_timeout_ticks": (None, [c_int64]),
+    "avs_debug_bnsync_trace": (None, [P]),
     "avs_tune_short_reduction_bytes": (None, [c_int]),
     "avs_debug_flags": (None, [c_int]),
     "avs_tune_pipeline": (None, [c_int]),

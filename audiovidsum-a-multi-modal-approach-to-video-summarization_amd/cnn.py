@@ -91,7 +91,14 @@ def _stem_weight(weight, px, dtype):
 
 
 class ResNet50Runner:
-    """Runs the container's parameters on uint8 frames [N,224,224,3] -> fp32 [N,2048]."""
+    """Runs the container's parameters on uint8 frames [N,224,224,3] -> fp32 [N,2048].
+
+    Batch-statistics BatchNorm (the reference's mode) has three forms here, chosen per layer:
+      sync    bf16, equal-sized groups: convolution + whole BatchNorm (+ residual + ReLU) in ONE launch whose tiles
+              wait for their group's statistics (avs_conv2d_nhwc_bnsync) - nothing raw in HBM, no second pass;
+      twopass bf16 1x1 layers: one workgroup walks a group twice (avs_conv1x1_bn_bf16);
+      split   convolution (+ statistics in its epilogue for bf16) -> avs_bn_finalize / avs_bn_batch_stats -> avs_bn_apply
+              (fp32 parity mode, ragged groups, shapes the other forms do not take)."""
 
     def __init__(self, trunk, dtype=torch.float32, bn_mode="batch"):
         if bn_mode not in ("batch", "folded"):
@@ -99,8 +106,16 @@ class ResNet50Runner:
         self.trunk, self.dtype, self.bn_mode = trunk, dtype, bn_mode
         self.fuse_conv_bn = True
         self.fuse_min_rows, self.fuse_ratio_num, self.fuse_ratio_den = 128, 2, 1
+        self.bn_sync = True
+        # measured on MI355X (tools/bn_study.py, 1024-frame chunk): a tile of the sync form waits for the SLOWEST
+        # tile of its group, so the form wins 1.1-1.35x where a group is two or three row tiles (14x14 and 7x7
+        # maps) and loses 3-5x where it is 25-100 of them (56x56, 112x112): taken up to this many rows per group
+        self.sync_max_group_rows = 256
         self._key = None
         self._w = None
+        self._plans = {}     # (n, group frames) -> per-layer (offset, bytes) | None of the sync form's workspace
+        self._ws = None
+        self._err = None
 
     # weights in kernel layout, rebuilt when the parameters change / move
     def _prepare(self):
@@ -127,57 +142,117 @@ class ResNet50Runner:
         self._w, self._key = w, key
         return w
 
-    def _conv1x1_bn(self, x, wt, cout, bnp, groups, hw, residual=None, relu=True):
-        """1x1 / stride-1 convolution + BatchNorm.  bf16 with equal-sized groups of >= 128 rows: one kernel
-        (statistics and normalised output in two passes over L2-resident operands, nothing raw in HBM);
-        otherwise the generic convolution + statistics + apply sequence."""
-        n, h, w_, cin = x.shape
-        grows, gmax, uniform = groups[hw]
-        # measured on MI355X: the one-kernel form wins where the layer is write-heavy (cout >= 2*cin: the conv3 /
-        # downsample layers) and a group is several row tiles long; it ties or loses on the wide-input conv1s
-        if (self.bn_mode == "batch" and uniform and self.dtype == torch.bfloat16 and self.fuse_conv_bn
-                and gmax >= self.fuse_min_rows and cout * self.fuse_ratio_den >= cin * self.fuse_ratio_num):
-            gamma, beta, eps, _, _ = bnp
-            y = torch.empty((n, h, w_, cout), dtype=self.dtype, device=x.device)
-            ops.conv1x1_bn(x.view(-1, cin), wt, gmax, gamma, beta, eps, y.view(-1, cout), residual, relu)
-            return y
+    # ---- convolution geometry (shared by the workspace plan and the forward pass) ----
+    @staticmethod
+    def _stem_geom(n):
+        # [N,230,232,4] pre-padded image; conv1 7x7/2 reads 8-pixel (32-element) runs: kh = 7 rows x 32 elements
+        return (n, 230, 112, 32, 7, 1, 2, 1, 0, 0, 112, 112, 64), (230 * 232 * 4, 232 * 4, 8), 7 * 32
 
-        def run(bnstats):
-            y = torch.empty((n, h, w_, cout), dtype=self.dtype, device=x.device)
-            r = ops.conv2d(x, wt, 1, 1, 1, 0, y, bnstats=bnstats)
-            return y, (r if bnstats is not None else None)
-        return self._conv_bn(run, cout, bnp, groups, hw, residual, relu)
+    @staticmethod
+    def _nhwc_geom(n, h, cin, k, s, p, cout):
+        ho = (h + 2 * p - k) // s + 1
+        return (n, h, h, cin, k, k, s, s, p, p, ho, ho, cout), (h * h * cin, h * cin, cin), k * k * cin
 
-    def _conv_bn(self, conv, c, bnp, groups, hw, residual=None, relu=True):
-        """Convolution `conv(bnstats) -> raw NHWC output` followed by BatchNorm (+residual, +ReLU), in place.
-        Batch-statistics mode with equal-sized groups takes the statistics from the convolution's epilogue;
-        ragged groups (a shot whose frame count is not a multiple of 4) use the separate statistics pass."""
+    def _layer_geoms(self, n):
+        """Every convolution of the trunk in forward order: (geometry, x strides, weight row stride)."""
+        yield self._stem_geom(n)
+        h, cin = 56, 64
+        for li, (planes, blocks, stride) in enumerate(((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))):
+            for b in range(blocks):
+                s = stride if b == 0 else 1
+                hout = h // s
+                yield self._nhwc_geom(n, h, cin, 1, 1, 0, planes)
+                yield self._nhwc_geom(n, h, planes, 3, s, 1, planes)
+                if b == 0:
+                    yield self._nhwc_geom(n, h, cin, 1, s, 0, planes * 4)
+                yield self._nhwc_geom(n, hout, planes, 1, 1, 0, planes * 4)
+                h, cin = hout, planes * 4
+
+    def _sync_plan(self, n, gsz, dev):
+        """Workspace layout of the sync form for n frames in groups of gsz: per layer (offset, bytes) or None."""
+        key = (n, gsz, self.sync_max_group_rows)
+        plan = self._plans.get(key)
+        if plan is None:
+            dcode = ops.dtype_code(self.dtype)
+            plan, off = [], 0
+            for geom, xs, wrs in self._layer_geoms(n):
+                ho, wo, cout = geom[10], geom[11], geom[12]
+                nbytes = None
+                if gsz * ho * wo <= self.sync_max_group_rows:
+                    nbytes = ops.conv_bnsync_workspace_bytes(dcode, *geom, *xs, wrs, cout, gsz * ho * wo)
+                plan.append(None if nbytes is None else (off, nbytes))
+                off += nbytes or 0
+            plan.append(off)
+            if len(self._plans) > 64:
+                self._plans.clear()
+            self._plans[key] = plan
+        total = plan[-1]
+        if self._ws is None or self._ws.numel() < total or self._ws.device != dev:
+            self._ws = torch.empty(max(total, 256), dtype=torch.uint8, device=dev)
+        if self._err is None or self._err.device != dev:
+            self._err = torch.zeros(1, dtype=torch.int32, device=dev)
+        if total:
+            self._ws[:total].zero_()   # statistics and arrival counters of every layer of this pass: one fill
+        return plan
+
+    def sync_failed(self):
+        """True when a group wait of the sync form timed out since the last call (host sync; clears the word).
+        Results produced since are void: recompute with ``bn_sync = False``."""
+        if self._err is None:
+            return False
+        bad = bool(self._err.item())
+        if bad:
+            self._err.zero_()
+        return bad
+
+    def _conv_bn(self, geom, xs, x, wt, bnp, groups, residual=None, relu=True, sync=None, algo_k=None):
+        """One convolution + BatchNorm (+ residual, + ReLU) -> NHWC activation; picks the form (class docstring)."""
+        n, ho, wo, cout = geom[0], geom[10], geom[11], geom[12]
+        cin, kh, sh = geom[3], geom[4], geom[6]
+        dev, dt = x.device, self.dtype
+        dcode = ops.dtype_code(dt)
         gamma, beta, eps, rmean, rvar = bnp
         act = ops.ACT_RELU if relu else ops.ACT_NONE
-        if self.bn_mode == "batch":
-            grows, gmax, uniform = groups[hw]
-            # the epilogue statistics are E[x^2]-E[x]^2 sums added with float atomics: fine for bf16 activations,
-            # not for the fp32 parity mode (which keeps the shifted, deterministic statistics pass)
-            if uniform and self.dtype == torch.bfloat16:
-                raw, (scale, shift) = conv((gmax, gamma, beta, eps))
-                raw2d = raw.view(-1, c)
-            else:
-                raw, _ = conv(None)
-                raw2d = raw.view(-1, c)
-                scale, shift = ops.bn_batch_stats(raw2d, grows, gamma, beta, eps)
-            ops.bn_apply(raw2d, scale, shift, grows, gmax, residual, act, raw2d)
-            return raw
-        raw, _ = conv(None)
-        raw2d = raw.view(-1, c)
-        scale = (gamma / torch.sqrt(rvar + eps)).contiguous()
-        shift = (beta - rmean * scale).contiguous()
-        ops.bn_apply(raw2d, scale.view(1, -1), shift.view(1, -1), None, 0, residual, act, raw2d)
-        return raw
+        y = torch.empty((n, ho, wo, cout), dtype=dt, device=dev)
+        y2d = y.view(-1, cout)
 
-    def forward(self, frames_u8, group_frames=None, out=None):
+        def conv(**kw):
+            return ops.conv2d_raw(dcode, *geom, x, *xs, wt, wt.stride(0), y, cout, algo_k=algo_k, **kw)
+
+        if self.bn_mode != "batch":
+            conv()
+            scale = (gamma / torch.sqrt(rvar + eps)).contiguous()
+            shift = (beta - rmean * scale).contiguous()
+            ops.bn_apply(y2d, scale.view(1, -1), shift.view(1, -1), None, 0, residual, act, y2d)
+            return y
+        grows, gmax, uniform = groups[ho * wo]
+        fast = uniform and dt == torch.bfloat16
+        if fast and sync is not None:
+            off, nbytes = sync
+            conv(act=act, bnsync=(gmax, gamma, beta, eps, residual, self._ws[off:off + nbytes], self._err))
+            return y
+        # measured on MI355X: the two-pass kernel wins over the split form where the layer is write-heavy
+        # (cout >= 2*cin: the conv3 / downsample layers) and a group is several row tiles long
+        if (fast and kh == 1 and sh == 1 and self.fuse_conv_bn and gmax >= self.fuse_min_rows
+                and cout * self.fuse_ratio_den >= cin * self.fuse_ratio_num):
+            ops.conv1x1_bn(x.view(-1, cin), wt, gmax, gamma, beta, eps, y2d, residual, relu)
+            return y
+        if fast:
+            # statistics from the convolution's epilogue (E[x^2]-E[x]^2 by float atomics: fine for bf16 activations)
+            scale, shift = conv(bnstats=(gmax, gamma, beta, eps))
+        else:
+            # fp32 parity mode / ragged groups: the shifted, deterministic statistics pass
+            conv()
+            scale, shift = ops.bn_batch_stats(y2d, grows, gamma, beta, eps)
+        ops.bn_apply(y2d, scale, shift, grows, gmax, residual, act, y2d)
+        return y
+
+    def forward(self, frames_u8, group_frames=None, out=None, check=True):
         """frames_u8: device uint8 [N,224,224,3] (already 224x224, extractors.py:132).
         group_frames: int64 CPU tensor / list [G+1] of frame offsets of the BatchNorm micro-batch groups
-        (extractors.py:48-56); default = one group per frame."""
+        (extractors.py:48-56); default = one group per frame.
+        check: verify (host sync) that no group wait of the sync form timed out, and recompute without it if one
+        did; a caller that batches many passes sets False and polls ``sync_failed()`` itself."""
         n, h, w_, _ = frames_u8.shape
         if (h, w_) != (224, 224):
             raise ValueError("ResNet50Runner expects 224x224 frames (resize first)")
@@ -195,26 +270,16 @@ class ResNet50Runner:
         uniform = bool((sizes == gsz).all())
         groups = {hw: ((group_frames * hw).to(dev), gsz * hw, uniform)
                   for hw in (112 * 112, 56 * 56, 28 * 28, 14 * 14, 7 * 7)}
-        dcode = ops.dtype_code(dt)
+        use_sync = self.bn_sync and self.bn_mode == "batch" and uniform and dt == torch.bfloat16
+        plan = iter(self._sync_plan(n, gsz, dev)[:-1]) if use_sync else None
 
-        def conv_op(x, wt, k, s, p, cout, hout):
-            def run(bnstats):
-                y = torch.empty((n, hout, hout, cout), dtype=dt, device=dev)
-                r = ops.conv2d(x, wt, k, k, s, p, y, bnstats=bnstats)
-                return y, (r if bnstats is not None else None)
-            return run
+        def slot():
+            return next(plan) if plan is not None else None
 
-        # stem: (x - mean)/std without /255 (extractors.py:133-139), zero padded by 3 (conv1 pad) into
-        # [N,230,232,4]; conv1 7x7/2 reads 8-pixel (32-element) runs: kh=7 rows x 32 elements.
+        # stem: (x - mean)/std without /255 (extractors.py:133-139), zero padded by 3 (conv1 pad)
         x0 = ops.frames_normalize(frames_u8, dt, 1.0, RESNET_MEAN, RESNET_STD, 230, 232, 3, 3)
-
-        def stem(bnstats):
-            y = torch.empty((n, 112, 112, 64), dtype=dt, device=dev)
-            r = ops.conv2d_raw(dcode, n, 230, 112, 32, 7, 1, 2, 1, 0, 0, 112, 112, 64, x0, 230 * 232 * 4, 232 * 4, 8,
-                               w["stem"], w["stem"].stride(0), y, 64, algo_k=147, bnstats=bnstats)
-            return y, r
-
-        a1 = self._conv_bn(stem, 64, w["bn1"], groups, 112 * 112)
+        geom, xs, _ = self._stem_geom(n)
+        a1 = self._conv_bn(geom, xs, x0, w["stem"], w["bn1"], groups, sync=slot(), algo_k=147)
         del x0
         x = torch.empty((n, 56, 56, 64), dtype=dt, device=dev)
         ops.pool2d(a1, "max", 3, 2, 1, x)
@@ -224,21 +289,29 @@ class ResNet50Runner:
             s, planes = blk["stride"], blk["planes"]
             cin = x.shape[3]
             hout = hcur // s
-            t1 = self._conv1x1_bn(x, blk["c1"], planes, blk["b1"], groups, hcur * hcur)
-            t2 = self._conv_bn(conv_op(t1, blk["c2"], 3, s, 1, planes, hout), planes, blk["b2"], groups, hout * hout)
+            geom, xs, _ = self._nhwc_geom(n, hcur, cin, 1, 1, 0, planes)
+            t1 = self._conv_bn(geom, xs, x, blk["c1"], blk["b1"], groups, sync=slot())
+            geom, xs, _ = self._nhwc_geom(n, hcur, planes, 3, s, 1, planes)
+            t2 = self._conv_bn(geom, xs, t1, blk["c2"], blk["b2"], groups, sync=slot())
             del t1
-            if "cd" in blk and s == 1:
-                idn = self._conv1x1_bn(x, blk["cd"], planes * 4, blk["bd"], groups, hout * hout,
-                                       relu=False).view(-1, planes * 4)
-            elif "cd" in blk:
-                idn = self._conv_bn(conv_op(x, blk["cd"], 1, s, 0, planes * 4, hout), planes * 4, blk["bd"], groups,
-                                    hout * hout, relu=False).view(-1, planes * 4)
+            if "cd" in blk:
+                geom, xs, _ = self._nhwc_geom(n, hcur, cin, 1, s, 0, planes * 4)
+                idn = self._conv_bn(geom, xs, x, blk["cd"], blk["bd"], groups, relu=False,
+                                    sync=slot()).view(-1, planes * 4)
             else:
                 idn = x.view(-1, cin)
-            x = self._conv1x1_bn(t2, blk["c3"], planes * 4, blk["b3"], groups, hout * hout, residual=idn, relu=True)
+            geom, xs, _ = self._nhwc_geom(n, hout, planes, 1, 1, 0, planes * 4)
+            x = self._conv_bn(geom, xs, t2, blk["c3"], blk["b3"], groups, residual=idn, relu=True, sync=slot())
             del t2, idn
             hcur = hout
-        return ops.global_avgpool(x, out)
+        feats = ops.global_avgpool(x, out)
+        if use_sync and check and self.sync_failed():
+            import warnings
+            warnings.warn("avsum_amd: a BatchNorm group wait timed out on the device; recomputing on the two-pass "
+                          "path and disabling the one-launch form for this runner")
+            self.bn_sync = False
+            return self.forward(frames_u8, group_frames, out, check)
+        return feats
 
 
 # ============================================================================ Inception-v3 container

@@ -57,6 +57,18 @@ struct IgemmParams {
   float* stat_sq;
   int rows_per_group;
   long long lin_stride;  // >= 0: output row m reads input row m at x + m*lin_stride (no (n,ho,wo) decode needed)
+  // EPI_BNSYNC (whole BatchNorm in the epilogue): arrival counters [groups][tiles_n] (zeroed by the caller together
+  // with stat_sum / stat_sq), the error word a timed-out wait sets, BatchNorm parameters, optional residual
+  unsigned* arrive;
+  int* err;
+  const float* gamma;
+  const float* beta;
+  float eps;
+  const char* residual;
+  long long ldr;
+  int tiles_m;
+  long long spin_ticks;
+  long long* trace;  // kernel-study only: per block {xcc id, start, arrive, wait end} wall-clock ticks
   int debug;  // ablation switches for kernel studies (0 in production): 1 = skip output stores, 2 = skip A/B loads
 };
 
@@ -72,7 +84,16 @@ struct IgemmParams {
 //   EPI_STATS  EPI_PLAIN + fused BatchNorm batch statistics
 //   EPI_ANY    everything decided at run time (bias per column / row, ReLU, alpha)
 //   EPI_BRELU  alpha == 1, bias per column, ReLU (the folded-BatchNorm convolutions of Inception-v3; Linear+ReLU)
-enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_ANY = 2, EPI_BRELU = 3 };
+//   EPI_BNSYNC bf16 only: the whole batch-statistics BatchNorm (+ residual, + ReLU) in the epilogue.  A tile adds its
+//              column sums to the group statistics (float atomics), signals an arrival counter per (group, column
+//              tile), WAITS until every tile of its group(s) has arrived — its accumulators stay in registers
+//              meanwhile — and then normalises and stores the final activation: the raw convolution never goes
+//              to HBM and there is no second pass.  Tiles of one group are dealt to neighbouring dispatch slots
+//              (see the tile map below), so the wait is the dispatch skew of a few dozen workgroups; the launcher
+//              only takes this form when a group's tiles fit the resident set several times over, and a wait that
+//              exceeds spin_ticks sets *err instead of hanging (the host then recomputes on the unfused path).
+enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_ANY = 2, EPI_BRELU = 3, EPI_BNSYNC = 4 };
+constexpr int BNSYNC_MAX_GROUPS = 4;  // groups one 128-row tile may overlap
 
 // PIPE: three operand buffers, the DMA of step s+2 is issued in step s; fragment reads are inline-asm
 // ds_read_b128 and the waits are hand-counted (s_waitcnt vmcnt(N) + raw s_barrier), because hipcc orders every
@@ -103,7 +124,8 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64) ? 3 : 2) void igemm_ker
   constexpr int CT_PITCH = BN * 2 + 16;      // bf16 epilogue staging tile: row pitch in bytes (16 bytes of padding)
   constexpr int CT_SLOTS = ES == 2 ? (A_ROWS * CT_PITCH) / 16 : 0;
   constexpr int NBUF = PIPE ? 3 : 2;
-  constexpr int LDS_SLOTS = NBUF * BUF > CT_SLOTS ? NBUF * BUF : CT_SLOTS;
+  constexpr int TAB_SLOTS = EPI == EPI_BNSYNC ? (BNSYNC_MAX_GROUPS * 2 * BN * 4) / 16 : 0;  // scale/shift table
+  constexpr int LDS_SLOTS = NBUF * BUF > CT_SLOTS + TAB_SLOTS ? NBUF * BUF : CT_SLOTS + TAB_SLOTS;
 
   __shared__ uint4 lds[LDS_SLOTS];
 
@@ -112,8 +134,22 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64) ? 3 : 2) void igemm_ker
   const unsigned nwg = gridDim.x, orig = blockIdx.x;
   const unsigned q = nwg >> 3, rr = nwg & 7, xcd = orig & 7;
   const unsigned wg = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
-  const int tn = wg % p.tiles_n;
-  const int tm = wg / p.tiles_n;
+  int tn = wg % p.tiles_n;
+  int tm = wg / p.tiles_n;
+  if constexpr (EPI == EPI_BNSYNC) {
+    // Dispatch-ordered map: blocks are dealt round-robin over the XCDs (orig & 7) and started in order, so the
+    // eight blocks of one dispatch level take eight consecutive row tiles and the levels walk the column tiles
+    // first: the tiles of one BatchNorm group start within a few levels of each other on every XCD (short
+    // waits), and the column tiles of one row tile share an XCD (A rows re-read from its L2).
+    const unsigned lvl = orig >> 3;
+    tn = lvl % p.tiles_n;
+    tm = (lvl / p.tiles_n) * 8 + xcd;
+    if (tm >= p.tiles_m) return;  // grid padding (rows of tiles rounded up to 8)
+    if (p.trace && threadIdx.x == 0) {
+      p.trace[4ll * orig + 0] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) ;  // HW_REG_XCC_ID[3:0]
+      p.trace[4ll * orig + 1] = wall_clock64();
+    }
+  }
   const int m0 = tm * A_ROWS;
   const int n0 = tn * BN;
 
@@ -364,7 +400,23 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64) ? 3 : 2) void igemm_ker
 
   // ---- epilogue ----
   // Register e of a 32x32 tile is row (e&3) + 8*(e>>2) + 4*lh, column lr.
-  if constexpr (EPI == EPI_STATS) {
+  constexpr int E_CPRW = BN / 8;           // 16-byte chunks per bf16 tile row
+  constexpr int E_RSTEP = 256 / E_CPRW;    // tile rows covered by one pass of the 256 threads
+  constexpr int E_NIT = A_ROWS / E_RSTEP;
+  uint4 resv[EPI == EPI_BNSYNC ? E_NIT : 1];
+  if constexpr (EPI == EPI_BNSYNC) {
+    // the residual rows this thread will add in the store phase: issued now, landed by the end of the wait
+    if (p.residual) {
+      const int srow = t / E_CPRW, sch = t - srow * E_CPRW;
+#pragma unroll
+      for (int it = 0; it < E_NIT; ++it) {
+        const int row = m0 + srow + it * E_RSTEP;
+        resv[it] = row < p.M ? *reinterpret_cast<const uint4*>(p.residual + ((long long)row * p.ldr + n0 + sch * 8) * 2)
+                             : make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+  }
+  if constexpr (EPI == EPI_STATS || EPI == EPI_BNSYNC) {
     // Fused batch statistics.  A lane owns one column of each 32-wide tile: it sums its 2 x 16 rows per
     // group, the two lane halves are folded by one shuffle, and lanes 0..31 issue one atomic pair per
     // (group, column).  Rows past M hold exact zeros and add nothing.
@@ -414,6 +466,133 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64) ? 3 : 2) void igemm_ker
         }
       }
     }
+  }
+  if constexpr (EPI == EPI_BNSYNC) {
+    static_assert(EPI != EPI_BNSYNC || ES == 2, "the synchronised BatchNorm epilogue is the bf16 throughput path");
+    char* ct = reinterpret_cast<char*>(lds);
+    float* tab = reinterpret_cast<float*>(ct + CT_SLOTS * 16);  // [group][scale | shift][BN]
+    const int rpg = p.rows_per_group;
+    const int m_last = (m0 + A_ROWS < p.M ? m0 + A_ROWS : p.M) - 1;
+    const int g_lo = m0 / rpg;
+    const int ng = m_last / rpg - g_lo + 1;  // <= BNSYNC_MAX_GROUPS (launcher)
+    // 1. every wave's statistics atomics have been performed, then one lane per group signals and waits
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t < ng) {
+      const int g = g_lo + t;
+      const long long first = (long long)g * rpg, last = first + rpg < p.M ? first + rpg - 1 : (long long)p.M - 1;
+      const unsigned expected = (unsigned)(last / A_ROWS - first / A_ROWS + 1);
+      unsigned* ctr = p.arrive + (long long)g * p.tiles_n + tn;
+      __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const long long t0 = wall_clock64();
+      if (p.trace && t == 0) p.trace[4ll * orig + 2] = t0;
+      const int nap = (p.debug >> 2) & 3;  // kernel-study knob: poll interval (production = 0: ~1 us)
+      unsigned polls = 0;
+      while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
+        // poll sparsely: hundreds of tiles wait at any time, and their polls share the memory system with the loads
+        if (nap == 0)
+          __builtin_amdgcn_s_sleep(32);
+        else if (nap == 1)
+          __builtin_amdgcn_s_sleep(4);
+        else if (nap == 2)
+          __builtin_amdgcn_s_sleep(127);
+        else
+          __builtin_amdgcn_s_sleep(12);
+        if ((polls++ & 15u) == 0 &&
+            (wall_clock64() - t0 > p.spin_ticks ||
+             __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // results of this launch are void
+          break;
+        }
+      }
+    }
+    if (p.trace && t == 0) p.trace[4ll * orig + 3] = wall_clock64();
+    __syncthreads();
+    // 2. folded affine of the tile's groups and columns (the statistics were written by agent-scope atomics only
+    //    and are read by agent-scope loads only)
+    {
+      const float inv_n = 1.f / (float)rpg;
+      for (int i = t; i < ng * BN; i += 256) {
+        const int k = i / BN, cc = i - k * BN;
+        const long long idx = (long long)(g_lo + k) * p.N + n0 + cc;
+        const float s1 = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p.stat_sum) + idx,
+                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const float s2 = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p.stat_sq) + idx,
+                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const float mean = s1 * inv_n;
+        const float var = fmaxf(s2 * inv_n - mean * mean, 0.f);
+        const float sc = p.gamma[n0 + cc] / sqrtf(var + p.eps);
+        tab[(2 * k) * BN + cc] = sc;
+        tab[(2 * k + 1) * BN + cc] = p.beta[n0 + cc] - mean * sc;
+      }
+    }
+    __syncthreads();
+    // 3. normalise the accumulators into the bf16 staging tile (ReLU here when there is no residual)
+    const bool relu_now = p.act == AVS_ACT_RELU && p.residual == nullptr;
+    {
+      char* cbase = ct + (wr * 64 + 4 * lh) * CT_PITCH + (wc * (BN / 2) + lr) * 2;
+      const int rel0 = wr * 64 + 4 * lh;                 // tile-relative row of roff = 0
+      const int b1 = (g_lo + 1) * rpg - m0 - rel0;       // roff at which the tile's 2nd / 3rd / 4th group starts
+      const int b2 = b1 + rpg, b3 = b2 + rpg;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int cc = wc * (BN / 2) + nt * 32 + lr;
+        if (ng == 1) {
+          const float sc = tab[cc], sf = tab[BN + cc];
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int roff = mt * 32 + (e & 3) + 8 * (e >> 2);
+              float v = fmaf(acc[mt][nt][e], sc, sf);
+              if (relu_now) v = fmaxf(v, 0.f);
+              *reinterpret_cast<unsigned short*>(cbase + roff * CT_PITCH + nt * 64) = avs_f32_to_bf16(v);
+            }
+        } else {
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int roff = mt * 32 + (e & 3) + 8 * (e >> 2);
+              const int k = (roff >= b1) + (roff >= b2) + (roff >= b3);
+              float v = fmaf(acc[mt][nt][e], tab[(2 * k) * BN + cc], tab[(2 * k + 1) * BN + cc]);
+              if (relu_now) v = fmaxf(v, 0.f);
+              *reinterpret_cast<unsigned short*>(cbase + roff * CT_PITCH + nt * 64) = avs_f32_to_bf16(v);
+            }
+        }
+      }
+    }
+    __syncthreads();
+    // 4. 16-byte row-major stores (+ residual, + ReLU)
+    {
+      const int srow = t / E_CPRW, sch = t - srow * E_CPRW;
+      const char* srcp = ct + srow * CT_PITCH + sch * 16;
+      char* dst = y + ((long long)(m0 + srow) * p.ldc + n0 + sch * 8) * 2;
+      const long long dstep = (long long)E_RSTEP * p.ldc * 2;
+      const bool relu_res = p.act == AVS_ACT_RELU;
+#pragma unroll
+      for (int it = 0; it < E_NIT; ++it) {
+        if (m0 + srow + it * E_RSTEP >= p.M) break;
+        uint4 v = *reinterpret_cast<const uint4*>(srcp + it * E_RSTEP * CT_PITCH);
+        if (p.residual) {
+          unsigned vv[4] = {v.x, v.y, v.z, v.w};
+          const unsigned rv[4] = {resv[it].x, resv[it].y, resv[it].z, resv[it].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float lo = __uint_as_float(vv[j] << 16) + __uint_as_float(rv[j] << 16);
+            float hi = __uint_as_float(vv[j] & 0xffff0000u) + __uint_as_float(rv[j] & 0xffff0000u);
+            if (relu_res) {
+              lo = fmaxf(lo, 0.f);
+              hi = fmaxf(hi, 0.f);
+            }
+            vv[j] = (unsigned)avs_f32_to_bf16(lo) | ((unsigned)avs_f32_to_bf16(hi) << 16);
+          }
+          v = make_uint4(vv[0], vv[1], vv[2], vv[3]);
+        }
+        *reinterpret_cast<uint4*>(dst + it * dstep) = v;
+      }
+    }
+    return;
   }
   if constexpr (ES == 2) {
     // bf16: through LDS, then 16-byte row-major stores.  Every per-element LDS address is a per-lane base plus
@@ -524,10 +703,23 @@ static int g_pipe3 = 1;  // 1: the 3-buffer hand-counted pipeline for the 64-byt
 extern "C" void avs_tune_pipeline(int enabled) { g_pipe3 = enabled; }
 
 template <int ES, int BN, bool ACC64, bool SP, int ROWB, bool PIPE>
-static void igemm_dispatch_epi2(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p) {
+static void igemm_dispatch_epi2(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p, int* occ) {
   if constexpr (ACC64) {
     hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_ANY, false>), grid, dim3(256), 0, stream, p);
   } else {
+    if constexpr (ES == 2) {
+      if (epi == EPI_BNSYNC) {
+        // occ != nullptr: report how many workgroups of this variant one CU holds instead of launching it
+        if (occ) {
+          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                  occ, igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BNSYNC, PIPE>, 256, 0) != hipSuccess)
+            *occ = 0;
+        } else {
+          hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BNSYNC, PIPE>), grid, dim3(256), 0, stream, p);
+        }
+        return;
+      }
+    }
     if (epi == EPI_PLAIN)
       hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_PLAIN, PIPE>), grid, dim3(256), 0, stream, p);
     else if (epi == EPI_STATS)
@@ -540,39 +732,43 @@ static void igemm_dispatch_epi2(int epi, dim3 grid, hipStream_t stream, const Ig
 }
 
 template <int ES, int BN, bool ACC64, bool SP, int ROWB>
-static void igemm_dispatch_epi(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p) {
+static void igemm_dispatch_epi(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p, int* occ) {
   if constexpr (ROWB == 64 && !ACC64) {
     if (g_pipe3 && p.K * ES > 2 * ROWB) {  // at least three steps, else there is nothing to pipeline
-      igemm_dispatch_epi2<ES, BN, ACC64, SP, ROWB, true>(epi, grid, stream, p);
+      igemm_dispatch_epi2<ES, BN, ACC64, SP, ROWB, true>(epi, grid, stream, p, occ);
       return;
     }
   }
-  igemm_dispatch_epi2<ES, BN, ACC64, SP, ROWB, false>(epi, grid, stream, p);
+  igemm_dispatch_epi2<ES, BN, ACC64, SP, ROWB, false>(epi, grid, stream, p, occ);
 }
 
 template <int ES, int BN, bool ACC64>
-static void igemm_dispatch(bool spatial, dim3 grid, hipStream_t stream, const IgemmParams& p) {
+static void igemm_dispatch(bool spatial, dim3 grid, hipStream_t stream, const IgemmParams& p, int* occ = nullptr) {
   const_cast<IgemmParams&>(p).debug = g_debug_flags;
   const bool short_k = (long long)p.K * ES <= g_rowb_threshold_bytes;
   int epi = EPI_ANY;
-  if (p.bias_mode == AVS_BIAS_NONE && p.act == AVS_ACT_NONE && p.alpha == 1.0f)
+  if (p.arrive)
+    epi = EPI_BNSYNC;
+  else if (p.bias_mode == AVS_BIAS_NONE && p.act == AVS_ACT_NONE && p.alpha == 1.0f)
     epi = p.stat_sum ? EPI_STATS : EPI_PLAIN;
   else if (p.bias_mode == AVS_BIAS_COL && p.act == AVS_ACT_RELU && p.alpha == 1.0f && !p.stat_sum)
     epi = EPI_BRELU;
   if (short_k) {
     if (spatial)
-      igemm_dispatch_epi<ES, BN, ACC64, true, 64>(epi, grid, stream, p);
+      igemm_dispatch_epi<ES, BN, ACC64, true, 64>(epi, grid, stream, p, occ);
     else
-      igemm_dispatch_epi<ES, BN, ACC64, false, 64>(epi, grid, stream, p);
+      igemm_dispatch_epi<ES, BN, ACC64, false, 64>(epi, grid, stream, p, occ);
   } else {
     if (spatial)
-      igemm_dispatch_epi<ES, BN, ACC64, true, 128>(epi, grid, stream, p);
+      igemm_dispatch_epi<ES, BN, ACC64, true, 128>(epi, grid, stream, p, occ);
     else
-      igemm_dispatch_epi<ES, BN, ACC64, false, 128>(epi, grid, stream, p);
+      igemm_dispatch_epi<ES, BN, ACC64, false, 128>(epi, grid, stream, p, occ);
   }
 }
 
-static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream, const char* who) {
+// occ != nullptr: validate and select the variant as for a launch, but only report its occupancy (EPI_BNSYNC)
+static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream, const char* who,
+                        int* occ = nullptr) {
   const int es = dtype == AVS_BF16 ? 2 : 4;
   const int ce = 16 / es;
   AVS_REQUIRE(dtype == AVS_F32 || dtype == AVS_BF16 || dtype == AVS_F32_ACC64, AVS_E_ARG, "%s: bad dtype %d", who,
@@ -580,7 +776,7 @@ static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream
   AVS_REQUIRE(p.M >= 0 && p.N > 0 && p.K > 0 && batch > 0, AVS_E_SHAPE, "%s: bad sizes M=%d N=%d K=%d batch=%d", who,
               p.M, p.N, p.K, batch);
   if (p.M == 0) return AVS_OK;
-  AVS_REQUIRE(p.x && p.w && p.y, AVS_E_ARG, "%s: null operand", who);
+  AVS_REQUIRE(occ || (p.x && p.w && p.y), AVS_E_ARG, "%s: null operand", who);
   AVS_REQUIRE(p.bias_mode == AVS_BIAS_NONE || p.bias, AVS_E_ARG, "%s: bias mode %d without bias", who, p.bias_mode);
   AVS_REQUIRE(p.cin % ce == 0 && p.K % ce == 0, AVS_E_SHAPE,
               "%s: cin=%d / K=%d must be multiples of %d elements (16 bytes)", who, p.cin, p.K, ce);
@@ -595,8 +791,13 @@ static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream
   const int bn = narrow ? 64 : 128;
   p.tiles_n = (p.N + bn - 1) / bn;
   const long long tiles_m = ((long long)p.M + 127) / 128;
-  const long long total = tiles_m * p.tiles_n;
+  long long total = tiles_m * p.tiles_n;
+  if (p.arrive) {  // EPI_BNSYNC deals eight row tiles per dispatch level: pad the rows of tiles to a multiple of 8
+    p.tiles_m = (int)tiles_m;
+    total = (tiles_m + 7) / 8 * 8 * p.tiles_n;
+  }
   AVS_REQUIRE(total < (1ll << 31), AVS_E_SHAPE, "%s: too many tiles", who);
+  AVS_REQUIRE(!occ || dtype == AVS_BF16, AVS_E_ARG, "%s: occupancy query is for the bf16 variants", who);
   // the per-tap bounds tests are only needed when a tap can leave the image
   const bool spatial = !(p.ph == 0 && p.pw == 0 && (p.HoWo / p.Wo - 1) * p.sh + (p.K / (p.cin * p.KW)) - 1 < p.H &&
                          (p.Wo - 1) * p.sw + p.KW - 1 < p.W);
@@ -611,9 +812,10 @@ static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream
   dim3 grid((unsigned)total, 1, (unsigned)batch);
   if (dtype == AVS_BF16) {
     if (narrow)
-      igemm_dispatch<2, 64, false>(spatial, grid, stream, p);
+      igemm_dispatch<2, 64, false>(spatial, grid, stream, p, occ);
     else
-      igemm_dispatch<2, 128, false>(spatial, grid, stream, p);
+      igemm_dispatch<2, 128, false>(spatial, grid, stream, p, occ);
+    if (occ) return AVS_OK;
   } else if (dtype == AVS_F32_ACC64) {
     igemm_dispatch<4, 64, true>(spatial, grid, stream, p);
   } else {
@@ -695,6 +897,102 @@ extern "C" int avs_conv2d_nhwc_bnstats(const avs_conv_desc* d, const void* d_x, 
   p.stat_sq = d_sumsq;
   p.rows_per_group = (int)rows_per_group;
   return igemm_launch(d->dtype, p, 1, (hipStream_t)stream, "avs_conv2d_nhwc_bnstats");
+}
+
+// ---- convolution + whole BatchNorm in one launch (EPI_BNSYNC) ----
+static int g_cu_count = 0;
+
+static int bnsync_plan(const avs_conv_desc* d, int64_t rpg, IgemmParams& p, int64_t* ws_bytes, const char* who) {
+  int st = conv_fill_params(d, (const void*)16, (const void*)16, nullptr, (void*)16, p, who);
+  if (st != AVS_OK) return st;
+  AVS_REQUIRE(rpg > 0, AVS_E_ARG, "%s: rows_per_group must be positive", who);
+  if (p.M == 0) {
+    *ws_bytes = 0;
+    return AVS_OK;
+  }
+  const int bn = p.N <= 64 ? 64 : 128;
+  const bool shape_ok = d->dtype == AVS_BF16 && p.N % bn == 0 && p.M % rpg == 0 && rpg < (1ll << 30) &&
+                        (127 + rpg - 1) / rpg + 1 <= BNSYNC_MAX_GROUPS && d->alpha == 1.0f &&
+                        (p.ldc * 2) % 16 == 0;
+  AVS_REQUIRE(shape_ok, AVS_E_UNSUPPORTED,
+              "%s: needs bf16, cout a multiple of %d, equal groups of >= 43 rows, 16-byte aligned output rows", who, bn);
+  p.tiles_n = p.N / bn;
+  // Forward progress: a waiting tile holds its slot, so every tile a wait depends on must get a slot while the
+  // waiters sit.  Blocks are dealt round-robin over the XCDs and started in order; one XCD runs one block of every
+  // dispatch level.  A tile only waits for tiles of its own column tile whose row tiles lie within the 8-tile
+  // blocks its groups touch, i.e. at most `span` levels away.  If an XCD holds S workgroups, a cycle of XCDs
+  // blocked on each other needs span > S - 1; the form is only taken at span <= S / 2 (also what keeps waits short).
+  if (g_cu_count == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      g_cu_count = prop.multiProcessorCount;
+    AVS_REQUIRE(g_cu_count > 0, AVS_E_HIP, "%s: cannot read the CU count", who);
+  }
+  int occ = 0;
+  p.arrive = reinterpret_cast<unsigned*>(16);  // selects the EPI_BNSYNC variant in the dispatch
+  st = igemm_launch(AVS_BF16, p, 1, nullptr, who, &occ);
+  p.arrive = nullptr;
+  if (st != AVS_OK) return st;
+  const long long tiles_per_group = (rpg + 127) / 128 + 1;         // row tiles one group can overlap
+  const long long blocks = (tiles_per_group - 1 + 7) / 8 + 1;      // 8-tile dispatch blocks those can touch
+  const long long span = (blocks - 1) * p.tiles_n;
+  const long long slots_per_xcd = (long long)(g_cu_count / 8) * occ;
+  AVS_REQUIRE(span * 2 <= slots_per_xcd, AVS_E_UNSUPPORTED,
+              "%s: the tiles of a %lld-row group start up to %lld dispatch levels apart, more than half of the %lld "
+              "workgroups an XCD holds", who, (long long)rpg, span, slots_per_xcd);
+  const long long groups = p.M / rpg;
+  *ws_bytes = (int64_t)((8 * groups * p.N + 4 * groups * p.tiles_n + 255) / 256 * 256);
+  return AVS_OK;
+}
+
+extern "C" int64_t avs_conv2d_bnsync_workspace_bytes(const avs_conv_desc* d, int64_t rows_per_group) {
+  IgemmParams p{};
+  int64_t ws = 0;
+  const int st = bnsync_plan(d, rows_per_group, p, &ws, "avs_conv2d_bnsync_workspace_bytes");
+  return st == AVS_OK ? ws : (int64_t)st;
+}
+
+static long long* g_bnsync_trace = nullptr;
+extern "C" void avs_debug_bnsync_trace(void* d_trace) { g_bnsync_trace = (long long*)d_trace; }
+static long long g_bnsync_spin_ticks = 5000000;  // 50 ms of the 100 MHz wall clock
+extern "C" void avs_tune_bnsync_timeout_ticks(int64_t ticks) { g_bnsync_spin_ticks = ticks; }
+
+extern "C" int avs_conv2d_nhwc_bnsync(const avs_conv_desc* d, const void* d_x, const void* d_w, void* d_y,
+                                      int64_t rows_per_group, const float* d_gamma, const float* d_beta, float eps,
+                                      const void* d_residual, int64_t ldr, void* d_ws_zeroed, int64_t ws_bytes,
+                                      int* d_err, avs_stream_t stream) {
+  const char* who = "avs_conv2d_nhwc_bnsync";
+  IgemmParams p{};
+  int64_t need = 0;
+  int st = bnsync_plan(d, rows_per_group, p, &need, who);
+  if (st != AVS_OK) return st;
+  if (p.M == 0) return AVS_OK;
+  AVS_REQUIRE(d_x && d_w && d_y && d_gamma && d_beta && d_ws_zeroed && d_err, AVS_E_ARG, "%s: null pointer", who);
+  AVS_REQUIRE(ws_bytes >= need, AVS_E_WORKSPACE, "%s: workspace %lld < %lld bytes", who, (long long)ws_bytes,
+              (long long)need);
+  AVS_REQUIRE(avs_aligned16(d_ws_zeroed) && avs_aligned16(d_y), AVS_E_ALIGN, "%s: workspace / y must be 16-byte aligned",
+              who);
+  AVS_REQUIRE(!d_residual || (avs_aligned16(d_residual) && (ldr * 2) % 16 == 0 && ldr >= p.N), AVS_E_ALIGN,
+              "%s: residual rows must be 16-byte aligned and at least cout long", who);
+  p.x = (const char*)d_x;
+  p.w = (const char*)d_w;
+  p.y = (char*)d_y;
+  const long long groups = p.M / rows_per_group;
+  p.stat_sum = reinterpret_cast<float*>(d_ws_zeroed);
+  p.stat_sq = p.stat_sum + groups * p.N;
+  p.arrive = reinterpret_cast<unsigned*>(p.stat_sq + groups * p.N);
+  p.rows_per_group = (int)rows_per_group;
+  p.err = d_err;
+  p.gamma = d_gamma;
+  p.beta = d_beta;
+  p.eps = eps;
+  p.residual = (const char*)d_residual;
+  p.ldr = ldr;
+  p.spin_ticks = g_bnsync_spin_ticks;
+  p.trace = g_bnsync_trace;
+  p.bias_mode = AVS_BIAS_NONE;
+  return igemm_launch(AVS_BF16, p, 1, (hipStream_t)stream, who);
 }
 
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sq,

@@ -11,7 +11,7 @@ from . import _abi
 from ._abi import ACT_NONE, ACT_RELU, AVS_BF16, AVS_F32, BIAS_COL, BIAS_NONE, BIAS_ROW, check, lib
 
 __all__ = [
-    "ACT_NONE", "ACT_RELU", "linear", "gemm_nt_batched", "conv2d", "conv2d_raw", "conv1x1_bn", "frames_normalize", "resize_bilinear",
+    "ACT_NONE", "ACT_RELU", "linear", "gemm_nt_batched", "conv2d", "conv2d_raw", "conv_bnsync_workspace_bytes", "conv1x1_bn", "frames_normalize", "resize_bilinear",
     "bn_batch_stats", "bn_apply", "pool2d", "global_avgpool", "segment_mean", "hsv_frame_diff", "reflect_pad", "stft_f64", "power_mel",
     "clamp_topdb", "fill", "lstm", "mha_batchaxis", "score_head", "mhsa_flash", "softmax_rows", "cdist", "dtw_path",
     "gather_scale", "dtype_code",
@@ -127,16 +127,49 @@ def linear(x, w, bias=None, act=ACT_NONE, out=None, alpha=1.0):
     return out
 
 
+def conv_bnsync_workspace_bytes(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x_img_stride,
+                                x_row_stride, x_px_stride, w_row_stride, y_px_stride, rows_per_group):
+    """Workspace bytes of the one-launch convolution + BatchNorm (avs_conv2d_nhwc_bnsync) for this shape, or None
+    when the library does not take it in that form (the caller then runs the unfused sequence)."""
+    d = _abi.ConvDesc(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x_img_stride, x_row_stride,
+                      x_px_stride, w_row_stride, y_px_stride, ACT_NONE, 1.0)
+    r = lib().avs_conv2d_bnsync_workspace_bytes(ctypes.byref(d), int(rows_per_group))
+    if r == _abi.E_UNSUPPORTED:
+        return None
+    if r < 0:
+        check(int(r), "avs_conv2d_bnsync_workspace_bytes")
+    return int(r)
+
+
 def conv2d_raw(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x, x_img_stride, x_row_stride, x_px_stride,
                wt, w_row_stride, y, y_px_stride, bias=None, act=ACT_NONE, alpha=1.0, x_off=0, y_off=0, algo_k=None,
-               bnstats=None):
+               bnstats=None, bnsync=None):
     """algo_k: the algorithmic reduction length when it differs from kh*kw*cin (zero-padded stem rows).
     bnstats = (rows_per_group, gamma, beta, eps): accumulate the BatchNorm batch statistics of equal-sized row
-    groups in the kernel's epilogue (no bias / activation) and return the folded (scale, shift) [G, cout]."""
+    groups in the kernel's epilogue (no bias / activation) and return the folded (scale, shift) [G, cout].
+    bnsync = (rows_per_group, gamma, beta, eps, residual2d | None, workspace uint8 (ZEROED), err int32[1]):
+    the whole BatchNorm (+ residual, then `act`) in the convolution's launch (avs_conv2d_nhwc_bnsync)."""
     _dev(x, wt, y, bias)
     d = _abi.ConvDesc(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x_img_stride, x_row_stride,
                       x_px_stride, w_row_stride, y_px_stride, act, float(alpha))
     flops = 2.0 * n * ho * wo * cout * (algo_k if algo_k is not None else kh * kw * cin)
+    if bnsync is not None:
+        rpg, gamma, beta, eps, residual, ws, err = bnsync
+        _dev(gamma, beta, residual, ws, err)
+        if bias is not None or bnstats is not None:
+            raise ValueError("the one-launch convolution + BatchNorm takes no bias / separate statistics")
+        if residual is not None:
+            _rowmajor2d(residual, "residual")
+            if residual.dtype != y.dtype or residual.shape != (n * ho * wo, cout):
+                raise ValueError("residual must be [rows, cout] in the activation dtype")
+        if err.dtype != torch.int32 or ws.dtype != torch.uint8:
+            raise TypeError("err must be int32, workspace uint8")
+        _timed("conv", dtype, flops, lambda: check(
+            lib().avs_conv2d_nhwc_bnsync(ctypes.byref(d), _p(x, x_off), _p(wt), _p(y, y_off), int(rpg), _p(gamma),
+                                         _p(beta), float(eps), _p(residual),
+                                         residual.stride(0) if residual is not None else 0, _p(ws), ws.numel(),
+                                         _p(err), _stream()), "avs_conv2d_nhwc_bnsync"))
+        return None
     if bnstats is None:
         _timed("conv", dtype, flops, lambda: check(
             lib().avs_conv2d_nhwc(ctypes.byref(d), _p(x, x_off), _p(wt), _p(bias), _p(y, y_off), _stream()),

@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=1024)
     ap.add_argument("--cpu-sample", type=int, default=512, help="frames for the CPU baseline (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--bn-sync", default="auto", choices=["auto", "on", "off"],
+                    help="tuning: one-launch convolution + BatchNorm (auto = the runner's per-layer choice)")
     ap.add_argument("--short-k-bytes", type=int, default=None, help="tuning: avs_tune_short_reduction_bytes")
     ap.add_argument("--fuse", default=None, help="tuning: min_rows,ratio_num,ratio_den of the one-kernel conv+BN")
     args = ap.parse_args()
@@ -133,6 +135,8 @@ def main():
         sd_cpu = ({k: v.clone() for k, v in extractor.resnet.state_dict().items()},
                   {k: v.clone() for k, v in scorer.state_dict().items()},
                   {k: v.clone() for k, v in extractor.inception.state_dict().items()} if use_inception else None)
+    if args.bn_sync != "auto":
+        extractor._resnet_runner.bn_sync = args.bn_sync == "on"
     if args.fuse is not None:
         r = extractor._resnet_runner
         r.fuse_min_rows, r.fuse_ratio_num, r.fuse_ratio_den = [int(v) for v in args.fuse.split(",")]

@@ -42,7 +42,8 @@ enum {
   AVS_E_SHAPE = -2,     /* sizes inconsistent with what the kernel assumes    */
   AVS_E_ALIGN = -3,     /* pointer or stride not 16-byte aligned              */
   AVS_E_HIP = -4,       /* the HIP runtime reported an error at launch        */
-  AVS_E_WORKSPACE = -5  /* workspace too small                                */
+  AVS_E_WORKSPACE = -5, /* workspace too small                                */
+  AVS_E_UNSUPPORTED = -6 /* this entry point does not take the shape; use the documented alternative */
 };
 
 enum { AVS_F32 = 0, AVS_BF16 = 1, AVS_F32_ACC64 = 2 };
@@ -95,6 +96,29 @@ int avs_conv2d_nhwc_bnstats(const avs_conv_desc* desc, const void* d_x, const vo
 int avs_bn_finalize(const float* d_sum, const float* d_sumsq, int groups, int c, int64_t rows_per_group,
                     const float* d_gamma, const float* d_beta, float eps, float* d_scale, float* d_shift,
                     avs_stream_t stream);
+
+/* Convolution + the WHOLE batch-statistics BatchNorm (+ residual, + ReLU) in one launch, bf16, equal-sized groups:
+ *   y[m,:] = act( bn_g(conv(x)[m,:]) + residual[m,:] ),  g = m / rows_per_group,  act = desc->act.
+ * Every output tile adds its column sums to the group statistics, signals a per-group arrival counter, waits
+ * (accumulators in registers) until the group's other tiles have arrived, then normalises and stores: one read of
+ * x, one write of y, nothing raw in HBM.  Replaces avs_conv2d_nhwc_bnstats + avs_bn_finalize + avs_bn_apply for
+ * the train-mode ResNet trunk (features/extractors.py:29,65).
+ * avs_conv2d_bnsync_workspace_bytes returns the workspace size (the caller ZEROES it on the stream before every
+ * call) or AVS_E_UNSUPPORTED when the shape cannot take this form: not bf16; cout not a multiple of the column
+ * tile; groups of fewer than 43 rows; or a group so long that its tiles would not be co-resident several times
+ * over (the wait needs them to be) — use the unfused sequence then.  d_err is a device int the caller zeroes once:
+ * a wait that exceeds the time-out sets it to 1 instead of hanging, and the results of every launch since are void.*/
+int64_t avs_conv2d_bnsync_workspace_bytes(const avs_conv_desc* desc, int64_t rows_per_group);
+int avs_conv2d_nhwc_bnsync(const avs_conv_desc* desc, const void* d_x, const void* d_w, void* d_y,
+                           int64_t rows_per_group, const float* d_gamma, const float* d_beta, float eps,
+                           const void* d_residual, int64_t ldr, void* d_ws_zeroed, int64_t ws_bytes,
+                           int* d_err, avs_stream_t stream);
+/* Tuning knob: time-out of the group wait in ticks of the 100 MHz device wall clock (default 5 000 000 = 50 ms). */
+void avs_tune_bnsync_timeout_ticks(int64_t ticks);
+
+/* Kernel study only (tools/): when non-NULL, every block of avs_conv2d_nhwc_bnsync writes four int64 to
+ * d_trace[4*block ..]: XCC id, start, arrival, end of wait (100 MHz wall-clock ticks).  NULL (default) = off. */
+void avs_debug_bnsync_trace(void* d_trace);
 
 /* 1x1 convolution + batch-statistics BatchNorm (+ residual, + ReLU) in one kernel, bf16, for equal-sized
  * groups of rows_per_group consecutive rows (a micro-batch of frames at one resolution):

@@ -2,6 +2,7 @@
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
@@ -261,6 +262,132 @@ def test_conv1x1_bn_one_kernel(dev, rpg, k, n, with_res, relu):
                    res.to(dev) if with_res else None, relu)
     err = (out.float().cpu() - ref).abs().max().item()
     assert err < 0.03 * max(1.0, ref.abs().max().item()), err
+
+
+def _bn_reference(raw, rpg, gamma, beta, res, relu):
+    rows, n = raw.shape
+    ref = torch.empty(rows, n)
+    for gi in range(rows // rpg):
+        blk = raw[gi * rpg:(gi + 1) * rpg]
+        mean, var = blk.mean(0), blk.var(0, unbiased=False)
+        ref[gi * rpg:(gi + 1) * rpg] = (blk - mean) / torch.sqrt(var + 1e-5) * gamma + beta
+    if res is not None:
+        ref = ref + res.float()
+    return torch.relu(ref) if relu else ref
+
+
+# (frames, hw in, cin, cout, kernel, stride, frames per BatchNorm group, residual, relu)
+_SYNC_CASES = [
+    (12, 56, 64, 256, 1, 1, 1, True, True),     # layer1 conv3: two column tiles, tiles straddle groups (3136 % 128 != 0)
+    (12, 56, 64, 64, 3, 1, 1, False, True),     # layer1 conv2: 64-wide tile, spatial taps
+    (9, 7, 512, 2048, 1, 1, 1, True, True),     # layer4 conv3: 49-row groups, up to 4 groups per tile, ragged last tile
+    (8, 28, 128, 128, 3, 2, 4, False, True),    # long reduction (128-byte rows), stride 2, 4-frame groups
+    (8, 28, 256, 512, 1, 2, 2, False, False),   # strided downsample, no ReLU
+    (5, 14, 1024, 256, 1, 1, 5, False, True),   # ONE group for the whole call (980 rows)
+    (64, 56, 64, 256, 1, 1, 4, True, True),     # the reference's 4-frame micro-batches, 200k rows: many tiles waiting
+]
+
+
+@pytest.mark.parametrize("cfg", _SYNC_CASES)
+def test_conv_bnsync_one_launch(dev, cfg):
+    """Convolution + whole batch-statistics BatchNorm (+residual, +ReLU) in one launch (tiles wait for their group's
+    statistics) against the same arithmetic in fp32 on the bf16-rounded operands, and against the split HIP path."""
+    from avsum_amd import ops
+    frames, hw, cin, cout, k, s, gf, with_res, relu = cfg
+    g = torch.Generator().manual_seed(sum(cfg[:6]))
+    pad = k // 2
+    ho = (hw + 2 * pad - k) // s + 1
+    rpg = gf * ho * ho
+    x = (torch.randn(frames, hw, hw, cin, generator=g) + 0.3).bfloat16()
+    w4 = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).bfloat16()
+    wt = w4.permute(0, 2, 3, 1).reshape(cout, -1).contiguous()
+    gamma, beta = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    res = torch.randn(frames * ho * ho, cout, generator=g).bfloat16() if with_res else None
+    raw = F.conv2d(x.float().permute(0, 3, 1, 2), w4.float(), stride=s, padding=pad).permute(0, 2, 3, 1).reshape(-1, cout)
+    ref = _bn_reference(raw, rpg, gamma, beta, res, relu)
+
+    geom = (frames, hw, hw, cin, k, k, s, s, pad, pad, ho, ho, cout)
+    xs = (hw * hw * cin, hw * cin, cin)
+    code = ops.dtype_code(torch.bfloat16)
+    nbytes = ops.conv_bnsync_workspace_bytes(code, *geom, *xs, wt.shape[1], cout, rpg)
+    assert nbytes is not None and nbytes > 0
+    ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    xd, wd = x.to(dev), wt.to(dev)
+    y = torch.empty((frames, ho, ho, cout), dtype=torch.bfloat16, device=dev)
+    ops.conv2d_raw(code, *geom, xd, *xs, wd, wd.stride(0), y, cout, act=ops.ACT_RELU if relu else ops.ACT_NONE,
+                   bnsync=(rpg, gamma.to(dev), beta.to(dev), 1e-5, res.to(dev) if with_res else None, ws, err))
+    assert err.item() == 0, "a group wait timed out"
+    got = y.float().cpu().view(-1, cout)
+    scale = max(1.0, ref.abs().max().item())
+    assert (got - ref).abs().max().item() < 0.03 * scale
+    # split path (statistics in the epilogue of a raw bf16 convolution, then avs_bn_apply): same to bf16 rounding
+    y2 = torch.empty_like(y)
+    sc, sh = ops.conv2d(xd, wd, k, k, s, pad, y2, bnstats=(rpg, gamma.to(dev), beta.to(dev), 1e-5))
+    rows = torch.arange(0, frames * ho * ho + 1, rpg, dtype=torch.int64, device=dev)
+    ops.bn_apply(y2.view(-1, cout), sc, sh, rows, rpg, res.to(dev) if with_res else None,
+                 ops.ACT_RELU if relu else ops.ACT_NONE, y2.view(-1, cout))
+    assert (got - y2.float().cpu().view(-1, cout)).abs().max().item() < 0.03 * scale
+    assert (got - ref).abs().mean().item() < 0.004 * scale
+
+
+def test_conv_bnsync_declines_and_times_out_loudly(dev):
+    """Shapes the one-launch form cannot take are declined up front (None -> the caller uses the split path); a wait
+    that times out sets the error word, and the runner then recomputes on the two-pass path."""
+    from avsum_amd import _abi, ops
+    from avsum_amd.cnn import ResNet50Runner, resnet50_trunk
+    code = ops.dtype_code(torch.bfloat16)
+    geom = lambda n, hw, cin, cout: ((n, hw, hw, cin, 1, 1, 1, 1, 0, 0, hw, hw, cout), (hw * hw * cin, hw * cin, cin))
+    g, xs = geom(8, 4, 64, 64)
+    assert ops.conv_bnsync_workspace_bytes(code, *g, *xs, 64, 64, 16) is None          # 16-row groups
+    g, xs = geom(4, 8, 64, 96)
+    assert ops.conv_bnsync_workspace_bytes(code, *g, *xs, 64, 96, 64) is None          # cout not a tile multiple
+    g, xs = geom(128, 112, 32, 64)
+    assert ops.conv_bnsync_workspace_bytes(code, *g, *xs, 32, 64, 128 * 112 * 112) is None  # a group too long to co-reside
+    assert ops.conv_bnsync_workspace_bytes(ops.dtype_code(torch.float32), *g, *xs, 32, 64, 112 * 112) is None
+
+    torch.manual_seed(3)
+    trunk = resnet50_trunk().to(dev)
+    frames = torch.from_numpy(_frames(6, 9)).to(dev)
+    plain = ResNet50Runner(trunk, torch.bfloat16)
+    plain.bn_sync = False
+    want = plain.forward(frames).cpu()
+    runner = ResNet50Runner(trunk, torch.bfloat16)
+    try:
+        _abi.lib().avs_tune_bnsync_timeout_ticks(-1)   # every wait that is not already satisfied times out
+        with pytest.warns(UserWarning, match="timed out"):
+            got = runner.forward(frames).cpu()
+    finally:
+        _abi.lib().avs_tune_bnsync_timeout_ticks(5000000)
+    # (statistics summed by float atomics: two runs of the split path agree to bf16 rounding noise, not bit for bit)
+    assert runner.bn_sync is False and ((got - want).norm() / want.norm()).item() < 0.05
+
+
+@pytest.mark.parametrize("gsize", [1, 4])
+def test_resnet50_bf16_sync_form_close_to_split_form(dev, gsize):
+    """Whole trunk: one-launch convolution + BatchNorm against the two-pass / split forms (both bf16) and fp32."""
+    from avsum_amd.cnn import ResNet50Runner, resnet50_trunk
+    torch.manual_seed(23)
+    trunk = resnet50_trunk().to(dev)
+    frames = torch.from_numpy(_frames(16, 4)).to(dev)
+    groups = list(range(0, 17, gsize))
+    sync = ResNet50Runner(trunk, torch.bfloat16)
+    sync.sync_max_group_rows = 1 << 30          # every layer the library takes, not only the small-group ones
+    got = sync.forward(frames, groups).cpu()
+    assert sync.bn_sync and not sync.sync_failed()
+    plan = sync._plans[(16, gsize, 1 << 30)]
+    assert sum(p is not None for p in plan[:-1]) >= (53 if gsize == 1 else 50)   # the form really ran
+    split = ResNet50Runner(trunk, torch.bfloat16)
+    split.bn_sync = False
+    ref_bf = split.forward(frames, groups).cpu()
+    ref32 = ResNet50Runner(trunk, torch.float32).forward(frames, groups).cpu()
+    cos = lambda a, b: torch.nn.functional.cosine_similarity(a, b, dim=1).min().item()
+    assert cos(got, ref32) > 0.98 and cos(got, ref_bf) > 0.98
+    # the one-launch form normalises the fp32 accumulators (no bf16 rounding of the raw convolution in between):
+    # it must not be further from fp32 than the split form is
+    e_sync = ((got - ref32).norm() / ref32.norm()).item()
+    e_split = ((ref_bf - ref32).norm() / ref32.norm()).item()
+    assert e_sync < 0.2 and e_sync < 1.25 * e_split, (e_sync, e_split)
 
 
 @pytest.mark.parametrize("groups", [[0, 4, 8], [0, 4, 7, 8]])
