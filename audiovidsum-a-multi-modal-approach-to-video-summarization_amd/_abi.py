@@ -64,6 +64,8 @@ _SIGNATURES = {
                              c_int64, P]),
     "avs_pool2d_nhwc": (c_int, [c_int, c_int, P, c_int, c_int, c_int, c_int, c_int64, c_int, c_int, c_int, P, c_int,
                                 c_int, c_int64, P]),
+    "avs_bn_maxpool_nhwc": (c_int, [c_int, P, c_int, c_int, c_int, c_int, c_int64, P, c_int, P, P, c_int, c_int, c_int,
+                                    c_int, P, c_int, c_int, c_int64, P]),
     "avs_global_avgpool_nhwc": (c_int, [c_int, P, c_int, c_int, c_int, P, c_int64, P]),
     "avs_segment_mean_f32": (c_int, [P, c_int64, c_int, P, c_int, P, c_int64, P]),
     "avs_hsv_frame_diff_u8": (c_int, [P, c_int, c_int, c_int, c_int, P, P]),

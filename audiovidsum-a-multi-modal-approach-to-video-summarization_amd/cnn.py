@@ -205,8 +205,10 @@ class ResNet50Runner:
             self._err.zero_()
         return bad
 
-    def _conv_bn(self, geom, xs, x, wt, bnp, groups, residual=None, relu=True, sync=None, algo_k=None):
-        """One convolution + BatchNorm (+ residual, + ReLU) -> NHWC activation; picks the form (class docstring)."""
+    def _conv_bn(self, geom, xs, x, wt, bnp, groups, residual=None, relu=True, sync=None, algo_k=None, pool=None):
+        """One convolution + BatchNorm (+ residual, + ReLU) -> NHWC activation; picks the form (class docstring).
+        pool = (k, s, p): a max pooling follows (the stem) - on the split form it is fused with the BatchNorm apply
+        (avs_bn_maxpool_nhwc: the normalised full-resolution map is never written)."""
         n, ho, wo, cout = geom[0], geom[10], geom[11], geom[12]
         cin, kh, sh = geom[3], geom[4], geom[6]
         dev, dt = x.device, self.dtype
@@ -219,17 +221,34 @@ class ResNet50Runner:
         def conv(**kw):
             return ops.conv2d_raw(dcode, *geom, x, *xs, wt, wt.stride(0), y, cout, algo_k=algo_k, **kw)
 
+        def pooled(t):
+            k, s, p = pool
+            hp, wp = (ho + 2 * p - k) // s + 1, (wo + 2 * p - k) // s + 1
+            return torch.empty((n, hp, wp, cout), dtype=dt, device=dev), k, s, p
+
+        def finish(scale, shift, grows, gmax):
+            if pool is not None and residual is None:
+                out, k, s, p = pooled(y)
+                return ops.bn_maxpool(y, scale, shift, grows, relu, k, s, p, out)
+            ops.bn_apply(y2d, scale, shift, grows, gmax, residual, act, y2d)
+            if pool is not None:
+                out, k, s, p = pooled(y)
+                return ops.pool2d(y, "max", k, s, p, out)
+            return y
+
         if self.bn_mode != "batch":
             conv()
             scale = (gamma / torch.sqrt(rvar + eps)).contiguous()
             shift = (beta - rmean * scale).contiguous()
-            ops.bn_apply(y2d, scale.view(1, -1), shift.view(1, -1), None, 0, residual, act, y2d)
-            return y
+            return finish(scale.view(1, -1), shift.view(1, -1), None, 0)
         grows, gmax, uniform = groups[ho * wo]
         fast = uniform and dt == torch.bfloat16
         if fast and sync is not None:
             off, nbytes = sync
             conv(act=act, bnsync=(gmax, gamma, beta, eps, residual, self._ws[off:off + nbytes], self._err))
+            if pool is not None:
+                out, k, s, p = pooled(y)
+                return ops.pool2d(y, "max", k, s, p, out)
             return y
         # measured on MI355X: the two-pass kernel wins over the split form where the layer is write-heavy
         # (cout >= 2*cin: the conv3 / downsample layers) and a group is several row tiles long
@@ -244,8 +263,7 @@ class ResNet50Runner:
             # fp32 parity mode / ragged groups: the shifted, deterministic statistics pass
             conv()
             scale, shift = ops.bn_batch_stats(y2d, grows, gamma, beta, eps)
-        ops.bn_apply(y2d, scale, shift, grows, gmax, residual, act, y2d)
-        return y
+        return finish(scale, shift, grows, gmax)
 
     def forward(self, frames_u8, group_frames=None, out=None, check=True):
         """frames_u8: device uint8 [N,224,224,3] (already 224x224, extractors.py:132).
@@ -279,11 +297,8 @@ class ResNet50Runner:
         # stem: (x - mean)/std without /255 (extractors.py:133-139), zero padded by 3 (conv1 pad)
         x0 = ops.frames_normalize(frames_u8, dt, 1.0, RESNET_MEAN, RESNET_STD, 230, 232, 3, 3)
         geom, xs, _ = self._stem_geom(n)
-        a1 = self._conv_bn(geom, xs, x0, w["stem"], w["bn1"], groups, sync=slot(), algo_k=147)
+        x = self._conv_bn(geom, xs, x0, w["stem"], w["bn1"], groups, sync=slot(), algo_k=147, pool=(3, 2, 1))
         del x0
-        x = torch.empty((n, 56, 56, 64), dtype=dt, device=dev)
-        ops.pool2d(a1, "max", 3, 2, 1, x)
-        del a1
         hcur = 56
         for blk in w["blocks"]:
             s, planes = blk["stride"], blk["planes"]

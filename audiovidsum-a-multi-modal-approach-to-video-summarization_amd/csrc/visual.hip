@@ -430,6 +430,108 @@ extern "C" int avs_pool2d_nhwc(int dtype, int mode, const void* d_x, int n, int 
   return AVS_OK;
 }
 
+// BatchNorm apply + ReLU + max pooling in one pass (the ResNet stem: bn1 -> relu -> maxpool 3x3/2,
+// features/extractors.py:29): reads the RAW convolution once and writes only the pooled map, instead of
+// avs_bn_apply (read + write of the full-resolution map) followed by avs_pool2d_nhwc (another read).
+// max(relu(.)) == relu(max(.)) and rounding to the activation dtype is monotone, so the result is bit-identical
+// to the two-kernel sequence.  Group of an image = the range of d_group_rows (input rows) its first row is in.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_maxpool_kernel(const T* __restrict__ x, int n, int h, int w, int c,
+                                                         long long xps, const int64_t* __restrict__ group_rows,
+                                                         int groups, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, int relu, int k, int s,
+                                                         int p, T* __restrict__ y, int ho, int wo, long long yps) {
+  const int cv = c / V;
+  const long long total = (long long)n * ho * wo * cv;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % cv) * V;
+    long long t = i / cv;
+    const int ox = (int)(t % wo);
+    t /= wo;
+    const int oy = (int)(t % ho);
+    const long long img = t / ho;
+    long long g = 0;
+    if (group_rows) {  // largest g with group_rows[g] <= first row of the image
+      const long long row = img * h * (long long)w;
+      int lo = 0, hi = groups - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (group_rows[mid] <= row)
+          lo = mid;
+        else
+          hi = mid - 1;
+      }
+      g = lo;
+    }
+    float sc[V], sf[V], a[V];
+    if constexpr (V == 8) {
+      load4<float>(scale + g * c + ch, reinterpret_cast<float(&)[4]>(sc[0]));
+      load4<float>(scale + g * c + ch + 4, reinterpret_cast<float(&)[4]>(sc[4]));
+      load4<float>(shift + g * c + ch, reinterpret_cast<float(&)[4]>(sf[0]));
+      load4<float>(shift + g * c + ch + 4, reinterpret_cast<float(&)[4]>(sf[4]));
+    } else {
+      load4<float>(scale + g * c + ch, reinterpret_cast<float(&)[4]>(sc[0]));
+      load4<float>(shift + g * c + ch, reinterpret_cast<float(&)[4]>(sf[0]));
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) a[j] = -INFINITY;
+    for (int ky = 0; ky < k; ++ky) {
+      const int iy = oy * s - p + ky;
+      if ((unsigned)iy >= (unsigned)h) continue;
+      for (int kx = 0; kx < k; ++kx) {
+        const int ix = ox * s - p + kx;
+        if ((unsigned)ix >= (unsigned)w) continue;
+        float v[V];
+        loadv<T, V>(x + ((img * h + iy) * (long long)w + ix) * xps + ch, v);
+#pragma unroll
+        for (int j = 0; j < V; ++j) a[j] = fmaxf(a[j], v[j] * sc[j] + sf[j]);  // avs_bn_apply's expression
+      }
+    }
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) a[j] = fmaxf(a[j], 0.f);
+    }
+    storev<T, V>(y + ((img * ho + oy) * (long long)wo + ox) * yps + ch, a);
+  }
+}
+
+extern "C" int avs_bn_maxpool_nhwc(int dtype, const void* d_x, int n, int h, int w, int c, int64_t x_px_stride,
+                                   const int64_t* d_group_rows, int groups, const float* d_scale,
+                                   const float* d_shift, int relu, int k, int s, int p, void* d_y, int ho, int wo,
+                                   int64_t y_px_stride, avs_stream_t stream) {
+  AVS_REQUIRE(dtype == AVS_F32 || dtype == AVS_BF16, AVS_E_ARG, "avs_bn_maxpool_nhwc: bad dtype");
+  AVS_REQUIRE(n >= 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0 && k > 0 && s > 0 && p >= 0 && p < k && ho > 0 &&
+                  wo > 0 && x_px_stride >= c && x_px_stride % 4 == 0 && y_px_stride >= c && y_px_stride % 4 == 0,
+              AVS_E_SHAPE, "avs_bn_maxpool_nhwc: bad extents");
+  AVS_REQUIRE((ho - 1) * s - p < h && (wo - 1) * s - p < w, AVS_E_SHAPE, "avs_bn_maxpool_nhwc: output extent too large");
+  AVS_REQUIRE((groups > 0) == (d_group_rows != nullptr), AVS_E_ARG,
+              "avs_bn_maxpool_nhwc: groups and d_group_rows disagree");
+  if (n == 0) return AVS_OK;
+  AVS_REQUIRE(d_x && d_y && d_scale && d_shift, AVS_E_ARG, "avs_bn_maxpool_nhwc: null pointer");
+  AVS_REQUIRE(avs_aligned16(d_scale) && avs_aligned16(d_shift), AVS_E_ALIGN,
+              "avs_bn_maxpool_nhwc: scale / shift must be 16-byte aligned");
+  const bool wide = dtype == AVS_BF16 && c % 8 == 0 && x_px_stride % 8 == 0 && y_px_stride % 8 == 0 &&
+                    avs_aligned16(d_x) && avs_aligned16(d_y);
+  const long long total = (long long)n * ho * wo * (c / (wide ? 8 : 4));
+  long long gx = avs_cdiv(total, 256);
+  if (gx > 65536) gx = 65536;
+  if (dtype == AVS_F32)
+    hipLaunchKernelGGL((bn_maxpool_kernel<float, 4>), dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)d_x, n, h, w, c, (long long)x_px_stride, d_group_rows, groups, d_scale, d_shift,
+                       relu, k, s, p, (float*)d_y, ho, wo, (long long)y_px_stride);
+  else if (wide)
+    hipLaunchKernelGGL((bn_maxpool_kernel<avs_bf16_tag, 8>), dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream,
+                       (const avs_bf16_tag*)d_x, n, h, w, c, (long long)x_px_stride, d_group_rows, groups, d_scale,
+                       d_shift, relu, k, s, p, (avs_bf16_tag*)d_y, ho, wo, (long long)y_px_stride);
+  else
+    hipLaunchKernelGGL((bn_maxpool_kernel<avs_bf16_tag, 4>), dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream,
+                       (const avs_bf16_tag*)d_x, n, h, w, c, (long long)x_px_stride, d_group_rows, groups, d_scale,
+                       d_shift, relu, k, s, p, (avs_bf16_tag*)d_y, ho, wo, (long long)y_px_stride);
+  AVS_CHECK_LAUNCH("avs_bn_maxpool_nhwc");
+  return AVS_OK;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void global_avgpool_kernel(const T* __restrict__ x, int n, int hw, int c,
                                                              float* __restrict__ y, long long ldy) {

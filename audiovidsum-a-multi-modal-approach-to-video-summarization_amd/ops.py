@@ -12,7 +12,7 @@ from ._abi import ACT_NONE, ACT_RELU, AVS_BF16, AVS_F32, BIAS_COL, BIAS_NONE, BI
 
 __all__ = [
     "ACT_NONE", "ACT_RELU", "linear", "gemm_nt_batched", "conv2d", "conv2d_raw", "conv_bnsync_workspace_bytes", "conv1x1_bn", "frames_normalize", "resize_bilinear",
-    "bn_batch_stats", "bn_apply", "pool2d", "global_avgpool", "segment_mean", "hsv_frame_diff", "reflect_pad", "stft_f64", "power_mel",
+    "bn_batch_stats", "bn_apply", "bn_maxpool", "pool2d", "global_avgpool", "segment_mean", "hsv_frame_diff", "reflect_pad", "stft_f64", "power_mel",
     "clamp_topdb", "fill", "lstm", "mha_batchaxis", "score_head", "mhsa_flash", "softmax_rows", "cdist", "dtw_path",
     "gather_scale", "dtype_code",
 ]
@@ -306,6 +306,21 @@ def pool2d(x, mode, k, s, p, out):
     _, ho, wo, _ = out.shape
     check(lib().avs_pool2d_nhwc(dtype_code(x.dtype), 0 if mode == "max" else 1, _p(x), n, h, w, c, x.stride(2), k, s,
                                 p, _p(out), ho, wo, out.stride(2), _stream()), "avs_pool2d_nhwc")
+    return out
+
+
+def bn_maxpool(x, scale, shift, group_rows, relu, k, s, p, out):
+    """out = maxpool(act(x*scale[g] + shift[g])) on NHWC views: avs_bn_apply + max pooling in one pass."""
+    _dev(x, scale, shift, group_rows, out)
+    n, h, w, c = x.shape
+    _, ho, wo, _ = out.shape
+    g = group_rows.numel() - 1 if group_rows is not None else 0
+    # algorithmic bytes: read the raw map once, write the pooled map
+    nbytes = float(x.numel() + out.numel()) * x.element_size()
+    _timed("bn_apply", dtype_code(x.dtype), nbytes, lambda: check(
+        lib().avs_bn_maxpool_nhwc(dtype_code(x.dtype), _p(x), n, h, w, c, x.stride(2), _p(group_rows), g, _p(scale),
+                                  _p(shift), 1 if relu else 0, k, s, p, _p(out), ho, wo, out.stride(2), _stream()),
+        "avs_bn_maxpool_nhwc"))
     return out
 
 

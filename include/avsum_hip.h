@@ -204,6 +204,15 @@ int avs_pool2d_nhwc(int dtype, int mode, const void* d_x, int n, int h, int w, i
                     int64_t x_px_stride, int k, int s, int p, void* d_y, int ho, int wo,
                     int64_t y_px_stride, avs_stream_t stream);
 
+/* BatchNorm apply + ReLU + max pooling in one pass: y = maxpool_{k,s,p}( act( x*scale[g] + shift[g] ) ), g = the
+ * group (d_group_rows ranges over INPUT rows, as in avs_bn_apply; groups == 0 / NULL: one affine) of the image.
+ * The ResNet stem's bn1 -> relu -> maxpool (features/extractors.py:29) without writing the normalised
+ * full-resolution map; bit-identical to avs_bn_apply followed by avs_pool2d_nhwc(max).                      */
+int avs_bn_maxpool_nhwc(int dtype, const void* d_x, int n, int h, int w, int c, int64_t x_px_stride,
+                        const int64_t* d_group_rows, int groups, const float* d_scale, const float* d_shift,
+                        int relu, int k, int s, int p, void* d_y, int ho, int wo, int64_t y_px_stride,
+                        avs_stream_t stream);
+
 /* Global average pool: y[n,c] = mean over h*w (fp32 out).  (adaptive avgpool) */
 int avs_global_avgpool_nhwc(int dtype, const void* d_x, int n, int hw, int c,
                             float* d_y, int64_t ldy, avs_stream_t stream);

@@ -382,6 +382,34 @@ def test_cdist_dtw_gather(dev):
     assert torch.equal(goti, refi)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bn_maxpool_is_bn_apply_then_pool(dev, dtype):
+    """The stem's fused BatchNorm apply + ReLU + max pooling must be bit-identical to the two-kernel sequence
+    (ragged groups, negative scales, one-affine mode)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    n, h, w, c = 7, 18, 14, 64
+    x = torch.randn(n, h, w, c, generator=g).to(dtype).to(dev)
+    frames = torch.tensor([0, 3, 4, 7], dtype=torch.int64)
+    rows = (frames * h * w).to(dev)
+    scale = torch.randn(3, c, generator=g).to(dev)      # both signs
+    shift = torch.randn(3, c, generator=g).to(dev)
+    for k, s, p in ((3, 2, 1), (3, 2, 0), (2, 2, 0)):
+        ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+        for relu in (True, False):
+            full = ops.bn_apply(x.view(-1, c), scale, shift, rows, 3 * h * w, None,
+                                ops.ACT_RELU if relu else ops.ACT_NONE).view(n, h, w, c)
+            want = ops.pool2d(full, "max", k, s, p, torch.empty((n, ho, wo, c), dtype=dtype, device=dev))
+            got = ops.bn_maxpool(x, scale, shift, rows, relu, k, s, p, torch.empty_like(want))
+            assert torch.equal(got, want)
+    full = ops.bn_apply(x.view(-1, c), scale[:1], shift[:1], None, 0, None, ops.ACT_RELU).view(n, h, w, c)
+    want = ops.pool2d(full, "max", 3, 2, 1, torch.empty((n, 9, 7, c), dtype=dtype, device=dev))
+    assert torch.equal(ops.bn_maxpool(x, scale[:1], shift[:1], None, True, 3, 2, 1, torch.empty_like(want)), want)
+    ref = F.max_pool2d(torch.relu(x.float().cpu().permute(0, 3, 1, 2) * scale[0].cpu().view(1, -1, 1, 1)
+                                  + shift[0].cpu().view(1, -1, 1, 1)), 3, 2, 1).permute(0, 2, 3, 1)
+    assert (want.float().cpu() - ref).abs().max().item() < (1e-5 if dtype == torch.float32 else 0.05)
+
+
 def _synthetic_video(n, h, w, cut_at, seed):
     """Slowly drifting noise scenes with abrupt content changes at `cut_at`."""
     rng = np.random.default_rng(seed)
