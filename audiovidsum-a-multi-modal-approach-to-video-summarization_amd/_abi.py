@@ -74,6 +74,8 @@ _SIGNATURES = {
     "avs_power_mel_f32": (c_int, [P, c_int64, c_int, P, P, P, c_int, c_int, P, P, P]),
     "avs_clamp_topdb_f32": (c_int, [P, c_int64, P, c_float, P]),
     "avs_fill_f32": (c_int, [P, c_int64, c_float, P]),
+    "avs_quantize_f32": (c_int, [P, c_int64, c_float, c_float, c_float, P, P]),
+    "avs_resample_f32": (c_int, [P, c_int64, c_int, P, c_int, c_int, c_int, c_int, P, c_int64, P]),
     "avs_lstm_f32": (c_int, [P, P, c_int, c_int, c_uint, P, c_int, P, c_int64, c_int, P]),
     "avs_mha_batchaxis_f32": (c_int, [P, c_int, c_int, c_int, c_int, P, P]),
     "avs_score_head_f32": (c_int, [P, c_int64, c_int, c_int64, P, P, P, P]),

@@ -118,3 +118,43 @@ class MelPlan:
         db = ops.power_mel(self.spectrum(wave), N_BINS, self.fb, self.fb_lo, self.fb_hi, 1, gmax)
         ops.clamp_topdb(db, gmax, top_db)
         return ops.linear(db, self.dct)
+
+
+# --------------------------------------------------------------------------- channel mix-down + resampling (F4)
+_RESAMPLE_TAPS = {}
+
+
+def resample_taps(orig_freq, new_freq, lowpass_filter_width=6, rolloff=0.99):
+    """Polyphase windowed-sinc taps fp32 [new, 2*width + orig] and `width` for orig -> new (reduced by their gcd):
+    Hann-windowed sinc, cut-off `rolloff` x the lower Nyquist, evaluated in float64.  The reference delegates this
+    step to ffmpeg through pydub (features/extractors.py:364-378), which cannot be reproduced bit for bit; this is
+    the published sinc_interp_hann design of torchaudio.functional.resample [3P-memory], parity unpinned."""
+    g = math.gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    base = min(orig, new) * rolloff
+    width = int(math.ceil(lowpass_filter_width * orig / base))
+    idx = np.arange(-width, width + orig, dtype=np.float64)[None, :] / orig
+    t = np.arange(0, -new, -1, dtype=np.float64)[:, None] / new + idx
+    t = np.clip(t * base, -lowpass_filter_width, lowpass_filter_width)
+    window = np.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    safe = np.where(t == 0, 1.0, t)
+    kern = np.where(t == 0, 1.0, np.sin(safe) / safe) * window * (base / orig)
+    return kern.astype(np.float32), width, orig, new
+
+
+def resample_to(x, orig_freq, new_freq):
+    """x fp32 [T] or interleaved [T, channels] on device -> mono fp32 [ceil(new*T/orig)] at new_freq."""
+    if int(orig_freq) == int(new_freq):
+        if x.dim() == 1:
+            return x
+        taps = torch.ones((1, 1), dtype=torch.float32, device=x.device)   # pure channel mix-down
+        return ops.resample(x.contiguous(), taps, 1, 1, 0, x.shape[0])
+    key = (int(orig_freq), int(new_freq), str(x.device))
+    if key not in _RESAMPLE_TAPS:
+        kern, width, orig, new = resample_taps(orig_freq, new_freq)
+        _RESAMPLE_TAPS[key] = (torch.from_numpy(kern).to(x.device), width, orig, new)
+    taps, width, orig, new = _RESAMPLE_TAPS[key]
+    t = x.shape[0]
+    out_len = -(-new * t // orig)
+    return ops.resample(x.contiguous(), taps, new, orig, width, out_len)

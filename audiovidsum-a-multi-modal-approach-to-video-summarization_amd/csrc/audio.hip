@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256) void power_mel_kernel(const float* __restrict_
     const int f = i / nbins, k = i - f * nbins;
     const float re = spec[(f0 + f) * 2 * nbins + k];
     const float im = spec[(f0 + f) * 2 * nbins + nbins + k];
-    pw[i] = re * re + im * im;
+    const float pwr = re * re + im * im;
+    pw[i] = mode == 3 ? sqrtf(pwr) : pwr;  // mode 3 (VGGish): magnitude spectrum
   }
   __syncthreads();
   float lmax = 0.f;
@@ -131,6 +132,8 @@ __global__ __launch_bounds__(256) void power_mel_kernel(const float* __restrict_
       const float cl = fmaxf(a, 1e-10f);
       lmax = fmaxf(lmax, cl);
       v = 10.f * log10f(cl);
+    } else if (mode == 3) {
+      v = logf(a + 0.01f);
     } else {
       v = a;
     }
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(256) void power_mel_kernel(const float* __restrict_
 extern "C" int avs_power_mel_f32(const float* d_spec, int64_t frames, int nbins, const float* d_fb, const int* d_fb_lo,
                                  const int* d_fb_hi, int nmel, int mode, float* d_out, float* d_max,
                                  avs_stream_t stream) {
-  AVS_REQUIRE(frames >= 0 && nbins > 0 && nbins <= AVS_MEL_MAXBINS && nmel > 0 && mode >= 0 && mode <= 2, AVS_E_SHAPE,
+  AVS_REQUIRE(frames >= 0 && nbins > 0 && nbins <= AVS_MEL_MAXBINS && nmel > 0 && mode >= 0 && mode <= 3, AVS_E_SHAPE,
               "avs_power_mel_f32: frames=%lld nbins=%d nmel=%d mode=%d", (long long)frames, nbins, nmel, mode);
   if (frames == 0) return AVS_OK;
   AVS_REQUIRE(d_spec && d_fb && d_fb_lo && d_fb_hi && d_out, AVS_E_ARG, "avs_power_mel_f32: null pointer");
@@ -194,5 +197,73 @@ extern "C" int avs_fill_f32(float* d_x, int64_t count, float value, avs_stream_t
   if (gx > 8192) gx = 8192;
   hipLaunchKernelGGL(fill_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, d_x, (long long)count, value);
   AVS_CHECK_LAUNCH("avs_fill_f32");
+  return AVS_OK;
+}
+
+// y = rint((clamp(x, lo, hi) - lo) * scale): the 8-bit quantiser of the VGGish post-processor (values kept as
+// float, round-half-to-even like torch.round).
+__global__ __launch_bounds__(256) void quantize_kernel(const float* __restrict__ x, long long count, float lo, float hi,
+                                                       float scale, float* __restrict__ y) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += (long long)gridDim.x * blockDim.x)
+    y[i] = rintf((fminf(fmaxf(x[i], lo), hi) - lo) * scale);
+}
+
+extern "C" int avs_quantize_f32(const float* d_x, int64_t count, float lo, float hi, float scale, float* d_y,
+                                avs_stream_t stream) {
+  AVS_REQUIRE(count >= 0 && hi > lo, AVS_E_SHAPE, "avs_quantize_f32: bad arguments");
+  if (count == 0) return AVS_OK;
+  AVS_REQUIRE(d_x && d_y, AVS_E_ARG, "avs_quantize_f32: null pointer");
+  long long gx = avs_cdiv(count, 256);
+  if (gx > 8192) gx = 8192;
+  hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, d_x, (long long)count, lo,
+                     hi, scale, d_y);
+  AVS_CHECK_LAUNCH("avs_quantize_f32");
+  return AVS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Channel mix-down + rational resampling (features/extractors.py:364-378 delegates to
+// pydub/ffmpeg "set_channels(1).set_frame_rate(16000)", :326-328 averages channels): polyphase FIR
+//   y[i*up + p] = sum_k mono[i*down + k - width] * taps[p][k],   mono[j] = mean_c x[j, c]  (0 outside the clip)
+// with `up` phases of `ntaps` windowed-sinc coefficients built on the host (audio.py).  One thread per output
+// sample; the taps of a phase are contiguous, the input window of neighbouring outputs overlaps (L1/L2 hits).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ x, long long t, int channels,
+                                                       const float* __restrict__ taps, int up, int down, int ntaps,
+                                                       int width, float* __restrict__ y, long long out_len) {
+  const float inv_c = 1.f / (float)channels;
+  for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < out_len;
+       o += (long long)gridDim.x * blockDim.x) {
+    const long long i = o / up;
+    const int ph = (int)(o - i * up);
+    const long long base = i * down - width;
+    const float* __restrict__ tp = taps + (long long)ph * ntaps;
+    float acc = 0.f;
+    for (int k = 0; k < ntaps; ++k) {
+      const long long j = base + k;
+      if (j < 0 || j >= t) continue;
+      float v = 0.f;
+      for (int c = 0; c < channels; ++c) v += x[j * channels + c];
+      if (channels > 1) v *= inv_c;
+      acc = fmaf(v, tp[k], acc);
+    }
+    y[o] = acc;
+  }
+}
+
+extern "C" int avs_resample_f32(const float* d_x, int64_t t, int channels, const float* d_taps, int up, int down,
+                                int ntaps, int width, float* d_y, int64_t out_len, avs_stream_t stream) {
+  AVS_REQUIRE(t >= 0 && channels > 0 && up > 0 && down > 0 && ntaps > 0 && width >= 0 && out_len >= 0, AVS_E_SHAPE,
+              "avs_resample_f32: bad extents");
+  if (out_len == 0) return AVS_OK;
+  AVS_REQUIRE(d_x && d_taps && d_y, AVS_E_ARG, "avs_resample_f32: null pointer");
+  AVS_REQUIRE((out_len - 1) / up * down - width < t, AVS_E_SHAPE,
+              "avs_resample_f32: %lld output samples need input past the %lld given", (long long)out_len, (long long)t);
+  long long gx = avs_cdiv(out_len, 256);
+  if (gx > 65536) gx = 65536;
+  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, d_x, (long long)t, channels,
+                     d_taps, up, down, ntaps, width, d_y, (long long)out_len);
+  AVS_CHECK_LAUNCH("avs_resample_f32");
   return AVS_OK;
 }

@@ -8,7 +8,7 @@ Same classes, attributes, method names and return types:
 
 Deviations forced by the environment: constructors never touch the
 network.  Weights come from ``load_state_dict`` (torchvision-compatible keys) or a seeded
-synthetic init; ``.vggish`` is a placeholder (VGGish is a torch.hub download).  All
+synthetic init (``.vggish`` included: the torch.hub model's module tree, vggish.py).  All
 arithmetic runs through libavsum_hip.so — there is no CPU fallback.
 """
 import numpy as np
@@ -18,6 +18,7 @@ import torch.nn as nn
 from .. import ops
 from ..audio import MelPlan
 from ..cnn import InceptionV3Runner, Inception3, ResNet50Runner, RESNET_MEAN, RESNET_STD, resnet50_trunk
+from ..vggish import VGGish
 
 FRAME_INTERVAL = 3  # extractors.py:399
 MAX_FRAMES = 100    # extractors.py:400
@@ -108,20 +109,16 @@ class VisualFeatureExtractor(nn.Module):
         return x[..., :3].permute(0, 3, 1, 2).contiguous().cpu()
 
 
-class _VGGishPlaceholder(nn.Module):
-    """``torch.hub.load('harritaylor/torchvggish', 'vggish')`` (extractors.py:188) is a network fetch and is
-    never attempted.  The literal forward never reaches VGGish; SURVEY §8 F3 lists it as next."""
-
-    def forward(self, *a, **k):
-        raise RuntimeError("VGGish weights are a torch.hub download and are not available offline")
-
-
 class AudioFeatureExtractor(nn.Module):
     def __init__(self, sr=16000, strict_reference=True):
         super().__init__()
         self.sr = sr
-        self.vggish = _VGGishPlaceholder()
+        # extractors.py:188 fetches the model with torch.hub (network: never attempted); this is the same
+        # module tree (load_state_dict-compatible) running on the MI355X, seeded synthetic weights until loaded
+        self.vggish = VGGish()
         self.vggish.eval()
+        for p in self.vggish.parameters():
+            p.requires_grad = False          # extractors.py:191-192
         self.mfcc_proj = nn.Linear(40, 128)  # random, never trained (extractors.py:193; SURVEY Q6)
         self.strict_reference = strict_reference
 
@@ -144,6 +141,11 @@ class AudioFeatureExtractor(nn.Module):
         out = np.zeros(296, dtype=np.float32)
         out[:40] = mfcc_mean[0].cpu().numpy()
         out[40:168] = mel_mean[0].cpu().numpy()
+        vg = self.vggish(wave.cpu().numpy(), self.sr)       # [n,128] / [128] / [0,128] (extractors.py:216)
+        vg = vg.reshape(-1, 128)
+        if vg.shape[0] > 0:
+            seg_v = torch.tensor([0, vg.shape[0]], dtype=torch.int64, device=vg.device)
+            out[168:] = ops.segment_mean(vg.contiguous(), seg_v)[0].cpu().numpy()   # vggish_feats.mean(0), :234
         return out
 
     def _extract_mfcc(self, waveform):
@@ -199,6 +201,16 @@ class AVProcessor:
         self.visual_extractor = VisualFeatureExtractor(dtype, bn_mode)
         self.audio_extractor = AudioFeatureExtractor(strict_reference=strict_reference)
         self.sr = self.audio_extractor.sr
+
+    def prepare_audio(self, samples, sample_rate):
+        """extractors.py:364-378 + :326-328 without ffmpeg: interleaved PCM [T] / [T, channels] at `sample_rate`
+        -> mono float32 numpy at self.sr (channel mean, polyphase resampling on the MI355X)."""
+        from ..audio import resample_to
+        x = np.asarray(samples)
+        if np.issubdtype(x.dtype, np.integer):
+            x = x.astype(np.float32) / float(1 << (8 * x.dtype.itemsize - 1))
+        x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(_device())
+        return resample_to(x, sample_rate, self.sr).cpu().numpy()
 
     def _detect_shots_decoded(self, frames):
         """extractors.py:388-393 on decoded frames: ContentDetector restated on the GPU (features/shots.py)."""

@@ -13,7 +13,7 @@ from ._abi import ACT_NONE, ACT_RELU, AVS_BF16, AVS_F32, BIAS_COL, BIAS_NONE, BI
 __all__ = [
     "ACT_NONE", "ACT_RELU", "linear", "gemm_nt_batched", "conv2d", "conv2d_raw", "conv_bnsync_workspace_bytes", "conv1x1_bn", "frames_normalize", "resize_bilinear",
     "bn_batch_stats", "bn_apply", "bn_maxpool", "pool2d", "global_avgpool", "segment_mean", "hsv_frame_diff", "reflect_pad", "stft_f64", "power_mel",
-    "clamp_topdb", "fill", "lstm", "mha_batchaxis", "score_head", "mhsa_flash", "softmax_rows", "cdist", "dtw_path",
+    "clamp_topdb", "fill", "quantize", "resample", "lstm", "mha_batchaxis", "score_head", "mhsa_flash", "softmax_rows", "cdist", "dtw_path",
     "gather_scale", "dtype_code",
 ]
 
@@ -396,6 +396,29 @@ def fill(x, value):
     _f32(x, "x")
     check(lib().avs_fill_f32(_p(x), x.numel(), float(value), _stream()), "avs_fill_f32")
     return x
+
+
+def quantize(x, lo, hi, scale, out=None):
+    _f32(x, "x")
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().avs_quantize_f32(_p(x), x.numel(), float(lo), float(hi), float(scale), _p(out), _stream()),
+          "avs_quantize_f32")
+    return out
+
+
+def resample(x, taps, up, down, width, out_len):
+    """x fp32 [t] or interleaved [t, channels] on device; taps fp32 [up, ntaps] -> mono fp32 [out_len]."""
+    _dev(x, taps)
+    _f32(x, "x")
+    _f32(taps, "taps")
+    if not x.is_contiguous() or not taps.is_contiguous() or taps.shape[0] != up:
+        raise ValueError("x must be contiguous [t] / [t, channels], taps contiguous [up, ntaps]")
+    channels = 1 if x.dim() == 1 else x.shape[1]
+    out = torch.empty(out_len, dtype=torch.float32, device=x.device)
+    check(lib().avs_resample_f32(_p(x), x.shape[0], channels, _p(taps), up, down, taps.shape[1], width, _p(out),
+                                 out_len, _stream()), "avs_resample_f32")
+    return out
 
 
 # --------------------------------------------------------------------------- scorer

@@ -253,7 +253,9 @@ int avs_stft_f64(const float* d_xpad, int64_t xpad_len, int64_t frames, int hop,
  *   mode 1: out = 10*log10(max(mel,1e-10)), and atomically folds the maximum
  *           of max(mel,1e-10) into *d_max, which the caller zeroed
  *           (AmplitudeToDB, first half)
- *   mode 2: out = mel                                                        */
+ *   mode 2: out = mel
+ *   mode 3: the MAGNITUDE spectrum sqrt(re^2+im^2) through the filterbank, out = ln(mel + 0.01): the VGGish
+ *           log-mel front end (torchvggish mel_features.log_mel_spectrogram; features/extractors.py:188,216) */
 int avs_power_mel_f32(const float* d_spec, int64_t frames, int nbins,
                       const float* d_fb, const int* d_fb_lo, const int* d_fb_hi,
                       int nmel, int mode, float* d_out, float* d_max,
@@ -263,6 +265,18 @@ int avs_power_mel_f32(const float* d_spec, int64_t frames, int nbins,
 int avs_clamp_topdb_f32(float* d_x, int64_t count, const float* d_max, float top_db,
                         avs_stream_t stream);
 int avs_fill_f32(float* d_x, int64_t count, float value, avs_stream_t stream);
+
+/* y = rint((clamp(x, lo, hi) - lo) * scale), round-half-to-even, values kept as float: the 8-bit quantiser of the
+ * VGGish post-processor (torchvggish Postprocessor.postprocess; features/extractors.py:188,216).              */
+int avs_quantize_f32(const float* d_x, int64_t count, float lo, float hi, float scale, float* d_y,
+                     avs_stream_t stream);
+
+/* Channel mix-down + rational resampling by a polyphase FIR (the reference delegates to
+ * pydub/ffmpeg set_channels(1).set_frame_rate(16000), features/extractors.py:364-378, and averages channels at
+ * :326-328):  y[i*up + p] = sum_k mono[i*down + k - width] * d_taps[p*ntaps + k],  mono = mean over the
+ * interleaved channels of d_x [t, channels], zero outside the clip.  The taps come from the host (audio.py).   */
+int avs_resample_f32(const float* d_x, int64_t t, int channels, const float* d_taps, int up, int down,
+                     int ntaps, int width, float* d_y, int64_t out_len, avs_stream_t stream);
 
 /* ---- importance scorer (K17-K19) ---------------------------------------- */
 

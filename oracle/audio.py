@@ -109,3 +109,28 @@ def audio_forward_literal(waveform):
     if len(waveform) < 1:
         return np.zeros(296, dtype=np.float32)
     return np.zeros(296)
+
+
+def resample_sinc(wave, orig_freq, new_freq, lowpass_filter_width=6, rolloff=0.99):
+    """Channel mean + torchaudio.functional.resample (sinc_interp_hann) restated with torch CPU ops [3P-memory,
+    parity unpinned]: the step the reference leaves to ffmpeg (features/extractors.py:364-378, :326-328).
+    wave: [T] or [T, channels] -> float32 [ceil(new*T/orig)]."""
+    x = torch.as_tensor(wave, dtype=torch.float32)
+    if x.dim() > 1:
+        x = x.mean(dim=1)
+    if int(orig_freq) == int(new_freq):
+        return x
+    g = math.gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    base = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base)
+    idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, None] / orig
+    t = torch.arange(0, -new, -1, dtype=torch.float64)[:, None, None] / new + idx
+    t = (t * base).clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    kern = (torch.where(t == 0, torch.tensor(1.0, dtype=torch.float64), t.sin() / t) * window * (base / orig)).float()
+    length = x.numel()
+    padded = torch.nn.functional.pad(x[None, None], (width, width + orig))
+    out = torch.nn.functional.conv1d(padded, kern, stride=orig).transpose(1, 2).reshape(-1)
+    return out[:math.ceil(new * length / orig)]

@@ -542,3 +542,65 @@ def test_train_synthetic_and_evaluate_scripts(dev, tmp_path):
     assert 0.0 <= out["f1"] <= 1.0
     with pytest.raises(ValueError):
         save_features(str(tmp_path), "bad", np.zeros((3, 100), np.float32), np.zeros((3, 296), np.float32))
+
+
+def test_vggish_vs_oracle(dev):
+    """VGGish on the HIP path (fp64-MFMA front end, fp32-MFMA network) against the CPU restatement: log-mel examples
+    <= 1e-4 abs, embeddings <= 1e-4 of their scale, quantised output identical up to rare +-1 round-off flips."""
+    from avsum_amd.vggish import VGGish, VGGishFrontEnd
+    from oracle import vggish as ov
+    torch.manual_seed(5)
+    net = VGGish()
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    rng = np.random.default_rng(3)
+    t = np.arange(16000 * 3 + 777) / 16000.0
+    wave = (0.4 * np.sin(2 * np.pi * 440 * t) + 0.2 * np.sin(2 * np.pi * 3100 * t) + 0.05 * rng.standard_normal(t.size))
+    wave = wave.astype(np.float32)
+    ref_ex = ov.waveform_to_examples(wave)
+    ex = VGGishFrontEnd.get(dev).examples(torch.from_numpy(wave).to(dev))
+    assert ex.shape == (3, 96, 64) and (ex.cpu() - ref_ex[:, 0]).abs().max().item() < 1e-4
+    with torch.no_grad():
+        ref_emb = ov.network(sd, ref_ex)
+        ref_out = ov.postprocess(sd, ref_emb)
+    net = net.to(dev)
+    emb = net.embed_examples(ex.contiguous()).cpu()
+    assert (emb - ref_emb).abs().max().item() < 1e-4 * max(1.0, ref_emb.abs().max().item())
+    out = net(wave, 16000).cpu()
+    assert out.shape == (3, 128) and out.min() >= 0 and out.max() <= 255
+    diff = (out - ref_out).abs()
+    assert diff.max().item() <= 1 and (diff > 0).float().mean().item() < 0.01
+    assert net(wave[:16000], 16000).shape == (128,)          # one example: squeezed like the hub model
+    assert net(wave[:8000], 16000).shape == (0, 128)         # shorter than one example
+    with pytest.raises(AttributeError):
+        net(torch.from_numpy(wave))                          # the hub model only takes numpy / a path
+
+
+def test_resample_and_audio_intent_mode(dev):
+    from avsum_amd import ops
+    from avsum_amd.audio import resample_to
+    from avsum_amd.features.extractors import AVProcessor, AudioFeatureExtractor
+    from oracle import audio as oa
+    rng = np.random.default_rng(8)
+    for sr, ch in ((48000, 1), (44100, 2), (22050, 1), (8000, 1), (16000, 2)):
+        x = rng.standard_normal((sr // 2 + 13, ch)).astype(np.float32)
+        ref = oa.resample_sinc(x, sr, 16000).numpy()
+        got = resample_to(torch.from_numpy(x if ch > 1 else x[:, 0].copy()).to(dev), sr, 16000).cpu().numpy()
+        assert got.shape == ref.shape and np.abs(got - ref).max() < 2e-5, (sr, ch)
+    proc = AVProcessor(strict_reference=False)
+    pcm = (rng.standard_normal((48000, 2)) * 8000).astype(np.int16)
+    mono = proc.prepare_audio(pcm, 48000)
+    assert mono.shape == (16000,) and mono.dtype == np.float32
+    assert np.abs(mono - oa.resample_sinc(pcm.astype(np.float32) / 32768.0, 48000, 16000).numpy()).max() < 2e-5
+    # "intent" mode of the audio extractor: [mean MFCC(40) | mean log2-mel(128) | mean VGGish(128)] = 296
+    torch.manual_seed(1)
+    ext = AudioFeatureExtractor(strict_reference=False)
+    t = np.arange(40000) / 16000.0
+    wave = (0.5 * np.sin(2 * np.pi * 660 * t)).astype(np.float32)
+    feat = ext(wave)
+    assert feat.shape == (296,) and np.isfinite(feat).all()
+    from oracle import vggish as ov
+    sd = {k: v.cpu() for k, v in ext.vggish.state_dict().items()}
+    want = ov.vggish_forward(sd, wave).mean(0).numpy()
+    assert np.abs(feat[168:] - want).max() <= 1.0
+    assert np.abs(feat[40:168] - oa.extract_mel_f64(wave).mean(0)).max() < 1e-3
+    assert np.array_equal(AudioFeatureExtractor()(wave), np.zeros(296))      # the literal reference behaviour stays

@@ -138,3 +138,58 @@ def test_shot_detector_restatement_known_answers():
     assert shots.detect_shots(video) == [(0, 20), (20, 40), (40, 45)]
     assert shots.detect_shots([a] * 30) == []      # no cut -> empty scene list, as scenedetect.detect returns
     assert shots.detect_shots([a] * 10 + [b] * 30) == []  # a change before min_scene_len frames is not a cut
+
+
+def test_vggish_restatement_known_answers():
+    """VGGish (third-party, absent here: parity unpinned) - facts of the published algorithm the restatement must
+    reproduce: parameter count, framing arithmetic, mel-matrix structure, front end of a pure tone, quantiser."""
+    from oracle import vggish as ov
+    from avsum_amd.vggish import VGGish
+    torch.manual_seed(0)
+    net = VGGish()
+    sd = net.state_dict()
+    assert sum(v.numel() for k, v in sd.items() if not k.startswith("pproc")) == 72141184
+    assert [k for k in sd if k.startswith("features")][::2] == [f"features.{i}.weight" for i in (0, 3, 6, 8, 11, 13)]
+    assert sd["embeddings.0.weight"].shape == (4096, 512 * 4 * 6) and sd["pproc.pca_means"].shape == (128, 1)
+    # framing: 25 ms windows every 10 ms, 96-frame examples every 96 frames
+    assert [ov.num_stft_frames(t) for t in (399, 400, 559, 560, 16000)] == [0, 1, 1, 2, 98]
+    assert [ov.num_examples(t) for t in (15599, 15600, 30959, 30960, 160000)] == [0, 1, 1, 2, 10]
+    fb = ov.mel_matrix()
+    assert fb.shape == (257, 64) and np.all(fb[0] == 0) and np.all(fb >= 0) and fb.max() <= 1.0
+    assert np.all((fb > 0).sum(1) <= 2) and np.all((fb > 0).sum(0) >= 1)       # <= 2 bands per bin, no empty band
+    hz = np.linspace(0, 8000, 257)
+    assert hz[(fb > 0).any(1)].min() > 125.0 and hz[(fb > 0).any(1)].max() < 7500.0
+    # a 1 kHz tone: the loudest band is the one whose triangle covers 1 kHz; silence -> log(0.01) everywhere
+    t = np.arange(16000) / 16000.0
+    lm = ov.log_mel_spectrogram(np.sin(2 * np.pi * 1000 * t))
+    edges = 700.0 * (np.exp(np.linspace(ov.hertz_to_mel(125.0), ov.hertz_to_mel(7500.0), 66) / 1127.0) - 1.0)
+    band = int(lm.mean(0).argmax())
+    assert edges[band] < 1000.0 < edges[band + 2]
+    assert np.allclose(ov.log_mel_spectrogram(np.zeros(4000)), np.log(0.01))
+    ex = ov.waveform_to_examples(np.sin(2 * np.pi * 1000 * np.arange(40000) / 16000.0))
+    assert ex.shape == (2, 1, 96, 64) and ex.dtype == torch.float32
+    out = ov.vggish_forward(sd, np.sin(2 * np.pi * 1000 * np.arange(40000) / 16000.0))
+    assert out.shape == (2, 128) and out.min() >= 0 and out.max() <= 255 and torch.equal(out, out.round())
+    q = ov.postprocess({"pproc.pca_eigen_vectors": torch.eye(128), "pproc.pca_means": torch.zeros(128, 1)},
+                       torch.tensor([-3.0, 0.0, 3.0, 1.0] + [0.0] * 124)[None])
+    assert q[0, :4].tolist() == [0.0, 128.0, 255.0, 191.0]     # 127.5 -> 128 and 191.25 -> 191 (half to even)
+
+
+def test_resample_restatement_known_answers():
+    from oracle import audio as oa
+    from avsum_amd.audio import resample_taps
+    kern, width, orig, new = resample_taps(48000, 16000)
+    assert (orig, new) == (3, 1) and kern.shape == (1, 2 * width + 3) and abs(kern.sum() - 1.0) < 1e-3   # DC gain 1
+    kern, width, orig, new = resample_taps(44100, 16000)
+    assert (orig, new) == (441, 160) and kern.shape == (160, 2 * width + 441)
+    assert np.allclose(kern.sum(1), 1.0, atol=2e-3)
+    t48 = np.arange(48000) / 48000.0
+    tone = np.sin(2 * np.pi * 1000 * t48).astype(np.float32)
+    y = oa.resample_sinc(tone, 48000, 16000).numpy()
+    assert y.shape == (16000,)
+    assert np.abs(y[100:-100] - np.sin(2 * np.pi * 1000 * np.arange(16000) / 16000.0)[100:-100]).max() < 1e-3
+    alias = oa.resample_sinc(np.sin(2 * np.pi * 11000 * t48).astype(np.float32), 48000, 16000).numpy()
+    assert np.abs(alias[100:-100]).max() < 0.02                                   # above the new Nyquist: removed
+    stereo = np.stack([tone, -tone], 1)
+    assert np.abs(oa.resample_sinc(stereo, 48000, 16000).numpy()).max() < 1e-6    # channel mean first
+    assert oa.resample_sinc(np.ones(44100, np.float32), 44100, 16000).shape == (16000,)
