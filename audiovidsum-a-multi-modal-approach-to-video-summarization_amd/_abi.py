@@ -45,6 +45,8 @@ _SIGNATURES = {
     "avs_bn_finalize": (c_int, [P, P, c_int, c_int, c_int64, P, P, c_float, P, P, P]),
     "avs_conv1x1_bn_bf16": (c_int, [P, c_int64, c_int, P, c_int64, c_int, c_int64, c_int, P, P, c_float, P, c_int64,
                                     c_int, P, c_int64, P]),
+    "avs_conv1x1_bn_in_bf16": (c_int, [P, c_int64, c_int, P, P, P, c_int64, c_int, c_int64, c_int, P, P, c_float, P,
+                                       c_int64, c_int, P, c_int64, P]),
     "avs_conv2d_bnsync_workspace_bytes": (c_int64, [POINTER(ConvDesc), c_int64]),
     "avs_conv2d_nhwc_bnsync": (c_int, [POINTER(ConvDesc), P, P, P, c_int64, P, P, c_float, P, c_int64, P, c_int64,
                                        P, P]),

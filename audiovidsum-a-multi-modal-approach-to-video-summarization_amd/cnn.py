@@ -107,6 +107,7 @@ class ResNet50Runner:
         self.fuse_conv_bn = True
         self.fuse_min_rows, self.fuse_ratio_num, self.fuse_ratio_den = 128, 2, 1
         self.bn_sync = True
+        self.defer_bn_apply = True   # bn2 + ReLU applied inside conv3's two-pass kernel (avs_conv1x1_bn_in_bf16)
         # measured on MI355X (tools/bn_study.py, 1024-frame chunk): a tile of the sync form waits for the SLOWEST
         # tile of its group, so the form wins 1.1-1.35x where a group is two or three row tiles (14x14 and 7x7
         # maps) and loses 3-5x where it is 25-100 of them (56x56, 112x112): taken up to this many rows per group
@@ -205,10 +206,19 @@ class ResNet50Runner:
             self._err.zero_()
         return bad
 
-    def _conv_bn(self, geom, xs, x, wt, bnp, groups, residual=None, relu=True, sync=None, algo_k=None, pool=None):
+    def _twopass_ok(self, cin, cout, kh, sh, gmax):
+        # measured on MI355X: the two-pass kernel wins over the split form where the layer is write-heavy
+        # (cout >= 2*cin: the conv3 / downsample layers) and a group is several row tiles long
+        return (kh == 1 and sh == 1 and self.fuse_conv_bn and gmax >= self.fuse_min_rows
+                and cout * self.fuse_ratio_den >= cin * self.fuse_ratio_num)
+
+    def _conv_bn(self, geom, xs, x, wt, bnp, groups, residual=None, relu=True, sync=None, algo_k=None, pool=None,
+                 defer=False, in_affine=None):
         """One convolution + BatchNorm (+ residual, + ReLU) -> NHWC activation; picks the form (class docstring).
         pool = (k, s, p): a max pooling follows (the stem) - on the split form it is fused with the BatchNorm apply
-        (avs_bn_maxpool_nhwc: the normalised full-resolution map is never written)."""
+        (avs_bn_maxpool_nhwc: the normalised full-resolution map is never written).
+        defer: return (raw convolution, (scale, shift)) WITHOUT applying the BatchNorm - the next layer's two-pass
+        kernel applies it while staging its input (in_affine), so this layer needs no apply pass (bf16, equal groups)."""
         n, ho, wo, cout = geom[0], geom[10], geom[11], geom[12]
         cin, kh, sh = geom[3], geom[4], geom[6]
         dev, dt = x.device, self.dtype
@@ -250,15 +260,14 @@ class ResNet50Runner:
                 out, k, s, p = pooled(y)
                 return ops.pool2d(y, "max", k, s, p, out)
             return y
-        # measured on MI355X: the two-pass kernel wins over the split form where the layer is write-heavy
-        # (cout >= 2*cin: the conv3 / downsample layers) and a group is several row tiles long
-        if (fast and kh == 1 and sh == 1 and self.fuse_conv_bn and gmax >= self.fuse_min_rows
-                and cout * self.fuse_ratio_den >= cin * self.fuse_ratio_num):
-            ops.conv1x1_bn(x.view(-1, cin), wt, gmax, gamma, beta, eps, y2d, residual, relu)
+        if in_affine is not None or (fast and self._twopass_ok(cin, cout, kh, sh, gmax)):
+            ops.conv1x1_bn(x.view(-1, cin), wt, gmax, gamma, beta, eps, y2d, residual, relu, in_affine)
             return y
         if fast:
             # statistics from the convolution's epilogue (E[x^2]-E[x]^2 by float atomics: fine for bf16 activations)
             scale, shift = conv(bnstats=(gmax, gamma, beta, eps))
+            if defer:
+                return y, (scale, shift)
         else:
             # fp32 parity mode / ragged groups: the shifted, deterministic statistics pass
             conv()
@@ -304,19 +313,32 @@ class ResNet50Runner:
             s, planes = blk["stride"], blk["planes"]
             cin = x.shape[3]
             hout = hcur // s
+            s1, s2 = slot(), slot()
+            sd = slot() if "cd" in blk else None
+            s3 = slot()
             geom, xs, _ = self._nhwc_geom(n, hcur, cin, 1, 1, 0, planes)
-            t1 = self._conv_bn(geom, xs, x, blk["c1"], blk["b1"], groups, sync=slot())
+            t1 = self._conv_bn(geom, xs, x, blk["c1"], blk["b1"], groups, sync=s1)
+            # bn2 + ReLU ride in conv3's input staging when conv3 takes the two-pass kernel: conv2 then only
+            # writes its raw output and statistics (no apply pass over it)
+            gmax3 = gsz * hout * hout
+            defer2 = (self.defer_bn_apply and self.bn_mode == "batch" and uniform and dt == torch.bfloat16
+                      and s2 is None and s3 is None and planes <= 512
+                      and self._twopass_ok(planes, planes * 4, 1, 1, gmax3))
             geom, xs, _ = self._nhwc_geom(n, hcur, planes, 3, s, 1, planes)
-            t2 = self._conv_bn(geom, xs, t1, blk["c2"], blk["b2"], groups, sync=slot())
+            t2 = self._conv_bn(geom, xs, t1, blk["c2"], blk["b2"], groups, sync=s2, defer=defer2)
+            aff2 = None
+            if defer2:
+                t2, aff2 = t2
             del t1
             if "cd" in blk:
                 geom, xs, _ = self._nhwc_geom(n, hcur, cin, 1, s, 0, planes * 4)
                 idn = self._conv_bn(geom, xs, x, blk["cd"], blk["bd"], groups, relu=False,
-                                    sync=slot()).view(-1, planes * 4)
+                                    sync=sd).view(-1, planes * 4)
             else:
                 idn = x.view(-1, cin)
             geom, xs, _ = self._nhwc_geom(n, hout, planes, 1, 1, 0, planes * 4)
-            x = self._conv_bn(geom, xs, t2, blk["c3"], blk["b3"], groups, residual=idn, relu=True, sync=slot())
+            x = self._conv_bn(geom, xs, t2, blk["c3"], blk["b3"], groups, residual=idn, relu=True, sync=s3,
+                              in_affine=aff2)
             del t2, idn
             hcur = hout
         feats = ops.global_avgpool(x, out)

@@ -33,13 +33,19 @@ struct ConvBnParams {
   long long lin_stride, ldb, ldc, ldr;
   int rows_per_group, groups, tiles_n;
   int relu;
+  // XF: the input is a RAW convolution output whose BatchNorm (+ ReLU) is applied on the way in:
+  // a[m,k] = relu(x[m,k] * in_scale[g,k] + in_shift[g,k]) rounded to bf16 (avs_bn_apply's arithmetic)
+  const float* in_scale;
+  const float* in_shift;
 };
+
+#define AVS_CONVBN_MAX_K 512
 
 #define AVS_GLDS16(src, dst)                                                                        \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),            \
                                    (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
-template <int BN>
+template <int BN, bool XF>
 __global__ __launch_bounds__(256, 3) void conv1x1_bn_kernel(ConvBnParams p) {
   constexpr int ES = 2, ROWB = 64;
   constexpr int CE = 16 / ES, BKE = ROWB / ES, CPRR = ROWB / 16, RPP = 256 / CPRR, SH = 2, KS = ROWB / 32;
@@ -55,6 +61,7 @@ __global__ __launch_bounds__(256, 3) void conv1x1_bn_kernel(ConvBnParams p) {
   // from 3 to 2 workgroups per CU than it won: 29.9 k vs 32.1 k frames/s end to end.)
   __shared__ uint4 lds[LDS_SLOTS];
   __shared__ float red[2][BN][2];
+  __shared__ __attribute__((aligned(16))) float xf[XF ? 2 : 1][XF ? AVS_CONVBN_MAX_K : 4];  // input scale | shift
 
   const unsigned nwg = gridDim.x, orig = blockIdx.x;
   const unsigned q = nwg >> 3, rr = nwg & 7, xcd = orig & 7;
@@ -86,6 +93,13 @@ __global__ __launch_bounds__(256, 3) void conv1x1_bn_kernel(ConvBnParams p) {
   }
 
   const int steps = (p.K + BKE - 1) / BKE;
+  if constexpr (XF) {
+    for (int i = t; i < p.K; i += 256) {
+      xf[0][i] = p.in_scale[(long long)g * p.K + i];
+      xf[1][i] = p.in_shift[(long long)g * p.K + i];
+    }
+    __syncthreads();
+  }
   float s1[NT], s2[NT], scale[NT], shift[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) s1[nt] = s2[nt] = scale[nt] = shift[nt] = 0.f;
@@ -116,6 +130,38 @@ __global__ __launch_bounds__(256, 3) void conv1x1_bn_kernel(ConvBnParams p) {
         }
         kc += BKE;
       };
+      // XF: every thread normalises the A chunks IT staged (its own LDS-DMA has landed after vmcnt(0)), in place,
+      // before the barrier that publishes the buffer.  Rows past the group and the K tail stay zero.
+      auto transform = [&](int buf, int kfirst) {
+        if constexpr (XF) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          const int kk = kfirst + cq * CE;
+          if (kk < p.K) {
+            const float4 sa = *reinterpret_cast<const float4*>(&xf[0][kk]);
+            const float4 sb = *reinterpret_cast<const float4*>(&xf[0][kk + 4]);
+            const float4 ha = *reinterpret_cast<const float4*>(&xf[1][kk]);
+            const float4 hb = *reinterpret_cast<const float4*>(&xf[1][kk + 4]);
+            const float sc[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+            const float sh[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+              if (a_base[i] == nullptr) continue;
+              uint4* slot = lds + buf * BUF + t + 256 * i;
+              const uint4 v = *slot;
+              unsigned vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                float lo = __uint_as_float(vv[j] << 16) * sc[2 * j] + sh[2 * j];
+                float hi = __uint_as_float(vv[j] & 0xffff0000u) * sc[2 * j + 1] + sh[2 * j + 1];
+                lo = fmaxf(lo, 0.f);
+                hi = fmaxf(hi, 0.f);
+                vv[j] = (unsigned)avs_f32_to_bf16(lo) | ((unsigned)avs_f32_to_bf16(hi) << 16);
+              }
+              *slot = make_uint4(vv[0], vv[1], vv[2], vv[3]);
+            }
+          }
+        }
+      };
 
       f32x16 acc[2][NT];
 #pragma unroll
@@ -126,6 +172,7 @@ __global__ __launch_bounds__(256, 3) void conv1x1_bn_kernel(ConvBnParams p) {
           for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
       stage(0);
+      transform(0, 0);
       __syncthreads();
       for (int s = 0; s < steps; ++s) {
         const int buf = s & 1;
@@ -157,6 +204,7 @@ __global__ __launch_bounds__(256, 3) void conv1x1_bn_kernel(ConvBnParams p) {
                                                                     __builtin_bit_cast(bf16x8, fb[ks][nt]),
                                                                     acc[mt][nt], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < steps) transform(buf ^ 1, (s + 1) * BKE);
         __syncthreads();
       }
 
@@ -253,10 +301,36 @@ __global__ __launch_bounds__(256, 3) void conv1x1_bn_kernel(ConvBnParams p) {
 static int g_convbn_narrow = 0;
 extern "C" void avs_tune_convbn_narrow(int enabled) { g_convbn_narrow = enabled; }
 
+static int conv1x1_bn_launch(const void* d_x, int64_t lin_stride, int k, const void* d_w, int64_t ldb, int n,
+                             int64_t rows_per_group, int groups, const float* d_gamma, const float* d_beta, float eps,
+                             const void* d_residual, int64_t ldr, int relu, void* d_y, int64_t ldc,
+                             const float* d_in_scale, const float* d_in_shift, avs_stream_t stream);
+
 extern "C" int avs_conv1x1_bn_bf16(const void* d_x, int64_t lin_stride, int k, const void* d_w, int64_t ldb, int n,
                                    int64_t rows_per_group, int groups, const float* d_gamma, const float* d_beta,
                                    float eps, const void* d_residual, int64_t ldr, int relu, void* d_y, int64_t ldc,
                                    avs_stream_t stream) {
+  return conv1x1_bn_launch(d_x, lin_stride, k, d_w, ldb, n, rows_per_group, groups, d_gamma, d_beta, eps, d_residual,
+                           ldr, relu, d_y, ldc, nullptr, nullptr, stream);
+}
+
+extern "C" int avs_conv1x1_bn_in_bf16(const void* d_x, int64_t lin_stride, int k, const float* d_in_scale,
+                                      const float* d_in_shift, const void* d_w, int64_t ldb, int n,
+                                      int64_t rows_per_group, int groups, const float* d_gamma, const float* d_beta,
+                                      float eps, const void* d_residual, int64_t ldr, int relu, void* d_y,
+                                      int64_t ldc, avs_stream_t stream) {
+  AVS_REQUIRE(d_in_scale && d_in_shift, AVS_E_ARG, "avs_conv1x1_bn_in_bf16: null input scale / shift");
+  AVS_REQUIRE(k <= AVS_CONVBN_MAX_K, AVS_E_UNSUPPORTED, "avs_conv1x1_bn_in_bf16: k=%d > %d", k, AVS_CONVBN_MAX_K);
+  AVS_REQUIRE(avs_aligned16(d_in_scale) && avs_aligned16(d_in_shift), AVS_E_ALIGN,
+              "avs_conv1x1_bn_in_bf16: input scale / shift must be 16-byte aligned");
+  return conv1x1_bn_launch(d_x, lin_stride, k, d_w, ldb, n, rows_per_group, groups, d_gamma, d_beta, eps, d_residual,
+                           ldr, relu, d_y, ldc, d_in_scale, d_in_shift, stream);
+}
+
+static int conv1x1_bn_launch(const void* d_x, int64_t lin_stride, int k, const void* d_w, int64_t ldb, int n,
+                             int64_t rows_per_group, int groups, const float* d_gamma, const float* d_beta, float eps,
+                             const void* d_residual, int64_t ldr, int relu, void* d_y, int64_t ldc,
+                             const float* d_in_scale, const float* d_in_shift, avs_stream_t stream) {
   AVS_REQUIRE(k > 0 && n > 0 && groups >= 0 && rows_per_group > 0 && rows_per_group < (1ll << 30), AVS_E_SHAPE,
               "avs_conv1x1_bn_bf16: k=%d n=%d groups=%d rows_per_group=%lld", k, n, groups, (long long)rows_per_group);
   if (groups == 0) return AVS_OK;
@@ -283,15 +357,22 @@ extern "C" int avs_conv1x1_bn_bf16(const void* d_x, int64_t lin_stride, int k, c
   p.rows_per_group = (int)rows_per_group;
   p.groups = groups;
   p.relu = relu;
+  p.in_scale = d_in_scale;
+  p.in_shift = d_in_shift;
+  const bool xf = d_in_scale != nullptr;
   const bool narrow = n <= 64 || g_convbn_narrow;
   const int bn = narrow ? 64 : 128;
   p.tiles_n = (n + bn - 1) / bn;
   const long long total = (long long)groups * p.tiles_n;
   AVS_REQUIRE(total < (1ll << 31), AVS_E_SHAPE, "avs_conv1x1_bn_bf16: too many workgroups");
-  if (narrow)
-    hipLaunchKernelGGL(conv1x1_bn_kernel<64>, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, p);
+  if (narrow && xf)
+    hipLaunchKernelGGL((conv1x1_bn_kernel<64, true>), dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, p);
+  else if (narrow)
+    hipLaunchKernelGGL((conv1x1_bn_kernel<64, false>), dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, p);
+  else if (xf)
+    hipLaunchKernelGGL((conv1x1_bn_kernel<128, true>), dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, p);
   else
-    hipLaunchKernelGGL(conv1x1_bn_kernel<128>, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((conv1x1_bn_kernel<128, false>), dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, p);
   AVS_CHECK_LAUNCH("avs_conv1x1_bn_bf16");
   return AVS_OK;
 }

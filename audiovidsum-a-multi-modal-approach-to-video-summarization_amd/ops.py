@@ -192,9 +192,11 @@ def conv2d_raw(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x, x_i
     return scale, shift
 
 
-def conv1x1_bn(x2d, wt, rows_per_group, gamma, beta, eps, out2d, residual=None, relu=True):
+def conv1x1_bn(x2d, wt, rows_per_group, gamma, beta, eps, out2d, residual=None, relu=True, in_affine=None):
     """Fused 1x1 convolution + batch-statistics BatchNorm (+residual, +ReLU), bf16.  x2d [rows, K] (rows =
-    groups * rows_per_group), wt [N, K], out2d [rows, N]; every tensor row-major with unit column stride."""
+    groups * rows_per_group), wt [N, K], out2d [rows, N]; every tensor row-major with unit column stride.
+    in_affine = (scale, shift) fp32 [groups, K]: x2d is a RAW convolution output whose BatchNorm + ReLU is applied
+    on the way in (avs_conv1x1_bn_in_bf16)."""
     _dev(x2d, wt, out2d, residual, gamma, beta)
     _rowmajor2d(x2d, "x")
     _rowmajor2d(wt, "w")
@@ -210,6 +212,17 @@ def conv1x1_bn(x2d, wt, rows_per_group, gamma, beta, eps, out2d, residual=None, 
     groups = rows // rows_per_group
     # algorithmic HBM bytes: read x once, write y once (+ read the residual); the second pass re-reads from L2
     nbytes = 2.0 * rows * (k + n * (2 if residual is not None else 1))
+    if in_affine is not None:
+        isc, ish = in_affine
+        _dev(isc, ish)
+        if isc.shape != (groups, k) or ish.shape != (groups, k) or not isc.is_contiguous() or not ish.is_contiguous():
+            raise ValueError("in_affine must be contiguous fp32 [groups, K]")
+        _timed("convbn", AVS_BF16, nbytes, lambda: check(
+            lib().avs_conv1x1_bn_in_bf16(_p(x2d), x2d.stride(0), k, _p(isc), _p(ish), _p(wt), wt.stride(0), n,
+                                         rows_per_group, groups, _p(gamma), _p(beta), float(eps), _p(residual),
+                                         residual.stride(0) if residual is not None else 0, 1 if relu else 0,
+                                         _p(out2d), out2d.stride(0), _stream()), "avs_conv1x1_bn_in_bf16"))
+        return out2d
     _timed("convbn", AVS_BF16, nbytes, lambda: check(
         lib().avs_conv1x1_bn_bf16(_p(x2d), x2d.stride(0), k, _p(wt), wt.stride(0), n, rows_per_group, groups,
                                   _p(gamma), _p(beta), float(eps), _p(residual),

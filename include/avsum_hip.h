@@ -132,6 +132,17 @@ int avs_conv1x1_bn_bf16(const void* d_x, int64_t lin_stride, int k, const void* 
                         float eps, const void* d_residual, int64_t ldr, int relu, void* d_y, int64_t ldc,
                         avs_stream_t stream);
 
+/* The same kernel reading a RAW convolution output as its input: the previous layer's BatchNorm + ReLU is applied
+ * on the way in,  a[m,k] = bf16( relu( x[m,k] * d_in_scale[g,k] + d_in_shift[g,k] ) )  (avs_bn_apply's arithmetic:
+ * bit-identical to running avs_bn_apply on x first), so the previous layer needs no apply pass at all: the
+ * conv2 -> bn2 -> relu -> conv3 -> bn3 -> +identity -> relu tail of a ResNet bottleneck in two launches.
+ * d_in_scale / d_in_shift are [groups, k] fp32 (avs_bn_finalize output); k <= 512 (else AVS_E_UNSUPPORTED).                      */
+int avs_conv1x1_bn_in_bf16(const void* d_x, int64_t lin_stride, int k, const float* d_in_scale,
+                           const float* d_in_shift, const void* d_w, int64_t ldb, int n,
+                           int64_t rows_per_group, int groups, const float* d_gamma, const float* d_beta,
+                           float eps, const void* d_residual, int64_t ldr, int relu, void* d_y, int64_t ldc,
+                           avs_stream_t stream);
+
 /* Tuning knob: 1 = 64-channel slabs (4 workgroups per CU) in avs_conv1x1_bn_bf16 whatever n is.          */
 void avs_tune_convbn_narrow(int enabled);
 

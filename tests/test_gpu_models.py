@@ -264,6 +264,44 @@ def test_conv1x1_bn_one_kernel(dev, rpg, k, n, with_res, relu):
     assert err < 0.03 * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize("rpg,k,n,with_res", [(3136, 64, 256, True), (784, 128, 512, True), (300, 64, 64, False),
+                                               (196, 256, 1024, True), (128, 512, 200, False)])
+def test_conv1x1_bn_input_affine_is_bn_apply_first(dev, rpg, k, n, with_res):
+    """avs_conv1x1_bn_in_bf16 (the previous layer's BatchNorm + ReLU applied while staging the input) must be
+    BIT-IDENTICAL to avs_bn_apply on the raw input followed by avs_conv1x1_bn_bf16."""
+    from avsum_amd import ops
+    g = torch.Generator().manual_seed(rpg * 3 + k)
+    groups = 4
+    rows = groups * rpg
+    raw = (torch.randn(rows, k, generator=g) * 2 + 0.3).bfloat16().to(dev)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).bfloat16().to(dev)
+    isc = torch.randn(groups, k, generator=g).to(dev)            # both signs
+    ish = torch.randn(groups, k, generator=g).to(dev)
+    gamma, beta = (torch.rand(n, generator=g) + 0.5).to(dev), torch.randn(n, generator=g).to(dev)
+    res = torch.randn(rows, n, generator=g).bfloat16().to(dev) if with_res else None
+    grows = torch.arange(0, rows + 1, rpg, dtype=torch.int64, device=dev)
+    xin = ops.bn_apply(raw, isc, ish, grows, rpg, None, ops.ACT_RELU)
+    want = ops.conv1x1_bn(xin, w, rpg, gamma, beta, 1e-5, torch.empty(rows, n, dtype=torch.bfloat16, device=dev), res, True)
+    got = ops.conv1x1_bn(raw, w, rpg, gamma, beta, 1e-5, torch.empty(rows, n, dtype=torch.bfloat16, device=dev), res, True,
+                         in_affine=(isc, ish))
+    assert torch.equal(got, want)
+
+
+def test_resnet50_bf16_deferred_bn_apply_close(dev):
+    """Whole trunk with bn2 applied inside conv3's kernel vs applied by its own pass: the same arithmetic; the runs
+    differ only by the order of the float atomics that sum conv2's statistics."""
+    from avsum_amd.cnn import ResNet50Runner, resnet50_trunk
+    torch.manual_seed(29)
+    trunk = resnet50_trunk().to(dev)
+    frames = torch.from_numpy(_frames(8, 6)).to(dev)
+    a = ResNet50Runner(trunk, torch.bfloat16)
+    b = ResNet50Runner(trunk, torch.bfloat16)
+    b.defer_bn_apply = False
+    fa, fb = a.forward(frames).cpu(), b.forward(frames).cpu()
+    assert ((fa - fb).norm() / fb.norm()).item() < 0.05
+    assert torch.nn.functional.cosine_similarity(fa, fb, dim=1).min().item() > 0.995
+
+
 def _bn_reference(raw, rpg, gamma, beta, res, relu):
     rows, n = raw.shape
     ref = torch.empty(rows, n)
