@@ -15,6 +15,9 @@ shapes = [  # name, n, hw, cin, cout, k, stride
     ("l3.conv3 1x1 256->1024", 1024, 14, 256, 1024, 1, 1),
     ("l3.conv2 3x3 256->256", 1024, 14, 256, 256, 3, 1),
     ("l4.conv2 3x3 512->512", 1024, 7, 512, 512, 3, 1),
+    ("l2.conv2 3x3 128->128", 1024, 28, 128, 128, 3, 1),
+    ("l3.conv1 1x1 1024->256", 1024, 14, 1024, 256, 1, 1),
+    ("l4.conv1 1x1 2048->512", 1024, 7, 2048, 512, 1, 1),
 ]
 dt = torch.bfloat16
 for name, n, hw, cin, cout, k, s in shapes:
@@ -26,7 +29,7 @@ for name, n, hw, cin, cout, k, s in shapes:
     byts = (x.numel() + y.numel() + w.numel()) * 2
     line = f"{name:26s}"
     for tag, flags, rowb, pipe in (("base", 0, 100000, 0), ("pipe3", 0, 100000, 1), ("rowb128", 0, 0, 0),
-                                   ("nostore", 1, 100000, 0)):
+                                   ("nostore", 1, 100000, 0), ("noload128", 2, 0, 0), ("noload64p", 2, 100000, 1)):
         L.avs_debug_flags(flags)
         L.avs_tune_short_reduction_bytes(rowb)
         L.avs_tune_pipeline(pipe)
