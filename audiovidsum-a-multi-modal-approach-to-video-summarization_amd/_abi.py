@@ -51,10 +51,12 @@ _SIGNATURES = {
     "avs_conv2d_nhwc_bnsync": (c_int, [POINTER(ConvDesc), P, P, P, c_int64, P, P, c_float, P, c_int64, P, c_int64,
                                        P, P]),
     "avs_tune_bnsync_timeout_ticks": (None, [c_int64]),
+    "avs_tune_bnlocal": (None, [c_int]),
     "avs_debug_bnsync_trace": (None, [P]),
     "avs_tune_short_reduction_bytes": (None, [c_int]),
     "avs_debug_flags": (None, [c_int]),
     "avs_tune_pipeline": (None, [c_int]),
+    "avs_tune_tall_tiles": (None, [c_int, c_int64, c_int64]),
     "avs_tune_convbn_narrow": (None, [c_int]),
     "avs_gemm_nt": (c_int, [c_int, c_int, c_int, c_int, P, c_int64, c_int64, P, c_int64, c_int64, P, c_int64,
                             c_int64, P, c_int, c_int64, c_float, c_int, c_int, P]),

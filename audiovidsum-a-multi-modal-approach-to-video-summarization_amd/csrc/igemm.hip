@@ -68,6 +68,8 @@ struct IgemmParams {
   long long ldr;
   int tiles_m;
   long long spin_ticks;
+  int tall;          // 1: the 256-row tile variants (WR = 4)
+  int tile_rows;     // EPI_BNLOCAL: rows of the tile that are used (whole groups), also the pitch between tiles
   long long* trace;  // kernel-study only: per block {xcc id, start, arrive, wait end} wall-clock ticks
   int debug;  // ablation switches for kernel studies (0 in production): 1 = skip output stores, 2 = skip A/B loads
 };
@@ -92,7 +94,14 @@ struct IgemmParams {
 //              (see the tile map below), so the wait is the dispatch skew of a few dozen workgroups; the launcher
 //              only takes this form when a group's tiles fit the resident set several times over, and a wait that
 //              exceeds spin_ticks sets *err instead of hanging (the host then recomputes on the unfused path).
-enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_ANY = 2, EPI_BRELU = 3, EPI_BNSYNC = 4 };
+//   EPI_BNLOCAL bf16, 256-row tiles only: the whole BatchNorm in the epilogue WITHOUT any traffic between workgroups.
+//              A tile holds floor(256 / rows_per_group) WHOLE groups (tile pitch = that many rows, the rest of the
+//              256 rows idle), so a group's statistics are sums over this tile's accumulators alone: per-wave masked
+//              column sums -> LDS across the four row-waves -> scale/shift table -> normalise (+ residual, + ReLU)
+//              -> store.  No atomics, no waiting, deterministic.  Taken when groups are at most 256 rows and fill
+//              at least 3/4 of the tile (per-frame 14x14 and 7x7 maps: 196 = 77 %, 5 x 49 = 96 %).
+enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_ANY = 2, EPI_BRELU = 3, EPI_BNSYNC = 4, EPI_BNLOCAL = 5 };
+constexpr int BNLOCAL_MAX_GROUPS = 6;  // groups per 256-row tile (rows_per_group >= 43)
 constexpr int BNSYNC_MAX_GROUPS = 4;  // groups one 128-row tile may overlap
 
 // PIPE: three operand buffers, the DMA of step s+2 is issued in step s; fragment reads are inline-asm
@@ -105,8 +114,13 @@ __device__ __forceinline__ uint4 avs_lds_read_b128(unsigned byte_addr) {
   return v;
 }
 
-template <int ES, int BN, bool ACC64, bool SPATIAL, int ROWB, int EPI, bool PIPE>
-__global__ __launch_bounds__(256, (ROWB == 64 && !ACC64) ? 3 : 2) void igemm_kernel(IgemmParams p) {
+// WR: rows of waves.  2 = the 128 x BN tile (2 x 2 waves of 64 x BN/2); 4 = a 256 x BN tile (4 x 1 waves of 64 x BN):
+// twice the matrix work per barrier and 0.75 (BN = 128) instead of 1 fragment read per MFMA, for layers with many
+// rows whose cost is the loop itself (the N = 64 layers run 4 MFMAs per wave between barriers at WR = 2).
+template <int ES, int BN, bool ACC64, bool SPATIAL, int ROWB, int EPI, bool PIPE, int WR = 2>
+__global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? 3 : 2) void igemm_kernel(
+    IgemmParams p) {
+  static_assert(WR == 2 || (WR == 4 && ES == 2 && !ACC64), "256-row tiles are built for the bf16 variants");
   static_assert(!PIPE || (ROWB == 64 && !ACC64), "the 3-buffer pipeline is built for the 64-byte-row variants");
   static_assert(!ACC64 || (ES == 4 && BN == 64), "fp64 slice accumulation: fp32 operands, narrow tile only");
   static_assert(ROWB == 64 || ROWB == 128, "row bytes");
@@ -116,15 +130,19 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64) ? 3 : 2) void igemm_ker
   constexpr int RPP = 256 / CPRR;    // rows staged per pass of the 256 threads
   constexpr int SH = ROWB == 128 ? 1 : 2;  // rows sharing one 256-byte bank row = 1 << SH
   constexpr int KS = ROWB / 32;      // MFMA sub-steps per row (two chunks each)
-  constexpr int A_ROWS = 128;
+  constexpr int WC = 4 / WR;         // columns of waves
+  constexpr int WCOLS = BN / WC;     // output columns per wave
+  constexpr int A_ROWS = 64 * WR;
   constexpr int NA = A_ROWS / RPP;   // A rows staged per thread
   constexpr int NB = BN / RPP;       // B rows staged per thread
-  constexpr int NT = BN / 64;        // 32-wide column tiles per wave
+  constexpr int NT = WCOLS / 32;     // 32-wide column tiles per wave
   constexpr int BUF = (A_ROWS + BN) * CPRR;  // uint4 slots per buffer
   constexpr int CT_PITCH = BN * 2 + 16;      // bf16 epilogue staging tile: row pitch in bytes (16 bytes of padding)
   constexpr int CT_SLOTS = ES == 2 ? (A_ROWS * CT_PITCH) / 16 : 0;
   constexpr int NBUF = PIPE ? 3 : 2;
-  constexpr int TAB_SLOTS = EPI == EPI_BNSYNC ? (BNSYNC_MAX_GROUPS * 2 * BN * 4) / 16 : 0;  // scale/shift table
+  constexpr int TAB_SLOTS = EPI == EPI_BNSYNC    ? (BNSYNC_MAX_GROUPS * 2 * BN * 4) / 16
+                            : EPI == EPI_BNLOCAL ? (BNLOCAL_MAX_GROUPS * 2 * BN * 4) / 16
+                                                 : 0;  // scale/shift table (behind the staging tile)
   constexpr int LDS_SLOTS = NBUF * BUF > CT_SLOTS + TAB_SLOTS ? NBUF * BUF : CT_SLOTS + TAB_SLOTS;
 
   __shared__ uint4 lds[LDS_SLOTS];
@@ -150,7 +168,7 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64) ? 3 : 2) void igemm_ker
       p.trace[4ll * orig + 1] = wall_clock64();
     }
   }
-  const int m0 = tm * A_ROWS;
+  const int m0 = EPI == EPI_BNLOCAL ? tm * p.tile_rows : tm * A_ROWS;
   const int n0 = tn * BN;
 
   const long long z = blockIdx.z;
@@ -171,7 +189,10 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64) ? 3 : 2) void igemm_ker
   int hi0[NA], wi0[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    const int m = m0 + rb + RPP * i;
+    int m = m0 + rb + RPP * i;
+    if constexpr (EPI == EPI_BNLOCAL) {
+      if (rb + RPP * i >= p.tile_rows) m = p.M;  // the tile's idle rows
+    }
     if (m < p.M && p.lin_stride >= 0) {
       hi0[i] = 0;
       wi0[i] = 0;
@@ -240,7 +261,7 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64) ? 3 : 2) void igemm_ker
     }
   };
 
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WC, wc = wave % WC;
   const int lr = lane & 31, lh = lane >> 5;
 
   f32x16 acc[2][NT];
@@ -265,8 +286,8 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64) ? 3 : 2) void igemm_ker
 
   const int steps = (p.K + BKE - 1) / BKE;
   if (p.debug & 2) {
-    a_base[0] = a_base[1] = nullptr;
-    if constexpr (NA > 2) a_base[NA - 2] = a_base[NA - 1] = nullptr;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) a_base[i] = nullptr;
 #pragma unroll
     for (int i = 0; i < NB; ++i) b_base[i] = nullptr;
   }
@@ -285,7 +306,7 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64) ? 3 : 2) void igemm_ker
       }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const int row = wc * (BN / 2) + nt * 32 + lr;
+        const int row = wc * WCOLS + nt * 32 + lr;
         fb_off[nt][ks] = (unsigned)((A_ROWS + row) * CPRR + (chunk ^ ((row >> SH) & (CPRR - 1)))) * 16u;
       }
     }
@@ -353,7 +374,7 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64) ? 3 : 2) void igemm_ker
         }
   #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          const int row = wc * (BN / 2) + nt * 32 + lr;
+          const int row = wc * WCOLS + nt * 32 + lr;
           fb[ks][nt] = bbuf[row * CPRR + (chunk ^ ((row >> SH) & (CPRR - 1)))];
         }
       }
@@ -426,7 +447,7 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64) ? 3 : 2) void igemm_ker
       const int g0 = r_first / p.rows_per_group, g1 = r_last / p.rows_per_group;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const int col = n0 + wc * (BN / 2) + nt * 32 + lr;
+        const int col = n0 + wc * WCOLS + nt * 32 + lr;
         if (g0 == g1) {
           float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -466,6 +487,138 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64) ? 3 : 2) void igemm_ker
         }
       }
     }
+  }
+  if constexpr (EPI == EPI_BNLOCAL) {
+    static_assert(EPI != EPI_BNLOCAL || (ES == 2 && WR == 4), "the local BatchNorm epilogue is built on the 256-row bf16 tiles");
+    char* ct = reinterpret_cast<char*>(lds);
+    float* red = reinterpret_cast<float*>(lds);                   // [WR][groups][sum | sumsq][BN], dead before staging
+    float* tab = reinterpret_cast<float*>(ct + CT_SLOTS * 16);    // [groups][scale | shift][BN]
+    const int rpg = p.rows_per_group;
+    const int used = (m0 + p.tile_rows <= p.M ? p.tile_rows : p.M - m0);  // rows of this tile that exist
+    const int ng = used / rpg;                                            // whole groups (M is a multiple of rpg)
+    // 1. zero the per-wave partial sums
+    for (int i = t; i < WR * ng * 2 * BN; i += 256) red[i] = 0.f;
+    __syncthreads();
+    // 2. per-wave masked column sums of the groups this wave's 64 rows touch
+    {
+      const int w_first = wr * 64;
+      if (w_first < used) {
+        const int w_last = (w_first + 63 < used ? w_first + 63 : used - 1);
+        const int k0 = w_first / rpg, k1 = w_last / rpg;
+        for (int k = k0; k <= k1; ++k) {
+          const int lo = k * rpg - w_first - 4 * lh, hi = lo + rpg;   // in units of roff
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+              for (int e = 0; e < 16; ++e) {
+                const int roff = mt * 32 + (e & 3) + 8 * (e >> 2);
+                const float v = (roff >= lo && roff < hi) ? acc[mt][nt][e] : 0.f;
+                s1 += v;
+                s2 = fmaf(v, v, s2);
+              }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lh == 0) {
+              const int cc = wc * WCOLS + nt * 32 + lr;
+              red[((wr * ng + k) * 2 + 0) * BN + cc] = s1;
+              red[((wr * ng + k) * 2 + 1) * BN + cc] = s2;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // 3. folded affine per (group, column): the four row-waves' partial sums added in a fixed order
+    {
+      const float inv_n = 1.f / (float)rpg;
+      for (int i = t; i < ng * BN; i += 256) {
+        const int k = i / BN, cc = i - k * BN;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < WR; ++r) {
+          s1 += red[((r * ng + k) * 2 + 0) * BN + cc];
+          s2 += red[((r * ng + k) * 2 + 1) * BN + cc];
+        }
+        const float mean = s1 * inv_n;
+        const float var = fmaxf(s2 * inv_n - mean * mean, 0.f);
+        const int col = n0 + cc;
+        const float sc = (col < p.N ? p.gamma[col] : 0.f) / sqrtf(var + p.eps);
+        tab[(2 * k) * BN + cc] = sc;
+        tab[(2 * k + 1) * BN + cc] = (col < p.N ? p.beta[col] : 0.f) - mean * sc;
+      }
+    }
+    __syncthreads();
+    // 4. normalise into the bf16 staging tile (which overwrites the partial sums)
+    const bool relu_now = p.act == AVS_ACT_RELU && p.residual == nullptr;
+    {
+      char* cbase = ct + (wr * 64 + 4 * lh) * CT_PITCH + (wc * WCOLS + lr) * 2;
+      const int rel0 = wr * 64 + 4 * lh;        // tile row of roff = 0
+      const int kbase = (wr * 64) / rpg;        // first group of this wave's rows; they span at most three
+      const int b1 = (kbase + 1) * rpg - rel0, b2 = b1 + rpg;
+      const int kmax = ng > 0 ? ng - 1 : 0;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int cc = wc * WCOLS + nt * 32 + lr;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int roff = mt * 32 + (e & 3) + 8 * (e >> 2);
+            int k = kbase + (roff >= b1) + (roff >= b2);
+            k = k < kmax ? k : kmax;            // idle rows: any table entry (never stored)
+            float v = fmaf(acc[mt][nt][e], tab[(2 * k) * BN + cc], tab[(2 * k + 1) * BN + cc]);
+            if (relu_now) v = fmaxf(v, 0.f);
+            *reinterpret_cast<unsigned short*>(cbase + roff * CT_PITCH + nt * 64) = avs_f32_to_bf16(v);
+          }
+      }
+    }
+    __syncthreads();
+    // 5. 16-byte row-major stores (+ residual, + ReLU)
+    {
+      const int srow = t / E_CPRW, sch = t - srow * E_CPRW;
+      const int col = n0 + sch * 8;
+      const bool relu_res = p.act == AVS_ACT_RELU;
+      if (col < p.N) {
+        // every residual row of this thread in flight at once (the accumulators are dead: registers are free),
+        // then the adds and stores: one memory latency per tile instead of one per row
+        uint4 r4[E_NIT];
+        if (p.residual) {
+#pragma unroll
+          for (int it = 0; it < E_NIT; ++it) {
+            const int lrow = srow + it * E_RSTEP;
+            r4[it] = lrow < used ? *reinterpret_cast<const uint4*>(p.residual + ((long long)(m0 + lrow) * p.ldr + col) * 2)
+                                 : make_uint4(0u, 0u, 0u, 0u);
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < E_NIT; ++it) {
+          const int lrow = srow + it * E_RSTEP;
+          if (lrow >= used) break;
+          const long long row = m0 + lrow;
+          uint4 v = *reinterpret_cast<const uint4*>(ct + lrow * CT_PITCH + sch * 16);
+          if (p.residual) {
+            unsigned vv[4] = {v.x, v.y, v.z, v.w};
+            const unsigned rv[4] = {r4[it].x, r4[it].y, r4[it].z, r4[it].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float lo = __uint_as_float(vv[j] << 16) + __uint_as_float(rv[j] << 16);
+              float hi = __uint_as_float(vv[j] & 0xffff0000u) + __uint_as_float(rv[j] & 0xffff0000u);
+              if (relu_res) {
+                lo = fmaxf(lo, 0.f);
+                hi = fmaxf(hi, 0.f);
+              }
+              vv[j] = (unsigned)avs_f32_to_bf16(lo) | ((unsigned)avs_f32_to_bf16(hi) << 16);
+            }
+            v = make_uint4(vv[0], vv[1], vv[2], vv[3]);
+          }
+          *reinterpret_cast<uint4*>(y + (row * p.ldc + col) * 2) = v;
+        }
+      }
+    }
+    return;
   }
   if constexpr (EPI == EPI_BNSYNC) {
     static_assert(EPI != EPI_BNSYNC || ES == 2, "the synchronised BatchNorm epilogue is the bf16 throughput path");
@@ -530,13 +683,13 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64) ? 3 : 2) void igemm_ker
     // 3. normalise the accumulators into the bf16 staging tile (ReLU here when there is no residual)
     const bool relu_now = p.act == AVS_ACT_RELU && p.residual == nullptr;
     {
-      char* cbase = ct + (wr * 64 + 4 * lh) * CT_PITCH + (wc * (BN / 2) + lr) * 2;
+      char* cbase = ct + (wr * 64 + 4 * lh) * CT_PITCH + (wc * WCOLS + lr) * 2;
       const int rel0 = wr * 64 + 4 * lh;                 // tile-relative row of roff = 0
       const int b1 = (g_lo + 1) * rpg - m0 - rel0;       // roff at which the tile's 2nd / 3rd / 4th group starts
       const int b2 = b1 + rpg, b3 = b2 + rpg;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const int cc = wc * (BN / 2) + nt * 32 + lr;
+        const int cc = wc * WCOLS + nt * 32 + lr;
         if (ng == 1) {
           const float sc = tab[cc], sf = tab[BN + cc];
 #pragma unroll
@@ -602,18 +755,18 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64) ? 3 : 2) void igemm_ker
     constexpr int RSTEP = 256 / CPRW;     // tile rows covered by one pass of the 256 threads
     char* ct = reinterpret_cast<char*>(lds);
     {
-      char* cbase = ct + (wr * 64 + 4 * lh) * CT_PITCH + (wc * (BN / 2) + lr) * 2;
+      char* cbase = ct + (wr * 64 + 4 * lh) * CT_PITCH + (wc * WCOLS + lr) * 2;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           float bcol = 0.f;
           if constexpr (EPI == EPI_ANY) {
-            const int col = n0 + wc * (BN / 2) + nt * 32 + lr;
+            const int col = n0 + wc * WCOLS + nt * 32 + lr;
             bcol = (p.bias_mode == AVS_BIAS_COL && col < p.N) ? bias[col] : 0.f;
           }
           if constexpr (EPI == EPI_BRELU) {
-            const int col = n0 + wc * (BN / 2) + nt * 32 + lr;
+            const int col = n0 + wc * WCOLS + nt * 32 + lr;
             bcol = col < p.N ? bias[col] : 0.f;
           }
 #pragma unroll
@@ -665,7 +818,7 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64) ? 3 : 2) void igemm_ker
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const int col = n0 + wc * (BN / 2) + nt * 32 + lr;
+        const int col = n0 + wc * WCOLS + nt * 32 + lr;
         if (col >= p.N) continue;
         float bcol = 0.f;
         if constexpr (EPI == EPI_ANY) bcol = (p.bias_mode == AVS_BIAS_COL) ? bias[col] : 0.f;
@@ -699,35 +852,62 @@ static int g_rowb_threshold_bytes = 2048;  // reductions of at most this many by
 
 extern "C" void avs_tune_short_reduction_bytes(int bytes) { g_rowb_threshold_bytes = bytes; }
 
+// 256-row tiles: 0 = by the rule in igemm_launch, 1 = never, 2 = whenever the variant exists
+static int g_tall_mode = 0;
+static long long g_tall_min_tiles = 2048;   // at least this many 256-row tiles (~4 full waves of workgroups)
+static long long g_tall_min_k_bytes = 1024; // BN = 128: only reductions long enough to be bound by the loop
+extern "C" void avs_tune_tall_tiles(int mode, int64_t min_tiles, int64_t min_k_bytes) {
+  g_tall_mode = mode;
+  if (min_tiles > 0) g_tall_min_tiles = min_tiles;
+  if (min_k_bytes >= 0) g_tall_min_k_bytes = min_k_bytes;
+}
 static int g_pipe3 = 1;  // 1: the 3-buffer hand-counted pipeline for the 64-byte-row variants
 extern "C" void avs_tune_pipeline(int enabled) { g_pipe3 = enabled; }
+
+template <int ES, int BN, bool ACC64, bool SP, int ROWB, bool PIPE, int WR>
+static void igemm_dispatch_epi3(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p, int* occ) {
+  if constexpr (ES == 2 && WR == 2) {
+    if (epi == EPI_BNSYNC) {
+      // occ != nullptr: report how many workgroups of this variant one CU holds instead of launching it
+      if (occ) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                occ, igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BNSYNC, PIPE, WR>, 256, 0) != hipSuccess)
+          *occ = 0;
+      } else {
+        hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BNSYNC, PIPE, WR>), grid, dim3(256), 0, stream,
+                           p);
+      }
+      return;
+    }
+  }
+  if constexpr (ES == 2 && WR == 4) {
+    if (epi == EPI_BNLOCAL) {
+      hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BNLOCAL, PIPE, WR>), grid, dim3(256), 0, stream, p);
+      return;
+    }
+  }
+  if (epi == EPI_PLAIN)
+    hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_PLAIN, PIPE, WR>), grid, dim3(256), 0, stream, p);
+  else if (epi == EPI_STATS)
+    hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE, WR>), grid, dim3(256), 0, stream, p);
+  else if (epi == EPI_BRELU)
+    hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BRELU, PIPE, WR>), grid, dim3(256), 0, stream, p);
+  else if constexpr (WR == 2)
+    hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_ANY, PIPE, WR>), grid, dim3(256), 0, stream, p);
+}
 
 template <int ES, int BN, bool ACC64, bool SP, int ROWB, bool PIPE>
 static void igemm_dispatch_epi2(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p, int* occ) {
   if constexpr (ACC64) {
     hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_ANY, false>), grid, dim3(256), 0, stream, p);
   } else {
-    if constexpr (ES == 2) {
-      if (epi == EPI_BNSYNC) {
-        // occ != nullptr: report how many workgroups of this variant one CU holds instead of launching it
-        if (occ) {
-          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
-                  occ, igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BNSYNC, PIPE>, 256, 0) != hipSuccess)
-            *occ = 0;
-        } else {
-          hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BNSYNC, PIPE>), grid, dim3(256), 0, stream, p);
-        }
+    if constexpr (ES == 2 && ROWB == 64 && PIPE) {
+      if (p.tall) {  // igemm_launch only sets it for the epilogue forms compiled at WR = 4
+        igemm_dispatch_epi3<ES, BN, ACC64, SP, ROWB, PIPE, 4>(epi, grid, stream, p, occ);
         return;
       }
     }
-    if (epi == EPI_PLAIN)
-      hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_PLAIN, PIPE>), grid, dim3(256), 0, stream, p);
-    else if (epi == EPI_STATS)
-      hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE>), grid, dim3(256), 0, stream, p);
-    else if (epi == EPI_BRELU)
-      hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BRELU, PIPE>), grid, dim3(256), 0, stream, p);
-    else
-      hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_ANY, PIPE>), grid, dim3(256), 0, stream, p);
+    igemm_dispatch_epi3<ES, BN, ACC64, SP, ROWB, PIPE, 2>(epi, grid, stream, p, occ);
   }
 }
 
@@ -745,9 +925,11 @@ static void igemm_dispatch_epi(int epi, dim3 grid, hipStream_t stream, const Ige
 template <int ES, int BN, bool ACC64>
 static void igemm_dispatch(bool spatial, dim3 grid, hipStream_t stream, const IgemmParams& p, int* occ = nullptr) {
   const_cast<IgemmParams&>(p).debug = g_debug_flags;
-  const bool short_k = (long long)p.K * ES <= g_rowb_threshold_bytes;
+  const bool short_k = p.tall || (long long)p.K * ES <= g_rowb_threshold_bytes;  // 256-row tiles: 64-byte rows only
   int epi = EPI_ANY;
-  if (p.arrive)
+  if (p.tile_rows)
+    epi = EPI_BNLOCAL;
+  else if (p.arrive)
     epi = EPI_BNSYNC;
   else if (p.bias_mode == AVS_BIAS_NONE && p.act == AVS_ACT_NONE && p.alpha == 1.0f)
     epi = p.stat_sum ? EPI_STATS : EPI_PLAIN;
@@ -790,7 +972,22 @@ static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream
   const bool narrow = p.N <= 64 || dtype == AVS_F32_ACC64;
   const int bn = narrow ? 64 : 128;
   p.tiles_n = (p.N + bn - 1) / bn;
-  const long long tiles_m = ((long long)p.M + 127) / 128;
+  // 256-row tiles (WR = 4): bf16, the compile-time epilogue forms, a reduction of at least three 64-byte steps (the
+  // variants are built on the 3-buffer pipeline), and enough rows that the grid still fills the chip several times
+  p.tall = 0;
+  {
+    const bool fixed_epi = !p.arrive && p.alpha == 1.0f &&
+                           ((p.bias_mode == AVS_BIAS_NONE && p.act == AVS_ACT_NONE) ||
+                            (p.bias_mode == AVS_BIAS_COL && p.act == AVS_ACT_RELU && !p.stat_sum));
+    const bool can = dtype == AVS_BF16 && fixed_epi && g_pipe3 && (long long)p.K * es > 128 && batch == 1;
+    const long long tall_tiles = ((long long)p.M + 255) / 256 * p.tiles_n;
+    if (can && (g_tall_mode == 2 || (g_tall_mode == 0 && tall_tiles >= g_tall_min_tiles &&
+                                     (narrow || (long long)p.K * es >= g_tall_min_k_bytes))))
+      p.tall = 1;
+  }
+  if (p.tile_rows) p.tall = 1;  // EPI_BNLOCAL (validated by bnsync_plan): 256-row tiles at a pitch of tile_rows
+  const int tile_rows = p.tile_rows ? p.tile_rows : (p.tall ? 256 : 128);
+  const long long tiles_m = ((long long)p.M + tile_rows - 1) / tile_rows;
   long long total = tiles_m * p.tiles_n;
   if (p.arrive) {  // EPI_BNSYNC deals eight row tiles per dispatch level: pad the rows of tiles to a multiple of 8
     p.tiles_m = (int)tiles_m;
@@ -901,6 +1098,8 @@ extern "C" int avs_conv2d_nhwc_bnstats(const avs_conv_desc* d, const void* d_x, 
 
 // ---- convolution + whole BatchNorm in one launch (EPI_BNSYNC) ----
 static int g_cu_count = 0;
+static int g_bnlocal = 1;  // 1: groups of <= 256 rows take the tile-local form (EPI_BNLOCAL)
+extern "C" void avs_tune_bnlocal(int enabled) { g_bnlocal = enabled; }
 
 static int bnsync_plan(const avs_conv_desc* d, int64_t rpg, IgemmParams& p, int64_t* ws_bytes, const char* who) {
   int st = conv_fill_params(d, (const void*)16, (const void*)16, nullptr, (void*)16, p, who);
@@ -917,6 +1116,16 @@ static int bnsync_plan(const avs_conv_desc* d, int64_t rpg, IgemmParams& p, int6
   AVS_REQUIRE(shape_ok, AVS_E_UNSUPPORTED,
               "%s: needs bf16, cout a multiple of %d, equal groups of >= 43 rows, 16-byte aligned output rows", who, bn);
   p.tiles_n = p.N / bn;
+  // Groups that fit a 256-row tile whole (and fill >= 3/4 of it): statistics inside the tile, no workspace, no waits
+  {
+    const long long per_tile = 256 / rpg;
+    if (g_bnlocal && g_pipe3 && rpg <= 256 && per_tile * rpg * 4 >= 256 * 3 && per_tile <= BNLOCAL_MAX_GROUPS &&
+        (long long)p.K * 2 > 128) {
+      p.tile_rows = (int)(per_tile * rpg);
+      *ws_bytes = 256;  // nothing is kept there; a non-zero size keeps the caller's bookkeeping uniform
+      return AVS_OK;
+    }
+  }
   // Forward progress: a waiting tile holds its slot, so every tile a wait depends on must get a slot while the
   // waiters sit.  Blocks are dealt round-robin over the XCDs and started in order; one XCD runs one block of every
   // dispatch level.  A tile only waits for tiles of its own column tile whose row tiles lie within the 8-tile
@@ -979,9 +1188,11 @@ extern "C" int avs_conv2d_nhwc_bnsync(const avs_conv_desc* d, const void* d_x, c
   p.w = (const char*)d_w;
   p.y = (char*)d_y;
   const long long groups = p.M / rows_per_group;
-  p.stat_sum = reinterpret_cast<float*>(d_ws_zeroed);
-  p.stat_sq = p.stat_sum + groups * p.N;
-  p.arrive = reinterpret_cast<unsigned*>(p.stat_sq + groups * p.N);
+  if (!p.tile_rows) {  // the synchronised form: statistics and arrival counters in the workspace
+    p.stat_sum = reinterpret_cast<float*>(d_ws_zeroed);
+    p.stat_sq = p.stat_sum + groups * p.N;
+    p.arrive = reinterpret_cast<unsigned*>(p.stat_sq + groups * p.N);
+  }
   p.rows_per_group = (int)rows_per_group;
   p.err = d_err;
   p.gamma = d_gamma;

@@ -113,6 +113,11 @@ int avs_conv2d_nhwc_bnsync(const avs_conv_desc* desc, const void* d_x, const voi
                            int64_t rows_per_group, const float* d_gamma, const float* d_beta, float eps,
                            const void* d_residual, int64_t ldr, void* d_ws_zeroed, int64_t ws_bytes,
                            int* d_err, avs_stream_t stream);
+/* Groups of at most 256 rows that fill >= 3/4 of a 256-row tile (per-frame 14x14 / 7x7 maps) take a tile-LOCAL form
+ * of the same entry point instead: a tile holds whole groups, the statistics are sums over its own accumulators, and
+ * there is no traffic between workgroups at all (no atomics, no waits, deterministic; the workspace is unused).
+ * Tuning knob: 0 switches that form off (every supported shape then takes the synchronised form).              */
+void avs_tune_bnlocal(int enabled);
 /* Tuning knob: time-out of the group wait in ticks of the 100 MHz device wall clock (default 5 000 000 = 50 ms). */
 void avs_tune_bnsync_timeout_ticks(int64_t ticks);
 
@@ -152,6 +157,10 @@ void avs_tune_short_reduction_bytes(int bytes);
 /* Tuning knob: 1 selects the 3-buffer, hand-counted-wait pipeline of the contraction kernel (DMA two steps
  * ahead) for reductions of three or more 64-byte steps.  Default on.                                     */
 void avs_tune_pipeline(int enabled);
+/* Tuning knob: 256-row output tiles of the contraction kernel (bf16, compile-time epilogue forms).  mode 0 = by
+ * rule (at least min_tiles such tiles, and cout <= 64 or a reduction of at least min_k_bytes), 1 = never,
+ * 2 = whenever the variant exists.  min_tiles <= 0 / min_k_bytes < 0 keep the current values.               */
+void avs_tune_tall_tiles(int mode, int64_t min_tiles, int64_t min_k_bytes);
 /* Kernel-study ablation switches for the contraction kernel (0 = production): bit 0 skips the output
  * stores, bit 1 skips the operand loads.  Results are wrong while set; tools/ only.                       */
 void avs_debug_flags(int flags);

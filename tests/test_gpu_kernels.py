@@ -149,6 +149,37 @@ def test_conv2d_bf16(dev, cfg):
     _conv_case(dev, torch.bfloat16, *cfg, tol=1.2e-2)
 
 
+@pytest.mark.parametrize("cfg", [(2, 14, 14, 64, 64, 3, 3, 1, 1), (3, 16, 16, 128, 256, 1, 1, 2, 0),
+                                 (1, 17, 17, 128, 192, 1, 7, 1, (0, 3)), (5, 13, 13, 96, 64, 3, 3, 1, 1),
+                                 (1, 35, 35, 288, 384, 3, 3, 2, 0), (2, 9, 9, 80, 200, 3, 3, 1, 0)])
+def test_conv2d_bf16_tall_tiles(dev, cfg):
+    """The 256-row tile variants (4 x 1 waves) forced on: same results as the 128-row tiles; also with the fused
+    BatchNorm statistics and on a plain (no bias) convolution, ragged last tile included."""
+    from avsum_amd import _abi
+    ops = _ops()
+    L = _abi.lib()
+    try:
+        L.avs_tune_tall_tiles(2, 0, -1)
+        _conv_case(dev, torch.bfloat16, *cfg, tol=1.2e-2)
+        n, h, w, cin, cout, kh, kw, stride, pad = cfg
+        g = torch.Generator().manual_seed(cin + cout)
+        x = torch.randn(n, h, w, cin, generator=g).bfloat16().to(dev)
+        wk = (torch.randn(cout, kh * kw * cin, generator=g) / (kh * kw * cin) ** 0.5).bfloat16().to(dev)
+        ph, pw = pad if isinstance(pad, tuple) else (pad, pad)
+        ho, wo = (h + 2 * ph - kh) // stride + 1, (w + 2 * pw - kw) // stride + 1
+        gamma, beta = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
+        tall = torch.empty((n, ho, wo, cout), dtype=torch.bfloat16, device=dev)
+        sc_t, sh_t = ops.conv2d(x, wk, kh, kw, stride, pad, tall, bnstats=(ho * wo, gamma, beta, 1e-5))
+        L.avs_tune_tall_tiles(1, 0, -1)
+        base = torch.empty_like(tall)
+        sc_b, sh_b = ops.conv2d(x, wk, kh, kw, stride, pad, base, bnstats=(ho * wo, gamma, beta, 1e-5))
+        assert torch.equal(tall, base)          # same products, same k order per output element
+        assert (sc_t - sc_b).abs().max().item() < 2e-3 * sc_b.abs().max().item()
+        assert (sh_t - sh_b).abs().max().item() < 2e-3 * max(1.0, sh_b.abs().max().item())
+    finally:
+        L.avs_tune_tall_tiles(0, 0, -1)
+
+
 def test_conv2d_channel_slice_output(dev):
     ops = _ops()
     g = torch.Generator().manual_seed(3)

@@ -323,13 +323,32 @@ _SYNC_CASES = [
     (8, 28, 256, 512, 1, 2, 2, False, False),   # strided downsample, no ReLU
     (5, 14, 1024, 256, 1, 1, 5, False, True),   # ONE group for the whole call (980 rows)
     (64, 56, 64, 256, 1, 1, 4, True, True),     # the reference's 4-frame micro-batches, 200k rows: many tiles waiting
+    # groups that fit a 256-row tile whole -> the tile-local form (no traffic between workgroups) when it is on
+    (11, 14, 256, 1024, 1, 1, 1, True, True),   # 196 rows: one group per tile
+    (11, 14, 256, 256, 3, 1, 1, False, True),   # 3x3 taps, 196-row groups
+    (7, 14, 1024, 256, 1, 1, 1, False, False),  # long reduction
+    (13, 8, 128, 128, 3, 1, 1, True, True),     # 64-row groups: four per tile, the tile exactly full
+    (6, 10, 64, 64, 1, 1, 1, False, True),      # 100-row groups: two per tile; 64-wide tile
+    (9, 7, 2048, 512, 1, 1, 1, False, True),    # 49-row groups: five per tile, last tile 4 groups
+    (8, 7, 512, 512, 3, 2, 4, False, True),     # stride 2 to 4x4 maps, 4-frame groups of 64 rows
 ]
 
 
+@pytest.mark.parametrize("local", [1, 0])
 @pytest.mark.parametrize("cfg", _SYNC_CASES)
-def test_conv_bnsync_one_launch(dev, cfg):
-    """Convolution + whole batch-statistics BatchNorm (+residual, +ReLU) in one launch (tiles wait for their group's
-    statistics) against the same arithmetic in fp32 on the bf16-rounded operands, and against the split HIP path."""
+def test_conv_bnsync_one_launch(dev, cfg, local):
+    """Convolution + whole batch-statistics BatchNorm (+residual, +ReLU) in one launch - tiles that wait for their
+    group's statistics, or (local = 1, groups of <= 256 rows) tiles that hold whole groups - against the same arithmetic
+    in fp32 on the bf16-rounded operands, and against the split HIP path."""
+    from avsum_amd import _abi, ops
+    _abi.lib().avs_tune_bnlocal(local)
+    try:
+        _bnsync_case(dev, cfg)
+    finally:
+        _abi.lib().avs_tune_bnlocal(1)
+
+
+def _bnsync_case(dev, cfg):
     from avsum_amd import ops
     frames, hw, cin, cout, k, s, gf, with_res, relu = cfg
     g = torch.Generator().manual_seed(sum(cfg[:6]))
@@ -391,12 +410,15 @@ def test_conv_bnsync_declines_and_times_out_loudly(dev):
     plain.bn_sync = False
     want = plain.forward(frames).cpu()
     runner = ResNet50Runner(trunk, torch.bfloat16)
+    runner.sync_max_group_rows = 1 << 30                # the waiting form on every layer the library takes
     try:
+        _abi.lib().avs_tune_bnlocal(0)
         _abi.lib().avs_tune_bnsync_timeout_ticks(-1)   # every wait that is not already satisfied times out
         with pytest.warns(UserWarning, match="timed out"):
             got = runner.forward(frames).cpu()
     finally:
         _abi.lib().avs_tune_bnsync_timeout_ticks(5000000)
+        _abi.lib().avs_tune_bnlocal(1)
     # (statistics summed by float atomics: two runs of the split path agree to bf16 rounding noise, not bit for bit)
     assert runner.bn_sync is False and ((got - want).norm() / want.norm()).item() < 0.05
 

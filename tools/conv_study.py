@@ -8,6 +8,7 @@ from avsum_amd import ops, _abi
 dev = torch.device("cuda", 0)
 L = _abi.lib()
 shapes = [  # name, n, hw, cin, cout, k, stride
+    ("stem-like 3x3 32->64 s2", 1024, 112, 32, 64, 3, 2),
     ("l1.conv3 1x1 64->256", 1024, 56, 64, 256, 1, 1),
     ("l1.conv1 1x1 256->64", 1024, 56, 256, 64, 1, 1),
     ("l1.conv2 3x3 64->64", 1024, 56, 64, 64, 3, 1),
@@ -28,11 +29,12 @@ for name, n, hw, cin, cout, k, s in shapes:
     flops = 2.0 * n * ho * ho * cout * k * k * cin
     byts = (x.numel() + y.numel() + w.numel()) * 2
     line = f"{name:26s}"
-    for tag, flags, rowb, pipe in (("base", 0, 100000, 0), ("pipe3", 0, 100000, 1), ("rowb128", 0, 0, 0),
-                                   ("nostore", 1, 100000, 0), ("noload128", 2, 0, 0), ("noload64p", 2, 100000, 1)):
+    for tag, flags, rowb, pipe, tall in (("pipe3", 0, 100000, 1, 1), ("rowb128", 0, 0, 1, 1), ("tall", 0, 2048, 1, 2),
+                                         ("tall-noload", 2, 2048, 1, 2), ("tall-nostore", 1, 2048, 1, 2)):
         L.avs_debug_flags(flags)
         L.avs_tune_short_reduction_bytes(rowb)
         L.avs_tune_pipeline(pipe)
+        L.avs_tune_tall_tiles(tall, 0, -1)
         for _ in range(2):
             ops.conv2d(x, w, k, k, s, k // 2, y)
         torch.cuda.synchronize()
@@ -46,4 +48,6 @@ for name, n, hw, cin, cout, k, s in shapes:
         line += f" | {tag} {us:7.1f}us {flops / us / 1e6:6.0f}TF {byts / us / 1e6:5.2f}TB/s"
     print(line, flush=True)
 L.avs_debug_flags(0)
-L.avs_tune_pipeline(0)
+L.avs_tune_pipeline(1)
+L.avs_tune_tall_tiles(0, 0, -1)
+L.avs_tune_short_reduction_bytes(2048)
