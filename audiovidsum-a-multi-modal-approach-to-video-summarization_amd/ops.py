@@ -24,10 +24,25 @@ def _stream():
 
 class LaunchProfiler:
     """Optional per-launch HIP-event timing of the contraction kernel (bench.py's roofline leg):
-    events are recorded on the stream the kernel is launched on, read back after a synchronize."""
+    events are recorded on the stream the kernel is launched on, read back after a synchronize.
+    ``count_only`` just counts the launches it would time (to size the event pool before a timed region:
+    creating events is the expensive part, so they are made up front and only recorded inside it)."""
 
-    def __init__(self):
+    def __init__(self, count_only=False, prealloc=0, sample_every=1):
+        """sample_every = n: bracket every n-th launch of each kind only (an event pair is a barrier between kernels:
+        timing EVERY launch costs the pipeline ~3 %); all launches are still counted."""
         self.records = []  # (kind, dtype_code, algorithmic work: FLOPs for conv/gemm, bytes for bn_apply, start, end)
+        self.count_only = count_only
+        self.count = 0
+        self.sample_every = max(1, int(sample_every))
+        self.seen = {}     # (kind, dtype) -> launches seen (timed or not)
+        self._pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                      for _ in range(prealloc)]
+
+    def events(self):
+        if self._pool:
+            return self._pool.pop()
+        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def summary(self):
         torch.cuda.synchronize()
@@ -51,8 +66,14 @@ def set_profiler(p):
 def _timed(kind, dtype, flops, fn):
     if _profiler is None:
         return fn()
-    s = torch.cuda.Event(enable_timing=True)
-    e = torch.cuda.Event(enable_timing=True)
+    if _profiler.count_only:
+        _profiler.count += 1
+        return fn()
+    seen = _profiler.seen.get((kind, dtype), 0)
+    _profiler.seen[(kind, dtype)] = seen + 1
+    if seen % _profiler.sample_every:
+        return fn()
+    s, e = _profiler.events()
     s.record()
     r = fn()
     e.record()

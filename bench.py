@@ -99,12 +99,16 @@ def main():
     ap.add_argument("--mean-frames", type=int, default=1800)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--extractor", default="resnet50", choices=["resnet50", "resnet50+inception3"])
-    ap.add_argument("--chunk", type=int, default=1024)
+    ap.add_argument("--chunk", type=int, default=12288,
+                    help="frames per pass of the trunk (activations of one pass: ~60 GB of the 288 GB at 12288)")
     ap.add_argument("--cpu-sample", type=int, default=512, help="frames for the CPU baseline (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--profile-every", type=int, default=3,
+                    help="bracket every n-th launch of each kernel kind with HIP events (1 = all: ~3%% slower)")
     ap.add_argument("--bn-sync", default="auto", choices=["auto", "on", "off"],
                     help="tuning: one-launch convolution + BatchNorm (auto = the runner's per-layer choice)")
     ap.add_argument("--short-k-bytes", type=int, default=None, help="tuning: avs_tune_short_reduction_bytes")
+    ap.add_argument("--tall", default=None, help="tuning: mode[,min_tiles[,min_k_bytes]] of avs_tune_tall_tiles")
     ap.add_argument("--fuse", default=None, help="tuning: min_rows,ratio_num,ratio_den of the one-kernel conv+BN")
     args = ap.parse_args()
 
@@ -116,6 +120,10 @@ def main():
     if args.short_k_bytes is not None:
         from avsum_amd import _abi
         _abi.lib().avs_tune_short_reduction_bytes(args.short_k_bytes)
+    if args.tall is not None:
+        from avsum_amd import _abi
+        tv = [int(v) for v in args.tall.split(",")] + [0, -1]
+        _abi.lib().avs_tune_tall_tiles(tv[0], tv[1], tv[2])
     rank, world, local = avd.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
@@ -169,13 +177,22 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    counter = ops.LaunchProfiler(count_only=True)
+    per_step = 0
     for i in range(args.warmup):
+        counter.count = 0
+        ops.set_profiler(counter)
         step()
+        ops.set_profiler(None)
+        per_step = counter.count
         torch.cuda.synchronize()
         log(f"warmup step {i} done")
     prof = None
     if not args.no_profile:
-        prof = ops.LaunchProfiler()
+        # the HIP events of the timed launches are created here, outside the timed region (creation is the costly
+        # part); inside it they are only recorded, on the stream the kernels are launched on
+        prof = ops.LaunchProfiler(prealloc=per_step * args.steps // args.profile_every + 64,
+                                   sample_every=args.profile_every)
         ops.set_profiler(prof)
     barrier()
     t0 = time.perf_counter()
@@ -211,24 +228,29 @@ def main():
                         traffic = json.load(open(PMC_TRAFFIC_FILE)).get("igemm_kernel", {}).get("hbm_bytes_per_launch")
                     except (OSError, ValueError):
                         traffic = None
-                roofline = {"bound": "mfma", "kernel": "igemm_kernel (avs_conv2d_nhwc[_bnstats])",
+                roofline = {"bound": "mfma", "kernel": "igemm_kernel (avs_conv2d_nhwc[_bnstats|_bnsync])",
                             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                             "frac": round(achieved / peak, 4), "traffic": traffic,
-                            "launches": conv["launches"],
+                            "launches": prof.seen.get(("conv", code), conv["launches"]),
+                            "timed_launches": conv["launches"],
                             "avg_launch_us": round(conv["ms"] * 1e3 / conv["launches"], 2),
                             "algorithmic_flop_per_launch": round(conv["flops"] / conv["launches"], 1),
-                            "share_of_step": round(conv["ms"] * 1e-3 / elapsed, 3)}
+                            "share_of_step": round(conv["ms"] * 1e-3 / elapsed *
+                                                   prof.seen.get(("conv", code), conv["launches"]) / conv["launches"], 3)}
             others = []
-            for kind, label in (("convbn", "conv1x1_bn_kernel (avs_conv1x1_bn_bf16)"),
-                                ("bn_apply", "bn_apply_kernel (avs_bn_apply)")):
+            for kind, label in (("convbn", "conv1x1_bn_kernel (avs_conv1x1_bn[_in]_bf16)"),
+                                ("bn_apply", "bn_apply_kernel / bn_maxpool_kernel (avs_bn_apply, avs_bn_maxpool_nhwc)")):
                 rec = summ.get((kind, code))
                 if rec and rec["ms"] > 0:
                     gbs = rec["flops"] / (rec["ms"] * 1e-3) / 1e9
                     others.append({"bound": "hbm", "kernel": label, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-                                   "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "launches": rec["launches"],
+                                   "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                   "launches": prof.seen.get((kind, code), rec["launches"]),
+                                   "timed_launches": rec["launches"],
                                    "avg_launch_us": round(rec["ms"] * 1e3 / rec["launches"], 2),
                                    "algorithmic_bytes_per_launch": round(rec["flops"] / rec["launches"], 1),
-                                   "share_of_step": round(rec["ms"] * 1e-3 / elapsed, 3)})
+                                   "share_of_step": round(rec["ms"] * 1e-3 / elapsed *
+                                                          prof.seen.get((kind, code), rec["launches"]) / rec["launches"], 3)})
             if roofline is not None and others:
                 roofline["other_kernels"] = others
         cpu = None
