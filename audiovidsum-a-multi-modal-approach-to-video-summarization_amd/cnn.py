@@ -229,7 +229,8 @@ class ResNet50Runner:
         y2d = y.view(-1, cout)
 
         def conv(**kw):
-            return ops.conv2d_raw(dcode, *geom, x, *xs, wt, wt.stride(0), y, cout, algo_k=algo_k, **kw)
+            return ops.conv2d_raw(dcode, *geom, x, *xs, wt, wt.stride(0), y, cout, algo_k=algo_k,
+                                  algo_in_elems=x.numel() if algo_k is not None else None, **kw)
 
         def pooled(t):
             k, s, p = pool
@@ -600,7 +601,7 @@ class InceptionV3Runner:
         c = w["Conv2d_1a_3x3"]
         x = torch.empty((n, 149, 149, 32), dtype=dt, device=dev)
         ops.conv2d_raw(ops.dtype_code(dt), n, 299, 149, 16, 3, 1, 2, 1, 0, 0, 149, 149, 32, x0, 299 * 300 * 4, 300 * 4, 8,
-                       c["w"], c["w"].stride(0), x, 32, c["b"], ops.ACT_RELU, algo_k=27)
+                       c["w"], c["w"].stride(0), x, 32, c["b"], ops.ACT_RELU, algo_k=27, algo_in_elems=x0.numel())
         del x0
         x = self._conv(w, "Conv2d_2a_3x3", x)
         x = self._conv(w, "Conv2d_2b_3x3", x)

@@ -31,7 +31,7 @@ class LaunchProfiler:
     def __init__(self, count_only=False, prealloc=0, sample_every=1):
         """sample_every = n: bracket every n-th launch of each kind only (an event pair is a barrier between kernels:
         timing EVERY launch costs the pipeline ~3 %); all launches are still counted."""
-        self.records = []  # (kind, dtype_code, algorithmic work: FLOPs for conv/gemm, bytes for bn_apply, start, end)
+        self.records = []  # (kind, dtype_code, algorithmic FLOPs (bytes for the HBM-bound kinds), algorithmic bytes, start, end)
         self.count_only = count_only
         self.count = 0
         self.sample_every = max(1, int(sample_every))
@@ -47,10 +47,11 @@ class LaunchProfiler:
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for kind, dt, flops, s, e in self.records:
-            d = out.setdefault((kind, dt), {"launches": 0, "flops": 0.0, "ms": 0.0})
+        for kind, dt, flops, nbytes, s, e in self.records:
+            d = out.setdefault((kind, dt), {"launches": 0, "flops": 0.0, "bytes": 0.0, "ms": 0.0})
             d["launches"] += 1
             d["flops"] += flops
+            d["bytes"] += nbytes
             d["ms"] += s.elapsed_time(e)
         return out
 
@@ -63,7 +64,7 @@ def set_profiler(p):
     _profiler = p
 
 
-def _timed(kind, dtype, flops, fn):
+def _timed(kind, dtype, flops, fn, nbytes=0.0):
     if _profiler is None:
         return fn()
     if _profiler.count_only:
@@ -77,7 +78,7 @@ def _timed(kind, dtype, flops, fn):
     s.record()
     r = fn()
     e.record()
-    _profiler.records.append((kind, dtype, float(flops), s, e))
+    _profiler.records.append((kind, dtype, float(flops), float(nbytes), s, e))
     return r
 
 
@@ -164,8 +165,9 @@ def conv_bnsync_workspace_bytes(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho,
 
 def conv2d_raw(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x, x_img_stride, x_row_stride, x_px_stride,
                wt, w_row_stride, y, y_px_stride, bias=None, act=ACT_NONE, alpha=1.0, x_off=0, y_off=0, algo_k=None,
-               bnstats=None, bnsync=None):
-    """algo_k: the algorithmic reduction length when it differs from kh*kw*cin (zero-padded stem rows).
+               bnstats=None, bnsync=None, algo_in_elems=None):
+    """algo_k: the algorithmic reduction length when it differs from kh*kw*cin (zero-padded stem rows);
+    algo_in_elems: input elements the launch reads when the geometry does not say (the re-viewed stem image).
     bnstats = (rows_per_group, gamma, beta, eps): accumulate the BatchNorm batch statistics of equal-sized row
     groups in the kernel's epilogue (no bias / activation) and return the folded (scale, shift) [G, cout].
     bnsync = (rows_per_group, gamma, beta, eps, residual2d | None, workspace uint8 (ZEROED), err int32[1]):
@@ -174,6 +176,11 @@ def conv2d_raw(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x, x_i
     d = _abi.ConvDesc(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x_img_stride, x_row_stride,
                       x_px_stride, w_row_stride, y_px_stride, act, float(alpha))
     flops = 2.0 * n * ho * wo * cout * (algo_k if algo_k is not None else kh * kw * cin)
+    # algorithmic HBM bytes: the input map read once (the pixels a strided 1x1 skips are not needed), the output
+    # written once (+ the residual read once); weights are negligible and L2-resident
+    es = 2 if dtype == AVS_BF16 else 4
+    touched = algo_in_elems if algo_in_elems is not None else n * (ho * wo if (kh == 1 and kw == 1) else h * w) * cin
+    cbytes = float(es) * (touched + n * ho * wo * cout)
     if bnsync is not None:
         rpg, gamma, beta, eps, residual, ws, err = bnsync
         _dev(gamma, beta, residual, ws, err)
@@ -189,12 +196,13 @@ def conv2d_raw(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x, x_i
             lib().avs_conv2d_nhwc_bnsync(ctypes.byref(d), _p(x, x_off), _p(wt), _p(y, y_off), int(rpg), _p(gamma),
                                          _p(beta), float(eps), _p(residual),
                                          residual.stride(0) if residual is not None else 0, _p(ws), ws.numel(),
-                                         _p(err), _stream()), "avs_conv2d_nhwc_bnsync"))
+                                         _p(err), _stream()), "avs_conv2d_nhwc_bnsync"),
+               cbytes + (float(es) * n * ho * wo * cout if residual is not None else 0.0))
         return None
     if bnstats is None:
         _timed("conv", dtype, flops, lambda: check(
             lib().avs_conv2d_nhwc(ctypes.byref(d), _p(x, x_off), _p(wt), _p(bias), _p(y, y_off), _stream()),
-            "avs_conv2d_nhwc"))
+            "avs_conv2d_nhwc"), cbytes)
         return None
     rpg, gamma, beta, eps = bnstats
     if bias is not None or act != ACT_NONE:
@@ -205,7 +213,7 @@ def conv2d_raw(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x, x_i
     ssq = torch.empty((groups, cout), dtype=torch.float32, device=x.device)
     _timed("conv", dtype, flops, lambda: check(
         lib().avs_conv2d_nhwc_bnstats(ctypes.byref(d), _p(x, x_off), _p(wt), _p(y, y_off), rpg, _p(ssum), _p(ssq),
-                                      _stream()), "avs_conv2d_nhwc_bnstats"))
+                                      _stream()), "avs_conv2d_nhwc_bnstats"), cbytes)
     scale = torch.empty((groups, cout), dtype=torch.float32, device=x.device)
     shift = torch.empty((groups, cout), dtype=torch.float32, device=x.device)
     check(lib().avs_bn_finalize(_p(ssum), _p(ssq), groups, cout, rpg, _p(gamma), _p(beta), float(eps), _p(scale),

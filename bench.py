@@ -34,7 +34,7 @@ if ROOT not in sys.path:
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_F32_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_d_pmc_traffic.json")
 RESNET50_FLOP_PER_FRAME = 2 * 4.0878e9
 
 
@@ -103,7 +103,7 @@ def main():
                     help="frames per pass of the trunk (activations of one pass: ~60 GB of the 288 GB at 12288)")
     ap.add_argument("--cpu-sample", type=int, default=512, help="frames for the CPU baseline (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--profile-every", type=int, default=3,
+    ap.add_argument("--profile-every", type=int, default=1,
                     help="bracket every n-th launch of each kernel kind with HIP events (1 = all: ~3%% slower)")
     ap.add_argument("--bn-sync", default="auto", choices=["auto", "on", "off"],
                     help="tuning: one-launch convolution + BatchNorm (auto = the runner's per-layer choice)")
@@ -235,6 +235,7 @@ def main():
                             "timed_launches": conv["launches"],
                             "avg_launch_us": round(conv["ms"] * 1e3 / conv["launches"], 2),
                             "algorithmic_flop_per_launch": round(conv["flops"] / conv["launches"], 1),
+                            "algorithmic_bytes_per_launch": round(conv["bytes"] / conv["launches"], 1),
                             "share_of_step": round(conv["ms"] * 1e-3 / elapsed *
                                                    prof.seen.get(("conv", code), conv["launches"]) / conv["launches"], 3)}
             others = []
