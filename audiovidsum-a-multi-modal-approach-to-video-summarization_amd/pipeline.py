@@ -34,26 +34,61 @@ class FrameScoringPipeline:
                 offs.append(cur)
         return offs
 
+    def _uniform_sets(self, video_offsets):
+        """Frames partitioned into sets of EQUAL-sized BatchNorm groups (the fast kernels want one group size per
+        pass): [(group size, frame indices | (start, end) when contiguous)].  With frames_per_group = g a video of
+        L frames gives L // g full groups and, when g does not divide L, one last group of L % g frames
+        (extractors.py:52-56: the last micro-batch of a shot is simply shorter); the full groups of all videos form
+        one set, the tails of each size another."""
+        gf = self.frames_per_group
+        offs = np.asarray(video_offsets, dtype=np.int64)
+        n = int(offs[-1])
+        if n == 0:
+            return []
+        if gf == 1:
+            return [(1, (0, n))]
+        lens = offs[1:] - offs[:-1]
+        rem = lens % gf
+        if not rem.any():
+            return [(gf, (0, n))]
+        full_end = offs[:-1] + (lens - rem)
+        sets = []
+        full = np.concatenate([np.arange(a, e) for a, e in zip(offs[:-1], full_end) if e > a] or [np.zeros(0, np.int64)])
+        if full.size:
+            sets.append((gf, full))
+        for r in range(1, gf):
+            tails = [np.arange(e, b) for e, b, q in zip(full_end, offs[1:], rem) if q == r]
+            if tails:
+                sets.append((r, np.concatenate(tails)))
+        return sets
+
     def embed(self, frames_u8, video_offsets, check=True):
         """uint8 [N,224,224,3] on device -> fp32 [N,4096] (ResNet-50 | Inception-v3 halves).
         check=False leaves the time-out poll of the one-launch convolution + BatchNorm (a host sync) to the caller."""
         n = frames_u8.shape[0]
-        visual = torch.zeros((n, 4096), dtype=torch.float32, device=frames_u8.device)
-        groups = self._group_offsets(video_offsets)
-        gi = 0
-        while gi < len(groups) - 1:
-            start = groups[gi]
-            gj = gi + 1
-            while gj < len(groups) - 1 and groups[gj + 1] - start <= self.chunk_frames:
-                gj += 1
-            end = groups[gj]
-            chunk = frames_u8[start:end]
-            local = [g - start for g in groups[gi:gj + 1]]
-            self.visual._resnet_runner.forward(chunk, local, out=visual[start:end, :2048], check=False)
-            if self.use_inception:
-                big = ops.resize_bilinear(chunk, 299, 299)
-                self.visual._inception_runner.forward(big, out=visual[start:end, 2048:])
-            gi = gj
+        dev = frames_u8.device
+        visual = torch.zeros((n, 4096), dtype=torch.float32, device=dev)
+        for gsz, where in self._uniform_sets(video_offsets):
+            per_pass = max(gsz, self.chunk_frames // gsz * gsz)
+            contiguous = isinstance(where, tuple)
+            lo, hi = where if contiguous else (0, len(where))
+            for a in range(lo, hi, per_pass):
+                b = min(a + per_pass, hi)
+                if contiguous:
+                    chunk, out = frames_u8[a:b], visual[a:b]
+                else:
+                    idx = torch.from_numpy(where[a:b]).to(dev)
+                    chunk = frames_u8.index_select(0, idx)     # memory plumbing: gather the pass's frames
+                    out = torch.empty((b - a, 4096), dtype=torch.float32, device=dev)
+                    if not self.use_inception:
+                        out[:, 2048:].zero_()
+                groups = torch.arange(0, b - a + 1, gsz, dtype=torch.int64)
+                self.visual._resnet_runner.forward(chunk, groups, out=out[:, :2048], check=False)
+                if self.use_inception:
+                    big = ops.resize_bilinear(chunk, 299, 299)
+                    self.visual._inception_runner.forward(big, out=out[:, 2048:])
+                if not contiguous:
+                    visual.index_copy_(0, idx, out)
         if check and self._sync_timed_out():
             return self.embed(frames_u8, video_offsets, check)
         return visual

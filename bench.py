@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=12288,
                     help="frames per pass of the trunk (activations of one pass: ~60 GB of the 288 GB at 12288)")
     ap.add_argument("--cpu-sample", type=int, default=512, help="frames for the CPU baseline (0 = skip)")
+    ap.add_argument("--frames-per-group", type=int, default=1,
+                    help="BatchNorm micro-batch inside a video: 1 = every frame its own shot (the per-frame scoring "
+                         "reading of north_star, default); 4 = the reference's micro-batches of 4 (extractors.py:48)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--profile-every", type=int, default=1,
                     help="bracket every n-th launch of each kernel kind with HIP events (1 = all: ~3%% slower)")
@@ -164,7 +167,7 @@ def main():
     torch.cuda.synchronize()
     log("frames ready")
     pipe = FrameScoringPipeline(extractor, scorer, use_inception=use_inception, chunk_frames=args.chunk,
-                                frames_per_group=1)
+                                frames_per_group=args.frames_per_group)
 
     def step():
         scores = pipe.score(frames, offsets)
@@ -273,7 +276,8 @@ def main():
             "data": "synthetic (uniform uint8 frames, seeded random-init weights; audio = literal zeros(296))",
             "config": {"workload": f"configs[1]: SumMe-shape batch, {args.videos} videos x ~{args.mean_frames} frames "
                                    f"({total} frames/GPU), visual-only {args.extractor} extractor (batch-stat BN, "
-                                   f"per-frame shots) + AVBiLSTM attention scorer + mean-threshold selection",
+                                   f"{'per-frame shots' if args.frames_per_group == 1 else str(args.frames_per_group) + '-frame micro-batches'}) "
+                                   f"+ AVBiLSTM attention scorer + mean-threshold selection",
                        "frames_per_gpu": total, "videos_per_gpu": args.videos, "extractor": args.extractor,
                        "chunk_frames": args.chunk, "parallelism": f"videos sharded x{world}, no data-path collective",
                        "selected_frames_rank0": int(sum(len(s) for s in selected))},

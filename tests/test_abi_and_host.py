@@ -100,6 +100,28 @@ def test_pipeline_group_offsets():
     assert p1._group_offsets([0, 3]) == [0, 1, 2, 3]
 
 
+def test_pipeline_uniform_sets_partition_the_frames():
+    """Ragged micro-batches (a video whose length is not a multiple of the group size) are split into sets of
+    equal-sized groups that together cover every frame exactly once and never mix videos inside a group."""
+    from avsum_amd.pipeline import FrameScoringPipeline
+    p = FrameScoringPipeline(None, None, frames_per_group=4)
+    offs = [0, 6, 6, 15, 23, 24]                  # lengths 6, 0, 9, 8, 1
+    sets = p._uniform_sets(offs)
+    assert [g for g, _ in sets] == [4, 1, 2]
+    cover = np.concatenate([np.arange(*w) if isinstance(w, tuple) else w for _, w in sets])
+    assert sorted(cover.tolist()) == list(range(24))
+    ref_groups = p._group_offsets(offs)
+    ref = {tuple(range(a, b)) for a, b in zip(ref_groups[:-1], ref_groups[1:])}
+    got = set()
+    for g, w in sets:
+        idx = np.arange(*w) if isinstance(w, tuple) else w
+        got |= {tuple(idx[i:i + g].tolist()) for i in range(0, len(idx), g)}
+    assert got == ref                              # the same groups the per-video rule makes
+    assert p._uniform_sets([0, 8, 16]) == [(4, (0, 16))]
+    assert FrameScoringPipeline(None, None, frames_per_group=1)._uniform_sets([0, 5, 9]) == [(1, (0, 9))]
+    assert p._uniform_sets([0, 0]) == []
+
+
 def test_audio_constants_match_oracle_formulas():
     from avsum_amd.audio import dct_matrix, mel_filterbank, windowed_dft_basis
     from oracle import audio as oa

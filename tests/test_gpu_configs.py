@@ -116,6 +116,23 @@ def test_batch_and_chunk_invariance_fp32(dev):
     assert [len(s) for s in sel] and all((np.diff(s) > 0).all() for s in sel if len(s) > 1)  # sorted indices
 
 
+def test_ragged_micro_batches_fp32(dev):
+    """frames_per_group = 4 on videos whose lengths are not multiples of 4: the pipeline's equal-size sets (full
+    groups gathered across videos, tails per size) give every frame the features of ITS group - identical, in the
+    deterministic fp32 mode, to one pass over explicitly ragged groups."""
+    from avsum_amd.features.extractors import VisualFeatureExtractor
+    from avsum_amd.pipeline import FrameScoringPipeline
+    torch.manual_seed(63)
+    ext = VisualFeatureExtractor(torch.float32, "batch").to(dev)
+    rng = np.random.default_rng(6)
+    frames = torch.from_numpy(rng.integers(0, 256, (14, 224, 224, 3), dtype=np.uint8)).to(dev)
+    offsets = [0, 6, 11, 14]                       # groups 4+2 | 4+1 | 3
+    pipe = FrameScoringPipeline(ext, None, use_inception=False, chunk_frames=8, frames_per_group=4)
+    got = pipe.embed(frames, offsets)[:, :2048].cpu()
+    want = ext._resnet_runner.forward(frames, pipe._group_offsets(offsets)).cpu()
+    assert torch.equal(got, want)
+
+
 def test_bf16_batch_invariance_is_close(dev):
     """Same property in the bf16 throughput mode: the fused-statistics float atomics reorder sums, so equality is
     to bf16 noise, not bitwise."""
