@@ -56,6 +56,7 @@ _SIGNATURES = {
     "avs_tune_short_reduction_bytes": (None, [c_int]),
     "avs_debug_flags": (None, [c_int]),
     "avs_tune_pipeline": (None, [c_int]),
+    "avs_tune_fast_staging": (None, [c_int]),
     "avs_tune_tall_tiles": (None, [c_int, c_int64, c_int64]),
     "avs_tune_convbn_narrow": (None, [c_int]),
     "avs_gemm_nt": (c_int, [c_int, c_int, c_int, c_int, P, c_int64, c_int64, P, c_int64, c_int64, P, c_int64,

@@ -117,7 +117,12 @@ __device__ __forceinline__ uint4 avs_lds_read_b128(unsigned byte_addr) {
 // WR: rows of waves.  2 = the 128 x BN tile (2 x 2 waves of 64 x BN/2); 4 = a 256 x BN tile (4 x 1 waves of 64 x BN):
 // twice the matrix work per barrier and 0.75 (BN = 128) instead of 1 fragment read per MFMA, for layers with many
 // rows whose cost is the loop itself (the N = 64 layers run 4 MFMAs per wave between barriers at WR = 2).
-template <int ES, int BN, bool ACC64, bool SPATIAL, int ROWB, int EPI, bool PIPE, int WR = 2>
+// FASTK: cin is a multiple of one reduction step (and there are at most 32 taps), so a step never straddles a tap:
+// the tap walk (kh, kw, ci) is the same for every thread - kept in scalar registers and advanced by additions -
+// a row's padding test is one bit of a per-row tap mask built once, and a DMA source is base + scalar offset.
+// (Measured on the 3x3 layers: the general staging code issues ~180 vector + scalar instructions per 16 MFMAs and
+// the loop ran at 45 % matrix-core occupancy for that reason alone - with no staging at all it reaches 1.5 PFLOP/s.)
+template <int ES, int BN, bool ACC64, bool SPATIAL, int ROWB, int EPI, bool PIPE, int WR = 2, bool FASTK = false>
 __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? 3 : 2) void igemm_kernel(
     IgemmParams p) {
   static_assert(WR == 2 || (WR == 4 && ES == 2 && !ACC64), "256-row tiles are built for the bf16 variants");
@@ -179,7 +184,9 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? 3 : 2) voi
   const char* zsrc = reinterpret_cast<const char*>(avs_zero16);
 
   const int t = threadIdx.x;
-  const int wave = t >> 6, lane = t & 63;
+  // the wave index is uniform: say so, and every address built from it (LDS-DMA destinations, tile quadrants)
+  // stays in scalar registers
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
   const int c = t & (CPRR - 1);
   const int rb = t / CPRR;                          // 0..RPP-1
   const int cq = c ^ ((rb >> SH) & (CPRR - 1));     // the k-chunk this thread fetches into slot c
@@ -219,15 +226,110 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? 3 : 2) voi
     b_base[i] = n < p.N ? w + (long long)n * p.ldb * ES : nullptr;
   }
 
+  if (p.debug & 2) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) a_base[i] = nullptr;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) b_base[i] = nullptr;
+  }
   int kc = cq * CE;
   int kk = kc / p.cin;
   int ci = kc - kk * p.cin;
   int kh = kk / p.KW;
   int kw = kk - kh * p.KW;
 
+  // ---- FASTK state: per-row tap masks and 32-bit buffer offsets (vector), the tap walk (scalar) ----
+  // Operands are fetched with buffer_load_dwordx4 ... lds: address = resource base (SGPRs) + per-lane offset (one
+  // VGPR, fixed for the whole reduction) + scalar offset (the tap walk / the k step).  A lane whose tap falls into
+  // the padding (or whose row does not exist) presents an offset beyond num_records and the hardware returns
+  // zeros, so staging costs no vector arithmetic per step beyond that select.  The A base is moved back by the
+  // padding so that every row's own offset is non-negative; the launcher guarantees a tile's rows and the tap walk
+  // stay inside the 2 GiB window.
+  constexpr unsigned BUF_OOB = 0x80000000u;
+  unsigned amask[FASTK ? NA : 1];
+  unsigned aoff[FASTK ? NA : 1], boff[FASTK ? NB : 1];
+  int f_tap = 0, f_ci0 = 0, f_kw = 0;
+  int f_koff = 0;   // bytes: the current tap + channel block relative to a row's first tap
+  int f_kb = 0;     // bytes: the current k step inside a B row
+  __amdgpu_buffer_rsrc_t a_rsrc, b_rsrc;
+  if constexpr (FASTK) {
+    const int taps = p.K / p.cin;
+    // uniform tile origin: the first image the tile touches (or its first row on the linear-row path)
+    long long a_origin;
+    int n_first = 0;
+    if (p.lin_stride >= 0) {
+      a_origin = (long long)m0 * p.lin_stride;
+    } else {
+      n_first = m0 / p.HoWo;
+      a_origin = (long long)n_first * p.x_img_stride - (long long)p.ph * p.x_row_stride - (long long)p.pw * p.x_px_stride;
+    }
+    a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(x) + a_origin * ES, 0, (int)BUF_OOB, 0x00020000);
+    b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(w) + (long long)n0 * p.ldb * ES, 0, (int)BUF_OOB,
+                                               0x00020000);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      unsigned mk = 0, off = BUF_OOB;
+      int m = m0 + rb + RPP * i;
+      if constexpr (EPI == EPI_BNLOCAL) {
+        if (rb + RPP * i >= p.tile_rows) m = p.M;
+      }
+      if (a_base[i] != nullptr && m < p.M) {
+        if (p.lin_stride >= 0) {
+          mk = ~0u;
+          off = (unsigned)((long long)(m - m0) * p.lin_stride * ES) + cq * 16;
+        } else {
+          const int n = m / p.HoWo;
+          if constexpr (SPATIAL) {
+            for (int tp = 0; tp < taps; ++tp) {
+              const int th = tp / p.KW, tw = tp - th * p.KW;
+              if ((unsigned)(hi0[i] + th) < (unsigned)p.H && (unsigned)(wi0[i] + tw) < (unsigned)p.W) mk |= 1u << tp;
+            }
+          } else {
+            mk = ~0u;
+          }
+          off = (unsigned)(((long long)(n - n_first) * p.x_img_stride + (long long)(hi0[i] + p.ph) * p.x_row_stride +
+                            (long long)(wi0[i] + p.pw) * p.x_px_stride) * ES) + cq * 16;
+        }
+      }
+      amask[i] = mk;
+      aoff[i] = off;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      boff[i] = b_base[i] != nullptr ? (unsigned)((long long)(rb + RPP * i) * p.ldb * ES) + cq * 16 : BUF_OOB;
+  }
+
   auto stage = [&](int buf) {
+    if (p.debug & 8) return;  // kernel study: no staging at all (the loop runs on whatever the LDS holds)
     uint4* abuf = lds + buf * BUF + wave * 64;        // wave-uniform; lane l lands at +l
     uint4* bbuf = abuf + A_ROWS * CPRR;
+    if constexpr (FASTK) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        unsigned off = aoff[i];
+        if constexpr (SPATIAL) off = ((amask[i] >> f_tap) & 1u) ? off : BUF_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(abuf + 256 * i), 16,
+                                                 (int)off, f_koff, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (__attribute__((address_space(3))) void*)(bbuf + 256 * i), 16,
+                                                 (int)boff[i], f_kb, 0, 0);
+      f_kb += BKE * ES;
+      // next step (scalar): the same tap's next channel block, or the next tap
+      f_ci0 += BKE;
+      f_koff += BKE * ES;
+      if (f_ci0 == p.cin) {
+        f_ci0 = 0;
+        ++f_tap;
+        f_koff += (int)((p.x_px_stride - p.cin) * ES);
+        if (++f_kw == p.KW) {
+          f_kw = 0;
+          f_koff += (int)((p.x_row_stride - (long long)p.KW * p.x_px_stride) * ES);
+        }
+      }
+      return;
+    }
     const bool kval = kc < p.K;
     const long long koff = ((long long)kh * p.x_row_stride + (long long)kw * p.x_px_stride + ci) * ES;
 #pragma unroll
@@ -285,12 +387,6 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? 3 : 2) voi
   }
 
   const int steps = (p.K + BKE - 1) / BKE;
-  if (p.debug & 2) {
-#pragma unroll
-    for (int i = 0; i < NA; ++i) a_base[i] = nullptr;
-#pragma unroll
-    for (int i = 0; i < NB; ++i) b_base[i] = nullptr;
-  }
   if constexpr (PIPE) {
     constexpr int NDMA = NA + NB;  // DMA instructions one stage() issues per wave
     const unsigned lds_base = (unsigned)(unsigned long long)((__attribute__((address_space(3))) char*)lds);
@@ -864,17 +960,17 @@ extern "C" void avs_tune_tall_tiles(int mode, int64_t min_tiles, int64_t min_k_b
 static int g_pipe3 = 1;  // 1: the 3-buffer hand-counted pipeline for the 64-byte-row variants
 extern "C" void avs_tune_pipeline(int enabled) { g_pipe3 = enabled; }
 
-template <int ES, int BN, bool ACC64, bool SP, int ROWB, bool PIPE, int WR>
-static void igemm_dispatch_epi3(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p, int* occ) {
+template <int ES, int BN, bool ACC64, bool SP, int ROWB, bool PIPE, int WR, bool FK>
+static void igemm_dispatch_epi4(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p, int* occ) {
   if constexpr (ES == 2 && WR == 2) {
     if (epi == EPI_BNSYNC) {
       // occ != nullptr: report how many workgroups of this variant one CU holds instead of launching it
       if (occ) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
-                occ, igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BNSYNC, PIPE, WR>, 256, 0) != hipSuccess)
+                occ, igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BNSYNC, PIPE, WR, FK>, 256, 0) != hipSuccess)
           *occ = 0;
       } else {
-        hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BNSYNC, PIPE, WR>), grid, dim3(256), 0, stream,
+        hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BNSYNC, PIPE, WR, FK>), grid, dim3(256), 0, stream,
                            p);
       }
       return;
@@ -882,18 +978,40 @@ static void igemm_dispatch_epi3(int epi, dim3 grid, hipStream_t stream, const Ig
   }
   if constexpr (ES == 2 && WR == 4) {
     if (epi == EPI_BNLOCAL) {
-      hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BNLOCAL, PIPE, WR>), grid, dim3(256), 0, stream, p);
+      hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BNLOCAL, PIPE, WR, FK>), grid, dim3(256), 0, stream, p);
       return;
     }
   }
   if (epi == EPI_PLAIN)
-    hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_PLAIN, PIPE, WR>), grid, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_PLAIN, PIPE, WR, FK>), grid, dim3(256), 0, stream, p);
   else if (epi == EPI_STATS)
-    hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE, WR>), grid, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE, WR, FK>), grid, dim3(256), 0, stream, p);
   else if (epi == EPI_BRELU)
-    hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BRELU, PIPE, WR>), grid, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BRELU, PIPE, WR, FK>), grid, dim3(256), 0, stream, p);
   else if constexpr (WR == 2)
-    hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_ANY, PIPE, WR>), grid, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_ANY, PIPE, WR, FK>), grid, dim3(256), 0, stream, p);
+}
+
+static int g_fastk = 1;  // 1: the scalar tap-walk staging where the shape allows it
+extern "C" void avs_tune_fast_staging(int enabled) { g_fastk = enabled; }
+
+template <int ES, int BN, bool ACC64, bool SP, int ROWB, bool PIPE, int WR>
+static void igemm_dispatch_epi3(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p, int* occ) {
+  constexpr int BKE = ROWB / ES;
+  // the buffer window: a tile's rows (at most 256, spread over whole images) plus the tap walk must stay below 2 GiB
+  const long long rows = 256;
+  long long extent;
+  if (p.lin_stride >= 0)
+    extent = rows * p.lin_stride + p.K;
+  else
+    extent = (rows / p.HoWo + 2) * p.x_img_stride + (long long)(p.K / (p.cin * p.KW) + p.ph) * p.x_row_stride +
+             (long long)(p.KW + p.pw) * p.x_px_stride + p.cin;
+  const bool window_ok = extent * ES < (1ll << 31) && (long long)BN * p.ldb * ES + (long long)p.K * ES < (1ll << 31) &&
+                         p.x_img_stride >= 0 && p.x_row_stride >= 0 && p.x_px_stride >= 0;
+  if (g_fastk && window_ok && p.cin % BKE == 0 && p.K % BKE == 0 && p.K / p.cin <= 32 && p.K % p.cin == 0)
+    igemm_dispatch_epi4<ES, BN, ACC64, SP, ROWB, PIPE, WR, true>(epi, grid, stream, p, occ);
+  else
+    igemm_dispatch_epi4<ES, BN, ACC64, SP, ROWB, PIPE, WR, false>(epi, grid, stream, p, occ);
 }
 
 template <int ES, int BN, bool ACC64, bool SP, int ROWB, bool PIPE>

@@ -161,6 +161,10 @@ void avs_tune_pipeline(int enabled);
  * rule (at least min_tiles such tiles, and cout <= 64 or a reduction of at least min_k_bytes), 1 = never,
  * 2 = whenever the variant exists.  min_tiles <= 0 / min_k_bytes < 0 keep the current values.               */
 void avs_tune_tall_tiles(int mode, int64_t min_tiles, int64_t min_k_bytes);
+/* Tuning knob: 0 switches off the scalar tap-walk operand staging of the contraction kernel (taken when cin is a
+ * multiple of one reduction step and the kernel has at most 32 taps); the general staging code then serves every
+ * shape.  Default on.                                                                                        */
+void avs_tune_fast_staging(int enabled);
 /* Kernel-study ablation switches for the contraction kernel (0 = production): bit 0 skips the output
  * stores, bit 1 skips the operand loads.  Results are wrong while set; tools/ only.                       */
 void avs_debug_flags(int flags);

@@ -3,8 +3,12 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from avsum_amd import ops
+from avsum_amd import ops, _abi
 n, hw, cin, cout, k = [int(v) for v in sys.argv[1:6]]
+if len(sys.argv) > 6:      # optional: debug flags (avs_debug_flags), tall mode
+    _abi.lib().avs_debug_flags(int(sys.argv[6]))
+if len(sys.argv) > 7:
+    _abi.lib().avs_tune_tall_tiles(int(sys.argv[7]), 0, -1)
 dev = torch.device("cuda", 0)
 dt = torch.bfloat16
 x = torch.randn(n, hw, hw, cin, device=dev).to(dt)
