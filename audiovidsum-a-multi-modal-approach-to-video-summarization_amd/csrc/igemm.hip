@@ -601,8 +601,9 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? 3 : 2) voi
       if (w_first < used) {
         const int w_last = (w_first + 63 < used ? w_first + 63 : used - 1);
         const int k0 = w_first / rpg, k1 = w_last / rpg;
-        for (int k = k0; k <= k1; ++k) {
-          const int lo = k * rpg - w_first - 4 * lh, hi = lo + rpg;   // in units of roff
+        if (k0 == k1) {
+          // the wave's 64 rows lie in one group (always so for groups of >= 64 rows that divide the tile evenly):
+          // plain column sums - rows past `used` hold exact zeros
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
             float s1 = 0.f, s2 = 0.f;
@@ -610,8 +611,7 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? 3 : 2) voi
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
               for (int e = 0; e < 16; ++e) {
-                const int roff = mt * 32 + (e & 3) + 8 * (e >> 2);
-                const float v = (roff >= lo && roff < hi) ? acc[mt][nt][e] : 0.f;
+                const float v = acc[mt][nt][e];
                 s1 += v;
                 s2 = fmaf(v, v, s2);
               }
@@ -619,8 +619,32 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? 3 : 2) voi
             s2 += __shfl_xor(s2, 32, 64);
             if (lh == 0) {
               const int cc = wc * WCOLS + nt * 32 + lr;
-              red[((wr * ng + k) * 2 + 0) * BN + cc] = s1;
-              red[((wr * ng + k) * 2 + 1) * BN + cc] = s2;
+              red[((wr * ng + k0) * 2 + 0) * BN + cc] = s1;
+              red[((wr * ng + k0) * 2 + 1) * BN + cc] = s2;
+            }
+          }
+        } else {
+          for (int k = k0; k <= k1; ++k) {
+            const int lo = k * rpg - w_first - 4 * lh, hi = lo + rpg;   // in units of roff
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+              for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                  const int roff = mt * 32 + (e & 3) + 8 * (e >> 2);
+                  const float v = (roff >= lo && roff < hi) ? acc[mt][nt][e] : 0.f;
+                  s1 += v;
+                  s2 = fmaf(v, v, s2);
+                }
+              s1 += __shfl_xor(s1, 32, 64);
+              s2 += __shfl_xor(s2, 32, 64);
+              if (lh == 0) {
+                const int cc = wc * WCOLS + nt * 32 + lr;
+                red[((wr * ng + k) * 2 + 0) * BN + cc] = s1;
+                red[((wr * ng + k) * 2 + 1) * BN + cc] = s2;
+              }
             }
           }
         }
@@ -652,23 +676,48 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? 3 : 2) voi
     {
       char* cbase = ct + (wr * 64 + 4 * lh) * CT_PITCH + (wc * WCOLS + lr) * 2;
       const int rel0 = wr * 64 + 4 * lh;        // tile row of roff = 0
-      const int kbase = (wr * 64) / rpg;        // first group of this wave's rows; they span at most three
-      const int b1 = (kbase + 1) * rpg - rel0, b2 = b1 + rpg;
       const int kmax = ng > 0 ? ng - 1 : 0;
+      const int kbase = (wr * 64) / rpg < kmax ? (wr * 64) / rpg : kmax;   // first group of this wave's rows
+      const int klast = (wr * 64 + 63) / rpg < kmax ? (wr * 64 + 63) / rpg : kmax;
+      if (kbase == klast) {
+        // one group for the whole wave: the affine of a column is two registers
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int cc = wc * WCOLS + nt * 32 + lr;
+        for (int nt = 0; nt < NT; ++nt) {
+          const int cc = wc * WCOLS + nt * 32 + lr;
+          const float sc = tab[(2 * kbase) * BN + cc], sf = tab[(2 * kbase + 1) * BN + cc];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+          for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int roff = mt * 32 + (e & 3) + 8 * (e >> 2);
-            int k = kbase + (roff >= b1) + (roff >= b2);
-            k = k < kmax ? k : kmax;            // idle rows: any table entry (never stored)
-            float v = fmaf(acc[mt][nt][e], tab[(2 * k) * BN + cc], tab[(2 * k + 1) * BN + cc]);
-            if (relu_now) v = fmaxf(v, 0.f);
-            *reinterpret_cast<unsigned short*>(cbase + roff * CT_PITCH + nt * 64) = avs_f32_to_bf16(v);
-          }
+            for (int e = 0; e < 16; ++e) {
+              const int roff = mt * 32 + (e & 3) + 8 * (e >> 2);
+              float v = fmaf(acc[mt][nt][e], sc, sf);
+              if (relu_now) v = fmaxf(v, 0.f);
+              *reinterpret_cast<unsigned short*>(cbase + roff * CT_PITCH + nt * 64) = avs_f32_to_bf16(v);
+            }
+        }
+      } else {
+        // up to three groups in the wave's 64 rows: their affines in registers, chosen per row by two compares
+        const int b1 = (kbase + 1) * rpg - rel0, b2 = b1 + rpg;
+        const int kb1 = kbase + 1 < kmax ? kbase + 1 : kmax, kb2 = kbase + 2 < kmax ? kbase + 2 : kmax;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int cc = wc * WCOLS + nt * 32 + lr;
+          const float sc0 = tab[(2 * kbase) * BN + cc], sf0 = tab[(2 * kbase + 1) * BN + cc];
+          const float sc1 = tab[(2 * kb1) * BN + cc], sf1 = tab[(2 * kb1 + 1) * BN + cc];
+          const float sc2 = tab[(2 * kb2) * BN + cc], sf2 = tab[(2 * kb2 + 1) * BN + cc];
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int roff = mt * 32 + (e & 3) + 8 * (e >> 2);
+              const bool g1 = roff >= b1, g2 = roff >= b2;
+              const float sc = g2 ? sc2 : (g1 ? sc1 : sc0);
+              const float sf = g2 ? sf2 : (g1 ? sf1 : sf0);
+              float v = fmaf(acc[mt][nt][e], sc, sf);
+              if (relu_now) v = fmaxf(v, 0.f);
+              *reinterpret_cast<unsigned short*>(cbase + roff * CT_PITCH + nt * 64) = avs_f32_to_bf16(v);
+            }
+        }
       }
     }
     __syncthreads();
