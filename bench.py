@@ -34,7 +34,7 @@ if ROOT not in sys.path:
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_F32_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_d_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_e_pmc_traffic.json")
 RESNET50_FLOP_PER_FRAME = 2 * 4.0878e9
 
 
