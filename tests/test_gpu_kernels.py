@@ -441,6 +441,38 @@ def test_bn_maxpool_is_bn_apply_then_pool(dev, dtype):
     assert (want.float().cpu() - ref).abs().max().item() < (1e-5 if dtype == torch.float32 else 0.05)
 
 
+def test_empty_and_degenerate_inputs(dev):
+    """Zero-size calls of the newer entry points return cleanly (the reference's own edge: an empty shot gives
+    zeros(4096), extractors.py:44-45; an empty clip zeros(296), :197-198)."""
+    ops = _ops()
+    from avsum_amd.audio import resample_to
+    from avsum_amd.features.extractors import AudioFeatureExtractor, VisualFeatureExtractor
+    from avsum_amd.features.shots import detect_shots
+    from avsum_amd.vggish import VGGish
+    bf = torch.bfloat16
+    code = ops.dtype_code(bf)
+    # no frames at all
+    x = torch.empty((0, 14, 14, 64), dtype=bf, device=dev)
+    y = torch.empty((0, 7, 7, 64), dtype=bf, device=dev)
+    sc = torch.ones((1, 64), device=dev)
+    assert ops.bn_maxpool(x, sc, sc, None, True, 3, 2, 1, y).shape == (0, 7, 7, 64)
+    geom, xs = (0, 14, 14, 64, 1, 1, 1, 1, 0, 0, 14, 14, 64), (14 * 14 * 64, 14 * 64, 64)
+    assert ops.conv_bnsync_workspace_bytes(code, *geom, *xs, 64, 64, 196) == 0
+    ws = torch.zeros(256, dtype=torch.uint8, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    w = torch.zeros((64, 64), dtype=bf, device=dev)
+    ops.conv2d_raw(code, *geom, x, *xs, w, 64, torch.empty((0, 14, 14, 64), dtype=bf, device=dev), 64,
+                   bnsync=(196, sc[0], sc[0], 1e-5, None, ws, err))
+    assert err.item() == 0
+    assert ops.hsv_frame_diff(torch.empty((0, 8, 8, 3), dtype=torch.uint8, device=dev)).shape == (0, 3)
+    assert detect_shots(torch.zeros((1, 8, 8, 3), dtype=torch.uint8, device=dev)) == []
+    assert resample_to(torch.zeros(0, device=dev), 48000, 16000).shape == (0,)
+    assert ops.quantize(torch.zeros(0, device=dev), -2, 2, 63.75).shape == (0,)
+    assert VGGish()(np.zeros(100, np.float32), 16000).shape == (0, 128)
+    assert np.array_equal(VisualFeatureExtractor(bf)([]), np.zeros(4096, np.float32))
+    assert np.array_equal(AudioFeatureExtractor()(np.zeros(0, np.float32)), np.zeros(296, np.float32))
+
+
 def _synthetic_video(n, h, w, cut_at, seed):
     """Slowly drifting noise scenes with abrupt content changes at `cut_at`."""
     rng = np.random.default_rng(seed)
