@@ -90,11 +90,13 @@ def gather_video_scores(local_scores, local_video_ids, local_lengths, num_videos
         return out
     world = dist.get_world_size()
     dev = local_scores.device
-    meta = torch.full((num_videos, 2), -1, dtype=torch.int64, device=dev)  # (video id, length) per slot
-    for k, (vid, ln) in enumerate(zip(local_video_ids, local_lengths)):
-        meta[k, 0], meta[k, 1] = vid, ln
+    # (video id, length) per slot, built on the host and moved once; one host read-back of all ranks' tables
+    rows = [[int(v), int(n)] for v, n in zip(local_video_ids, local_lengths)]
+    rows += [[-1, -1]] * (num_videos - len(rows))
+    meta = torch.tensor(rows, dtype=torch.int64).reshape(num_videos, 2).to(dev)
     metas = [torch.empty_like(meta) for _ in range(world)]
     dist.all_gather(metas, meta)
+    metas = list(torch.stack(metas).cpu())
     totals = [int(m[:, 1].clamp(min=0).sum()) for m in metas]
     pad = max(max(totals), 1)
     buf = torch.zeros(pad, dtype=local_scores.dtype, device=dev)
