@@ -8,6 +8,11 @@ import ctypes
 import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_uint, c_void_p
 
+# torch first: its HIP runtime (torch/lib/libamdhip64) must be the one this process initialises.  Loading
+# libavsum_hip.so before torch pulls in /opt/rocm's copy of the same SONAME instead, and the second runtime to come
+# up then reports "no ROCm-capable device".
+import torch  # noqa: F401  (memory, streams and the HIP runtime come from here)
+
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "lib", "libavsum_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "avsum_hip.h")
