@@ -92,6 +92,19 @@ def test_extractor_containers_have_torchvision_keys():
     assert t.training and not i.training  # only the Inception net is put in eval mode
 
 
+def test_binding_brings_up_torchs_hip_runtime_first():
+    """One HIP runtime per process: the binding must import torch before it dlopens libavsum_hip.so (which links
+    /opt/rocm's libamdhip64 of the same SONAME); in the other order the second runtime finds no device - seen as
+    build() followed by smoke() in one process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import avsum_amd._abi as a; assert 'torch' in sys.modules; "
+            "a.lib(); print('ok')" % root)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-500:]
+
+
 def test_pipeline_group_offsets():
     from avsum_amd.pipeline import FrameScoringPipeline
     p = FrameScoringPipeline(None, None, frames_per_group=4)
