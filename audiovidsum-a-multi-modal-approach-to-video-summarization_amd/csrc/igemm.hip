@@ -415,7 +415,6 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? 3 : 2) voi
       else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (s + 2 < steps) stage(cur == 0 ? 2 : cur - 1);  // (s+2) % 3 == (cur + 2) % 3
       const unsigned bbase = lds_base + (unsigned)cur * (BUF * 16u);
       uint4 fa[KS][2], fb[KS][NT];
 #pragma unroll
@@ -425,10 +424,17 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? 3 : 2) voi
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) fb[ks][nt] = avs_lds_read_b128(bbase + fb_off[nt][ks]);
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
+      // the DMA of step s+2 is issued while the fragment reads are in flight; the MFMAs of the first half-step
+      // start as soon as ITS fragments have landed (LDS reads return in order; a scalar load in between can only
+      // make the counted wait more conservative)
+      if (s + 2 < steps) stage(cur == 0 ? 2 : cur - 1);  // (s+2) % 3 == (cur + 2) % 3
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS)
+          asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((KS - 1) * (2 + NT)) : "memory");
+        else
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -446,6 +452,8 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? 3 : 2) voi
               acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[mt][nt], 0, 0, 0);
             }
           }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       cur = cur == 2 ? 0 : cur + 1;
     }
     __syncthreads();  // every wave is done with the operand buffers before the epilogue reuses the LDS
