@@ -180,6 +180,35 @@ def test_conv2d_bf16_tall_tiles(dev, cfg):
         L.avs_tune_tall_tiles(0, 0, -1)
 
 
+def test_conv2d_seeded_shape_sweep(dev):
+    """Seeded sweep over convolution shapes against torch: channel counts on both sides of the fast-staging rule
+    (cin a multiple of one reduction step or not), 1..49 taps (more than 32 taps use the general staging), strides,
+    asymmetric kernels / padding, ragged tiles, both dtypes, with and without the 256-row tiles."""
+    from avsum_amd import _abi
+    L = _abi.lib()
+    rng = np.random.default_rng(20261004)
+    kernels = [(1, 1), (3, 3), (5, 5), (7, 7), (1, 7), (7, 1), (3, 1), (2, 2)]
+    cases = []
+    for _ in range(36):
+        kh, kw = kernels[rng.integers(len(kernels))]
+        stride = int(rng.integers(1, 3))
+        ph, pw = int(rng.integers(0, kh // 2 + 1)), int(rng.integers(0, kw // 2 + 1))
+        h, w = int(rng.integers(max(kh, 5), 23)), int(rng.integers(max(kw, 5), 23))
+        cin = int(rng.choice([8, 16, 24, 32, 48, 64, 96, 128, 160]))
+        cout = int(rng.choice([8, 24, 64, 72, 128, 136, 200, 256]))
+        n = int(rng.integers(1, 6))
+        cases.append((n, h, w, cin, cout, kh, kw, stride, (ph, pw)))
+    try:
+        for i, cfg in enumerate(cases):
+            dtype, tol = (torch.bfloat16, 1.2e-2) if i % 3 else (torch.float32, 2e-5)
+            L.avs_tune_tall_tiles(2 if i % 2 else 1, 0, -1)
+            L.avs_tune_fast_staging(0 if i % 5 == 4 else 1)
+            _conv_case(dev, dtype, *cfg, tol=tol)
+    finally:
+        L.avs_tune_tall_tiles(0, 0, -1)
+        L.avs_tune_fast_staging(1)
+
+
 def test_conv2d_channel_slice_output(dev):
     ops = _ops()
     g = torch.Generator().manual_seed(3)
