@@ -147,3 +147,30 @@ def test_bf16_batch_invariance_is_close(dev):
     a = FrameScoringPipeline(ext, model, use_inception=False, chunk_frames=1024).score(frames, [0, 4, 9]).cpu()
     b = FrameScoringPipeline(ext, model, use_inception=False, chunk_frames=3).score(frames, [0, 4, 9]).cpu()
     assert (a - b).abs().max().item() < 2e-3
+
+
+def test_bench_contract_line(dev):
+    """bench.py on a tiny instance of configs[1]: exactly one JSON line on stdout with the fields the driver reads,
+    the roofline measured live (HIP events) and the CPU-baseline leg."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--videos", "2", "--mean-frames", "24",
+                          "--chunk", "16", "--steps", "1", "--warmup", "1", "--cpu-sample", "4"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-800:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["steps"] == 1 and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "bf16" and d["value"] > 0 and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["launches"] > 0 and r["avg_launch_us"] > 0 and r["algorithmic_bytes_per_launch"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "frames/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
