@@ -1014,6 +1014,8 @@ extern "C" void avs_tune_tall_tiles(int mode, int64_t min_tiles, int64_t min_k_b
   if (min_tiles > 0) g_tall_min_tiles = min_tiles;
   if (min_k_bytes >= 0) g_tall_min_k_bytes = min_k_bytes;
 }
+static int g_fastk = 1;  // 1: the scalar tap-walk staging where the shape allows it
+extern "C" void avs_tune_fast_staging(int enabled) { g_fastk = enabled; }
 static int g_pipe3 = 1;  // 1: the 3-buffer hand-counted pipeline for the 64-byte-row variants
 extern "C" void avs_tune_pipeline(int enabled) { g_pipe3 = enabled; }
 
@@ -1049,8 +1051,6 @@ static void igemm_dispatch_epi4(int epi, dim3 grid, hipStream_t stream, const Ig
     hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_ANY, PIPE, WR, FK>), grid, dim3(256), 0, stream, p);
 }
 
-static int g_fastk = 1;  // 1: the scalar tap-walk staging where the shape allows it
-extern "C" void avs_tune_fast_staging(int enabled) { g_fastk = enabled; }
 
 template <int ES, int BN, bool ACC64, bool SP, int ROWB, bool PIPE, int WR>
 static void igemm_dispatch_epi3(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p, int* occ) {
@@ -1100,7 +1100,10 @@ static void igemm_dispatch_epi(int epi, dim3 grid, hipStream_t stream, const Ige
 template <int ES, int BN, bool ACC64>
 static void igemm_dispatch(bool spatial, dim3 grid, hipStream_t stream, const IgemmParams& p, int* occ = nullptr) {
   const_cast<IgemmParams&>(p).debug = g_debug_flags;
-  const bool short_k = p.tall || (long long)p.K * ES <= g_rowb_threshold_bytes;  // 256-row tiles: 64-byte rows only
+  // 64-byte rows: short reductions, the 256-row tiles, and shapes whose channel count fits the scalar tap walk only
+  // at the 64-byte step (cin = 96, 160, 288 ... of Inception-v3): the cheaper staging is worth more than the longer step
+  const bool fast64_only = g_fastk && p.cin % (64 / ES) == 0 && p.cin % (128 / ES) != 0 && p.K / p.cin <= 32;
+  const bool short_k = p.tall || fast64_only || (long long)p.K * ES <= g_rowb_threshold_bytes;
   int epi = EPI_ANY;
   if (p.tile_rows)
     epi = EPI_BNLOCAL;
