@@ -257,78 +257,6 @@ extern "C" int avs_bn_batch_stats(int dtype, const void* d_x, int64_t rows, int 
   return AVS_OK;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, int c, long long ldx,
-                                                       const int64_t* __restrict__ group_rows, long long rows,
-                                                       const float* __restrict__ scale, const float* __restrict__ shift,
-                                                       const T* __restrict__ res, long long ldr, int act,
-                                                       T* __restrict__ y, long long ldy) {
-  const int cv = c >> 2;
-  long long r0 = 0, r1 = rows;
-  long long g = 0;
-  if (group_rows) {
-    g = blockIdx.y;
-    r0 = group_rows[g];
-    r1 = group_rows[g + 1];
-  }
-  const long long total = (r1 - r0) * cv;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const long long row = r0 + i / cv;
-    const int ch = (int)(i % cv) * 4;
-    float v[4], sc[4], sf[4];
-    load4<T>(x + row * ldx + ch, v);
-    load4<float>(scale + g * c + ch, sc);
-    load4<float>(shift + g * c + ch, sf);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = v[j] * sc[j] + sf[j];
-    if (res) {
-      float rv[4];
-      load4<T>(res + row * ldr + ch, rv);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] += rv[j];
-    }
-    if (act == AVS_ACT_RELU) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-    }
-    store4<T>(y + row * ldy + ch, v);
-  }
-}
-
-extern "C" int avs_bn_apply(int dtype, const void* d_x, int64_t rows, int c, int64_t ldx, const int64_t* d_group_rows,
-                            int groups, int64_t max_group_rows, const float* d_scale, const float* d_shift,
-                            const void* d_residual, int64_t ldr, int act, void* d_y, int64_t ldy,
-                            avs_stream_t stream) {
-  AVS_REQUIRE(dtype == AVS_F32 || dtype == AVS_BF16, AVS_E_ARG, "avs_bn_apply: bad dtype");
-  AVS_REQUIRE(rows >= 0 && c > 0 && c % 4 == 0 && ldx >= c && ldx % 4 == 0 && ldy >= c && ldy % 4 == 0 &&
-                  (!d_residual || (ldr >= c && ldr % 4 == 0)),
-              AVS_E_SHAPE, "avs_bn_apply: rows=%lld c=%d ldx=%lld ldy=%lld ldr=%lld", (long long)rows, c,
-              (long long)ldx, (long long)ldy, (long long)ldr);
-  AVS_REQUIRE((groups > 0) == (d_group_rows != nullptr), AVS_E_ARG, "avs_bn_apply: groups and d_group_rows disagree");
-  if (rows == 0) return AVS_OK;
-  AVS_REQUIRE(d_x && d_scale && d_shift && d_y, AVS_E_ARG, "avs_bn_apply: null pointer");
-  const long long span = (groups > 0 ? max_group_rows : rows) * (c >> 2);
-  AVS_REQUIRE(span > 0, AVS_E_SHAPE, "avs_bn_apply: max_group_rows must be > 0");
-  long long gx = avs_cdiv(span, 256);
-  if (gx > 8192) gx = 8192;
-  dim3 grid((unsigned)gx, groups > 0 ? groups : 1);
-  AVS_REQUIRE(grid.y <= 65535, AVS_E_SHAPE, "avs_bn_apply: more than 65535 groups in one call");
-  if (dtype == AVS_F32)
-    hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)d_x, c,
-                       (long long)ldx, d_group_rows, (long long)rows, d_scale, d_shift, (const float*)d_residual,
-                       (long long)ldr, act, (float*)d_y, (long long)ldy);
-  else
-    hipLaunchKernelGGL(bn_apply_kernel<avs_bf16_tag>, grid, dim3(256), 0, (hipStream_t)stream,
-                       (const avs_bf16_tag*)d_x, c, (long long)ldx, d_group_rows, (long long)rows, d_scale, d_shift,
-                       (const avs_bf16_tag*)d_residual, (long long)ldr, act, (avs_bf16_tag*)d_y, (long long)ldy);
-  AVS_CHECK_LAUNCH("avs_bn_apply");
-  return AVS_OK;
-}
-
-// ---------------------------------------------------------------------------
-// Pooling on NHWC
-// ---------------------------------------------------------------------------
 // 16 bytes of channels per thread (4 fp32 / 8 bf16) whenever the channel count allows; the taps of
 // neighbouring outputs overlap, so most loads are L2 hits and the kernel is bound by load issue.
 template <typename T, int V>
@@ -360,6 +288,88 @@ __device__ __forceinline__ void storev(T* p, const float (&v)[V]) {
   }
 }
 
+// V elements (4, or 8 = 16 bytes of bf16) per thread
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, int c, long long ldx,
+                                                       const int64_t* __restrict__ group_rows, long long rows,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       const T* __restrict__ res, long long ldr, int act,
+                                                       T* __restrict__ y, long long ldy) {
+  const int cv = c / V;
+  long long r0 = 0, r1 = rows;
+  long long g = 0;
+  if (group_rows) {
+    g = blockIdx.y;
+    r0 = group_rows[g];
+    r1 = group_rows[g + 1];
+  }
+  const long long total = (r1 - r0) * cv;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long row = r0 + i / cv;
+    const int ch = (int)(i % cv) * V;
+    float v[V], sc[V], sf[V];
+    loadv<T, V>(x + row * ldx + ch, v);
+#pragma unroll
+    for (int q = 0; q < V; q += 4) {
+      load4<float>(scale + g * c + ch + q, reinterpret_cast<float(&)[4]>(sc[q]));
+      load4<float>(shift + g * c + ch + q, reinterpret_cast<float(&)[4]>(sf[q]));
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) v[j] = v[j] * sc[j] + sf[j];
+    if (res) {
+      float rv[V];
+      loadv<T, V>(res + row * ldr + ch, rv);
+#pragma unroll
+      for (int j = 0; j < V; ++j) v[j] += rv[j];
+    }
+    if (act == AVS_ACT_RELU) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) v[j] = fmaxf(v[j], 0.f);
+    }
+    storev<T, V>(y + row * ldy + ch, v);
+  }
+}
+
+extern "C" int avs_bn_apply(int dtype, const void* d_x, int64_t rows, int c, int64_t ldx, const int64_t* d_group_rows,
+                            int groups, int64_t max_group_rows, const float* d_scale, const float* d_shift,
+                            const void* d_residual, int64_t ldr, int act, void* d_y, int64_t ldy,
+                            avs_stream_t stream) {
+  AVS_REQUIRE(dtype == AVS_F32 || dtype == AVS_BF16, AVS_E_ARG, "avs_bn_apply: bad dtype");
+  AVS_REQUIRE(rows >= 0 && c > 0 && c % 4 == 0 && ldx >= c && ldx % 4 == 0 && ldy >= c && ldy % 4 == 0 &&
+                  (!d_residual || (ldr >= c && ldr % 4 == 0)),
+              AVS_E_SHAPE, "avs_bn_apply: rows=%lld c=%d ldx=%lld ldy=%lld ldr=%lld", (long long)rows, c,
+              (long long)ldx, (long long)ldy, (long long)ldr);
+  AVS_REQUIRE((groups > 0) == (d_group_rows != nullptr), AVS_E_ARG, "avs_bn_apply: groups and d_group_rows disagree");
+  if (rows == 0) return AVS_OK;
+  AVS_REQUIRE(d_x && d_scale && d_shift && d_y, AVS_E_ARG, "avs_bn_apply: null pointer");
+  const bool wide = dtype == AVS_BF16 && c % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && (!d_residual || ldr % 8 == 0) &&
+                    avs_aligned16(d_x) && avs_aligned16(d_y) && avs_aligned16(d_residual);
+  const long long span = (groups > 0 ? max_group_rows : rows) * (c / (wide ? 8 : 4));
+  AVS_REQUIRE(span > 0, AVS_E_SHAPE, "avs_bn_apply: max_group_rows must be > 0");
+  long long gx = avs_cdiv(span, 256);
+  if (gx > 8192) gx = 8192;
+  dim3 grid((unsigned)gx, groups > 0 ? groups : 1);
+  AVS_REQUIRE(grid.y <= 65535, AVS_E_SHAPE, "avs_bn_apply: more than 65535 groups in one call");
+  if (dtype == AVS_F32)
+    hipLaunchKernelGGL((bn_apply_kernel<float, 4>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)d_x, c,
+                       (long long)ldx, d_group_rows, (long long)rows, d_scale, d_shift, (const float*)d_residual,
+                       (long long)ldr, act, (float*)d_y, (long long)ldy);
+  else if (wide)
+    hipLaunchKernelGGL((bn_apply_kernel<avs_bf16_tag, 8>), grid, dim3(256), 0, (hipStream_t)stream,
+                       (const avs_bf16_tag*)d_x, c, (long long)ldx, d_group_rows, (long long)rows, d_scale, d_shift,
+                       (const avs_bf16_tag*)d_residual, (long long)ldr, act, (avs_bf16_tag*)d_y, (long long)ldy);
+  else
+    hipLaunchKernelGGL((bn_apply_kernel<avs_bf16_tag, 4>), grid, dim3(256), 0, (hipStream_t)stream,
+                       (const avs_bf16_tag*)d_x, c, (long long)ldx, d_group_rows, (long long)rows, d_scale, d_shift,
+                       (const avs_bf16_tag*)d_residual, (long long)ldr, act, (avs_bf16_tag*)d_y, (long long)ldy);
+  AVS_CHECK_LAUNCH("avs_bn_apply");
+  return AVS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Pooling on NHWC
+// ---------------------------------------------------------------------------
 template <typename T, int V>
 __global__ __launch_bounds__(256) void pool2d_kernel(int mode, const T* __restrict__ x, int n, int h, int w, int c,
                                                      long long xps, int k, int s, int p, T* __restrict__ y, int ho,
