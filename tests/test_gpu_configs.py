@@ -59,6 +59,34 @@ def test_config0_single_video_extract_score_f1(dev):
     assert segments_from_indices(select_frames(got)) == osel.segments_from_indices(osel.select_frames(ref))
 
 
+def test_decoded_video_with_detected_shots(dev):
+    """The whole decoded-input front end of AVProcessor.process_video (extractors.py:339-362): shot detection on the
+    GPU (row F2), the every-third-frame sampling rule, resize to 224 / 299, 4-frame micro-batches with ragged tails,
+    per-shot means - against the oracle run shot by shot on the oracle's own cuts."""
+    from avsum_amd.features.extractors import AVProcessor, sample_shot_indices
+    from oracle import cnn as ocnn, shots as oshots
+    rng = np.random.default_rng(12)
+    n, h, w = 64, 40, 56
+    frames = np.zeros((n, h, w, 3), dtype=np.uint8)
+    base = rng.integers(0, 256, (h, w, 3))
+    for f in range(n):
+        if f in (22, 45):
+            base = rng.integers(0, 256, (h, w, 3))
+        frames[f] = np.clip(base + rng.integers(-3, 4, (h, w, 3)), 0, 255).astype(np.uint8)
+    wave = np.zeros(int(n / 30 * 16000), dtype=np.float32)
+    torch.manual_seed(9)
+    proc = AVProcessor(torch.float32, "batch")
+    rsd = {k: v.clone() for k, v in proc.visual_extractor.resnet.state_dict().items()}
+    isd = {k: v.clone() for k, v in proc.visual_extractor.inception.state_dict().items()}
+    shots = oshots.detect_shots(frames)
+    assert shots == [(0, 22), (22, 45), (45, 64)]
+    want = np.array([ocnn.visual_forward(rsd, isd, [frames[i] for i in sample_shot_indices(s, e)]) for s, e in shots])
+    proc.visual_extractor.to(dev)
+    vis, aud = proc.process_decoded(frames, wave, 30.0)          # shots=None: detected on the GPU
+    assert vis.shape == (3, 4096) and aud.shape == (3, 296) and not aud.any()
+    assert np.abs(vis - want).max() < 5e-4 * max(1.0, np.abs(want).max())
+
+
 def test_config2_audio_visual_fusion(dev):
     """configs[2] at reduced size: mel / MFCC of a multi-sine + noise waveform, CNN embeddings, then
     features/fusion.py on the two 512-d embedded streams (cost matrix float64, DTW path, gather)."""
