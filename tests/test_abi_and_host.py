@@ -105,6 +105,46 @@ def test_binding_brings_up_torchs_hip_runtime_first():
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-500:]
 
 
+def test_preprocess_orchestration_and_disk_format(tmp_path):
+    """scripts/preprocess.py counterpart (reference scripts/preprocess.py:32-85): walks *.mp4, writes
+    data/processed/<vid>/{visual,audio}.npy as float32 [S,4096] / [S,296], skips finished videos, removes a partial
+    directory on failure, and the dataset reader (data/dataset.py:35-62) returns what was written.  Host logic only:
+    the processor is a stand-in."""
+    import pandas as pd
+    from avsum_amd.data.dataset import TVSumDataset
+    from avsum_amd.scripts.preprocess import preprocess_dataset
+    raw, out = tmp_path / "raw", tmp_path / "processed"
+    raw.mkdir()
+    for name in ("a.mp4", "b.mp4", "bad.mp4", "notes.txt"):
+        (raw / name).write_bytes(b"x")
+    calls = []
+
+    class FakeProcessor:
+        def process_video(self, path):
+            calls.append(os.path.basename(path))
+            if "bad" in path:
+                os.makedirs(out / "bad", exist_ok=True)          # a partial output directory
+                raise RuntimeError("decode failed")
+            s = 3 if path.endswith("a.mp4") else 5
+            return np.full((s, 4096), 0.5, np.float64), np.zeros((s, 296))   # audio: the literal float64 zeros
+
+    done, failed = preprocess_dataset(str(raw), str(out), FakeProcessor())
+    assert done == ["a", "b"] and failed == ["bad"] and calls == ["a.mp4", "b.mp4", "bad.mp4"]
+    assert not (out / "bad").exists()                             # preprocess.py:83-85
+    v = np.load(out / "a" / "visual.npy")
+    a = np.load(out / "b" / "audio.npy")
+    assert v.dtype == np.float32 and v.shape == (3, 4096) and a.dtype == np.float32 and a.shape == (5, 296)
+    calls.clear()
+    done, failed = preprocess_dataset(str(raw), str(out), FakeProcessor())
+    assert done == [] and calls == ["bad.mp4"]                    # preprocess.py:46-55: finished videos are skipped
+    df = pd.DataFrame({"Video File Name": ["a", "a", "b"],
+                       "Annotations": [np.ones(4), 3 * np.ones(4), np.arange(4.0)]})
+    ds = TVSumDataset(df, str(out))
+    feats, scores = ds[0]
+    assert feats["visual"].shape == (3, 4096) and feats["audio"].shape == (3, 296)
+    assert torch.equal(scores, torch.full((4,), 2.0))             # mean over the users' annotations
+
+
 def test_pipeline_group_offsets():
     from avsum_amd.pipeline import FrameScoringPipeline
     p = FrameScoringPipeline(None, None, frames_per_group=4)
