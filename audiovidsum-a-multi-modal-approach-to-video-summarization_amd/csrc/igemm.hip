@@ -304,17 +304,21 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? 3 : 2) voi
     uint4* abuf = lds + buf * BUF + wave * 64;        // wave-uniform; lane l lands at +l
     uint4* bbuf = abuf + A_ROWS * CPRR;
     if constexpr (FASTK) {
+      if (!(p.debug & 16)) {  // kernel study: bit 4 skips the A operand, bit 5 the B operand
 #pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        unsigned off = aoff[i];
-        if constexpr (SPATIAL) off = ((amask[i] >> f_tap) & 1u) ? off : BUF_OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(abuf + 256 * i), 16,
-                                                 (int)off, f_koff, 0, 0);
+        for (int i = 0; i < NA; ++i) {
+          unsigned off = aoff[i];
+          if constexpr (SPATIAL) off = ((amask[i] >> f_tap) & 1u) ? off : BUF_OOB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(abuf + 256 * i), 16,
+                                                   (int)off, f_koff, 0, 0);
+        }
       }
+      if (!(p.debug & 32)) {
 #pragma unroll
-      for (int i = 0; i < NB; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (__attribute__((address_space(3))) void*)(bbuf + 256 * i), 16,
-                                                 (int)boff[i], f_kb, 0, 0);
+        for (int i = 0; i < NB; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (__attribute__((address_space(3))) void*)(bbuf + 256 * i), 16,
+                                                   (int)boff[i], f_kb, 0, 0);
+      }
       f_kb += BKE * ES;
       // next step (scalar): the same tap's next channel block, or the next tap
       f_ci0 += BKE;

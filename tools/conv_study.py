@@ -29,8 +29,8 @@ for name, n, hw, cin, cout, k, s in shapes:
     flops = 2.0 * n * ho * ho * cout * k * k * cin
     byts = (x.numel() + y.numel() + w.numel()) * 2
     line = f"{name:26s}"
-    for tag, flags, rowb, pipe, tall in (("pipe3", 0, 100000, 1, 1), ("rowb128", 0, 0, 1, 1), ("tall", 0, 2048, 1, 2),
-                                         ("nostage", 8, 2048, 1, 1), ("tall-nostage", 8, 2048, 1, 2), ("noload", 2, 2048, 1, 1)):
+    for tag, flags, rowb, pipe, tall in (("auto", 0, 2048, 1, 0), ("nostage", 8, 2048, 1, 0), ("noA", 16, 2048, 1, 0),
+                                         ("noB", 32, 2048, 1, 0), ("noload", 2, 2048, 1, 0)):
         L.avs_debug_flags(flags)
         L.avs_tune_short_reduction_bytes(rowb)
         L.avs_tune_pipeline(pipe)
