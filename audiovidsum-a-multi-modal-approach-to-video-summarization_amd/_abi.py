@@ -14,7 +14,10 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_uint,
 import torch  # noqa: F401  (memory, streams and the HIP runtime come from here)
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "lib", "libavsum_hip.so")
+# AVS_STUDY_LIB=1 loads the kernel-study build (`make study`: the same library with the ablation switches of tools/
+# compiled in, plus avs_debug_flags); the product never sets it
+STUDY = os.environ.get("AVS_STUDY_LIB") == "1"
+LIB_PATH = os.path.join(_PKG_DIR, "lib", "libavsum_hip_study.so" if STUDY else "libavsum_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "avsum_hip.h")
 
 AVS_F32, AVS_BF16, AVS_F32_ACC64 = 0, 1, 2
@@ -46,20 +49,16 @@ _SIGNATURES = {
     "avs_last_error": (c_char_p, []),
     "avs_device_info": (c_int, [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int64), c_char_p, c_int]),
     "avs_conv2d_nhwc": (c_int, [POINTER(ConvDesc), P, P, P, P, P]),
-    "avs_conv2d_nhwc_bnstats": (c_int, [POINTER(ConvDesc), P, P, P, c_int64, P, P, P]),
-    "avs_bn_finalize": (c_int, [P, P, c_int, c_int, c_int64, P, P, c_float, P, P, P]),
+    "avs_conv2d_bnstats_workspace_bytes": (c_int64, [POINTER(ConvDesc), c_int64]),
+    "avs_conv2d_nhwc_bnstats": (c_int, [POINTER(ConvDesc), P, P, P, c_int64, P, P, c_float, P, P, P, c_int64, P]),
     "avs_conv1x1_bn_bf16": (c_int, [P, c_int64, c_int, P, c_int64, c_int, c_int64, c_int, P, P, c_float, P, c_int64,
                                     c_int, P, c_int64, P]),
     "avs_conv1x1_bn_in_bf16": (c_int, [P, c_int64, c_int, P, P, P, c_int64, c_int, c_int64, c_int, P, P, c_float, P,
                                        c_int64, c_int, P, c_int64, P]),
-    "avs_conv2d_bnsync_workspace_bytes": (c_int64, [POINTER(ConvDesc), c_int64]),
-    "avs_conv2d_nhwc_bnsync": (c_int, [POINTER(ConvDesc), P, P, P, c_int64, P, P, c_float, P, c_int64, P, c_int64,
-                                       P, P]),
-    "avs_tune_bnsync_timeout_ticks": (None, [c_int64]),
+    "avs_conv2d_bnlocal_tile_rows": (c_int, [POINTER(ConvDesc), c_int64]),
+    "avs_conv2d_nhwc_bnlocal": (c_int, [POINTER(ConvDesc), P, P, P, c_int64, P, P, c_float, P, c_int64, P]),
     "avs_tune_bnlocal": (None, [c_int]),
-    "avs_debug_bnsync_trace": (None, [P]),
     "avs_tune_short_reduction_bytes": (None, [c_int]),
-    "avs_debug_flags": (None, [c_int]),
     "avs_tune_pipeline": (None, [c_int]),
     "avs_tune_fast_staging": (None, [c_int]),
     "avs_tune_tall_tiles": (None, [c_int, c_int64, c_int64]),
@@ -126,6 +125,9 @@ def lib():
             "(run __graft_entry__.build() or `make -C <package>/csrc`). There is no CPU fallback."
         )
     handle = ctypes.CDLL(LIB_PATH)
+    if STUDY:
+        handle.avs_debug_flags.restype = None
+        handle.avs_debug_flags.argtypes = [c_int]
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(handle, name)
         fn.restype = res

@@ -93,12 +93,13 @@ def _stem_weight(weight, px, dtype):
 class ResNet50Runner:
     """Runs the container's parameters on uint8 frames [N,224,224,3] -> fp32 [N,2048].
 
-    Batch-statistics BatchNorm (the reference's mode) has three forms here, chosen per layer:
-      sync    bf16, equal-sized groups: convolution + whole BatchNorm (+ residual + ReLU) in ONE launch whose tiles
-              wait for their group's statistics (avs_conv2d_nhwc_bnsync) - nothing raw in HBM, no second pass;
+    Batch-statistics BatchNorm (the reference's mode) has three forms here, chosen per layer; every one
+    of them is deterministic (no float atomics: two runs give bit-identical features):
+      local   bf16, equal-sized groups of <= 256 rows (14x14 / 7x7 maps): convolution + whole BatchNorm (+ residual
+              + ReLU) in ONE launch, statistics inside a tile (avs_conv2d_nhwc_bnlocal) - nothing raw in HBM;
       twopass bf16 1x1 layers: one workgroup walks a group twice (avs_conv1x1_bn_bf16);
-      split   convolution (+ statistics in its epilogue for bf16) -> avs_bn_finalize / avs_bn_batch_stats -> avs_bn_apply
-              (fp32 parity mode, ragged groups, shapes the other forms do not take)."""
+      split   convolution (+ per-tile partial statistics in its epilogue for bf16, folded in tile order) or
+              avs_bn_batch_stats -> avs_bn_apply (fp32 parity mode, ragged groups, shapes the other forms decline)."""
 
     def __init__(self, trunk, dtype=torch.float32, bn_mode="batch"):
         if bn_mode not in ("batch", "folded"):
@@ -106,17 +107,11 @@ class ResNet50Runner:
         self.trunk, self.dtype, self.bn_mode = trunk, dtype, bn_mode
         self.fuse_conv_bn = True
         self.fuse_min_rows, self.fuse_ratio_num, self.fuse_ratio_den = 128, 2, 1
-        self.bn_sync = True
+        self.bn_local = True         # the one-launch tile-local form where the library takes the shape
         self.defer_bn_apply = True   # bn2 + ReLU applied inside conv3's two-pass kernel (avs_conv1x1_bn_in_bf16)
-        # measured on MI355X (tools/bn_study.py, 1024-frame chunk): a tile of the sync form waits for the SLOWEST
-        # tile of its group, so the form wins 1.1-1.35x where a group is two or three row tiles (14x14 and 7x7
-        # maps) and loses 3-5x where it is 25-100 of them (56x56, 112x112): taken up to this many rows per group
-        self.sync_max_group_rows = 256
         self._key = None
         self._w = None
-        self._plans = {}     # (n, group frames) -> per-layer (offset, bytes) | None of the sync form's workspace
-        self._ws = None
-        self._err = None
+        self._plans = {}     # (n, group frames) -> per layer: does it take the tile-local form
 
     # weights in kernel layout, rebuilt when the parameters change / move
     def _prepare(self):
@@ -169,42 +164,21 @@ class ResNet50Runner:
                 yield self._nhwc_geom(n, hout, planes, 1, 1, 0, planes * 4)
                 h, cin = hout, planes * 4
 
-    def _sync_plan(self, n, gsz, dev):
-        """Workspace layout of the sync form for n frames in groups of gsz: per layer (offset, bytes) or None."""
-        key = (n, gsz, self.sync_max_group_rows)
+    def _local_plan(self, n, gsz):
+        """Per layer (forward order): does the one-launch tile-local form take it for n frames in groups of gsz."""
+        key = (n, gsz)
         plan = self._plans.get(key)
         if plan is None:
             dcode = ops.dtype_code(self.dtype)
-            plan, off = [], 0
+            plan = []
             for geom, xs, wrs in self._layer_geoms(n):
                 ho, wo, cout = geom[10], geom[11], geom[12]
-                nbytes = None
-                if gsz * ho * wo <= self.sync_max_group_rows:
-                    nbytes = ops.conv_bnsync_workspace_bytes(dcode, *geom, *xs, wrs, cout, gsz * ho * wo)
-                plan.append(None if nbytes is None else (off, nbytes))
-                off += nbytes or 0
-            plan.append(off)
+                plan.append(gsz * ho * wo <= 256 and
+                            ops.conv_bnlocal_tile_rows(dcode, *geom, *xs, wrs, cout, gsz * ho * wo) is not None)
             if len(self._plans) > 64:
                 self._plans.clear()
             self._plans[key] = plan
-        total = plan[-1]
-        if self._ws is None or self._ws.numel() < total or self._ws.device != dev:
-            self._ws = torch.empty(max(total, 256), dtype=torch.uint8, device=dev)
-        if self._err is None or self._err.device != dev:
-            self._err = torch.zeros(1, dtype=torch.int32, device=dev)
-        if total:
-            self._ws[:total].zero_()   # statistics and arrival counters of every layer of this pass: one fill
         return plan
-
-    def sync_failed(self):
-        """True when a group wait of the sync form timed out since the last call (host sync; clears the word).
-        Results produced since are void: recompute with ``bn_sync = False``."""
-        if self._err is None:
-            return False
-        bad = bool(self._err.item())
-        if bad:
-            self._err.zero_()
-        return bad
 
     def _twopass_ok(self, cin, cout, kh, sh, gmax):
         # measured on MI355X: the two-pass kernel wins over the split form where the layer is write-heavy
@@ -212,7 +186,7 @@ class ResNet50Runner:
         return (kh == 1 and sh == 1 and self.fuse_conv_bn and gmax >= self.fuse_min_rows
                 and cout * self.fuse_ratio_den >= cin * self.fuse_ratio_num)
 
-    def _conv_bn(self, geom, xs, x, wt, bnp, groups, residual=None, relu=True, sync=None, algo_k=None, pool=None,
+    def _conv_bn(self, geom, xs, x, wt, bnp, groups, residual=None, relu=True, local=False, algo_k=None, pool=None,
                  defer=False, in_affine=None):
         """One convolution + BatchNorm (+ residual, + ReLU) -> NHWC activation; picks the form (class docstring).
         pool = (k, s, p): a max pooling follows (the stem) - on the split form it is fused with the BatchNorm apply
@@ -254,9 +228,8 @@ class ResNet50Runner:
             return finish(scale.view(1, -1), shift.view(1, -1), None, 0)
         grows, gmax, uniform = groups[ho * wo]
         fast = uniform and dt == torch.bfloat16
-        if fast and sync is not None:
-            off, nbytes = sync
-            conv(act=act, bnsync=(gmax, gamma, beta, eps, residual, self._ws[off:off + nbytes], self._err))
+        if fast and local:
+            conv(act=act, bnlocal=(gmax, gamma, beta, eps, residual))
             if pool is not None:
                 out, k, s, p = pooled(y)
                 return ops.pool2d(y, "max", k, s, p, out)
@@ -264,23 +237,24 @@ class ResNet50Runner:
         if in_affine is not None or (fast and self._twopass_ok(cin, cout, kh, sh, gmax)):
             ops.conv1x1_bn(x.view(-1, cin), wt, gmax, gamma, beta, eps, y2d, residual, relu, in_affine)
             return y
+        affine = None
         if fast:
-            # statistics from the convolution's epilogue (E[x^2]-E[x]^2 by float atomics: fine for bf16 activations)
-            scale, shift = conv(bnstats=(gmax, gamma, beta, eps))
-            if defer:
-                return y, (scale, shift)
-        else:
-            # fp32 parity mode / ragged groups: the shifted, deterministic statistics pass
-            conv()
-            scale, shift = ops.bn_batch_stats(y2d, grows, gamma, beta, eps)
-        return finish(scale, shift, grows, gmax)
+            # statistics from the convolution's epilogue: per-tile partial sums of the fp32 accumulators, folded in
+            # tile order (E[x^2]-E[x]^2: fine for bf16 activations); None = groups too small for that form
+            affine = conv(bnstats=(gmax, gamma, beta, eps))
+        if affine is None:
+            # fp32 parity mode / ragged groups / tiny groups: the shifted statistics pass over the stored output
+            if not fast:
+                conv()
+            affine = ops.bn_batch_stats(y2d, grows, gamma, beta, eps)
+        if defer:
+            return y, affine
+        return finish(affine[0], affine[1], grows, gmax)
 
-    def forward(self, frames_u8, group_frames=None, out=None, check=True):
+    def forward(self, frames_u8, group_frames=None, out=None):
         """frames_u8: device uint8 [N,224,224,3] (already 224x224, extractors.py:132).
         group_frames: int64 CPU tensor / list [G+1] of frame offsets of the BatchNorm micro-batch groups
-        (extractors.py:48-56); default = one group per frame.
-        check: verify (host sync) that no group wait of the sync form timed out, and recompute without it if one
-        did; a caller that batches many passes sets False and polls ``sync_failed()`` itself."""
+        (extractors.py:48-56); default = one group per frame."""
         n, h, w_, _ = frames_u8.shape
         if (h, w_) != (224, 224):
             raise ValueError("ResNet50Runner expects 224x224 frames (resize first)")
@@ -298,16 +272,16 @@ class ResNet50Runner:
         uniform = bool((sizes == gsz).all())
         groups = {hw: ((group_frames * hw).to(dev), gsz * hw, uniform)
                   for hw in (112 * 112, 56 * 56, 28 * 28, 14 * 14, 7 * 7)}
-        use_sync = self.bn_sync and self.bn_mode == "batch" and uniform and dt == torch.bfloat16
-        plan = iter(self._sync_plan(n, gsz, dev)[:-1]) if use_sync else None
+        use_local = self.bn_local and self.bn_mode == "batch" and uniform and dt == torch.bfloat16
+        plan = iter(self._local_plan(n, gsz)) if use_local else None
 
         def slot():
-            return next(plan) if plan is not None else None
+            return next(plan) if plan is not None else False
 
         # stem: (x - mean)/std without /255 (extractors.py:133-139), zero padded by 3 (conv1 pad)
         x0 = ops.frames_normalize(frames_u8, dt, 1.0, RESNET_MEAN, RESNET_STD, 230, 232, 3, 3)
         geom, xs, _ = self._stem_geom(n)
-        x = self._conv_bn(geom, xs, x0, w["stem"], w["bn1"], groups, sync=slot(), algo_k=147, pool=(3, 2, 1))
+        x = self._conv_bn(geom, xs, x0, w["stem"], w["bn1"], groups, local=slot(), algo_k=147, pool=(3, 2, 1))
         del x0
         hcur = 56
         for blk in w["blocks"]:
@@ -315,18 +289,18 @@ class ResNet50Runner:
             cin = x.shape[3]
             hout = hcur // s
             s1, s2 = slot(), slot()
-            sd = slot() if "cd" in blk else None
+            sd = slot() if "cd" in blk else False
             s3 = slot()
             geom, xs, _ = self._nhwc_geom(n, hcur, cin, 1, 1, 0, planes)
-            t1 = self._conv_bn(geom, xs, x, blk["c1"], blk["b1"], groups, sync=s1)
+            t1 = self._conv_bn(geom, xs, x, blk["c1"], blk["b1"], groups, local=s1)
             # bn2 + ReLU ride in conv3's input staging when conv3 takes the two-pass kernel: conv2 then only
             # writes its raw output and statistics (no apply pass over it)
             gmax3 = gsz * hout * hout
             defer2 = (self.defer_bn_apply and self.bn_mode == "batch" and uniform and dt == torch.bfloat16
-                      and s2 is None and s3 is None and planes <= 512
+                      and not s2 and not s3 and planes <= 512
                       and self._twopass_ok(planes, planes * 4, 1, 1, gmax3))
             geom, xs, _ = self._nhwc_geom(n, hcur, planes, 3, s, 1, planes)
-            t2 = self._conv_bn(geom, xs, t1, blk["c2"], blk["b2"], groups, sync=s2, defer=defer2)
+            t2 = self._conv_bn(geom, xs, t1, blk["c2"], blk["b2"], groups, local=s2, defer=defer2)
             aff2 = None
             if defer2:
                 t2, aff2 = t2
@@ -334,22 +308,15 @@ class ResNet50Runner:
             if "cd" in blk:
                 geom, xs, _ = self._nhwc_geom(n, hcur, cin, 1, s, 0, planes * 4)
                 idn = self._conv_bn(geom, xs, x, blk["cd"], blk["bd"], groups, relu=False,
-                                    sync=sd).view(-1, planes * 4)
+                                    local=sd).view(-1, planes * 4)
             else:
                 idn = x.view(-1, cin)
             geom, xs, _ = self._nhwc_geom(n, hout, planes, 1, 1, 0, planes * 4)
-            x = self._conv_bn(geom, xs, t2, blk["c3"], blk["b3"], groups, residual=idn, relu=True, sync=s3,
+            x = self._conv_bn(geom, xs, t2, blk["c3"], blk["b3"], groups, residual=idn, relu=True, local=s3,
                               in_affine=aff2)
             del t2, idn
             hcur = hout
-        feats = ops.global_avgpool(x, out)
-        if use_sync and check and self.sync_failed():
-            import warnings
-            warnings.warn("avsum_amd: a BatchNorm group wait timed out on the device; recomputing on the two-pass "
-                          "path and disabling the one-launch form for this runner")
-            self.bn_sync = False
-            return self.forward(frames_u8, group_frames, out, check)
-        return feats
+        return ops.global_avgpool(x, out)
 
 
 # ============================================================================ Inception-v3 container

@@ -51,28 +51,32 @@ struct IgemmParams {
   float alpha;
   int act, bias_mode;
   int tiles_n;
-  // optional fused BatchNorm batch statistics: per (row / rows_per_group, column) sum and sum of squares of
-  // the values as stored, accumulated with float atomics
-  float* stat_sum;
-  float* stat_sq;
+  // EPI_STATS (fused BatchNorm batch statistics): every row tile writes, for each group it overlaps, its column sums
+  // and sums of squares of the fp32 accumulators to its OWN slot stat_part[tile][slot][sum | sumsq][N] (plain stores,
+  // no atomics); bn_fold_kernel adds a group's slots in tile order, so the statistics are reproducible bit for bit
+  float* stat_part;
+  int stat_slots;    // slots per row tile = groups a tile can overlap
   int rows_per_group;
   long long lin_stride;  // >= 0: output row m reads input row m at x + m*lin_stride (no (n,ho,wo) decode needed)
-  // EPI_BNSYNC (whole BatchNorm in the epilogue): arrival counters [groups][tiles_n] (zeroed by the caller together
-  // with stat_sum / stat_sq), the error word a timed-out wait sets, BatchNorm parameters, optional residual
-  unsigned* arrive;
-  int* err;
+  // EPI_BNLOCAL (whole BatchNorm in the epilogue): BatchNorm parameters, optional residual
   const float* gamma;
   const float* beta;
   float eps;
   const char* residual;
   long long ldr;
-  int tiles_m;
-  long long spin_ticks;
   int tall;          // 1: the 256-row tile variants (WR = 4)
   int tile_rows;     // EPI_BNLOCAL: rows of the tile that are used (whole groups), also the pitch between tiles
-  long long* trace;  // kernel-study only: per block {xcc id, start, arrive, wait end} wall-clock ticks
-  int debug;  // ablation switches for kernel studies (0 in production): 1 = skip output stores, 2 = skip A/B loads
+#ifdef AVS_STUDY
+  int debug;  // ablation switches of the kernel-study build (tools/): 1 = skip output stores, 2 = skip A/B loads, ...
+#endif
 };
+
+// Ablation switches exist in the study build only (make study -> libavsum_hip_study.so); the shipped kernels carry none.
+#ifdef AVS_STUDY
+#define AVS_DEBUG_BIT(p, bit) ((p).debug & (bit))
+#else
+#define AVS_DEBUG_BIT(p, bit) 0
+#endif
 
 #define AVS_GLDS16(src, dst)                                                                        \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),            \
@@ -83,26 +87,22 @@ struct IgemmParams {
 // cost is the latency of their few loads and their stores rather than the matrix work.
 // EPI: the epilogue is what a tile of a short reduction costs, so its common forms are compiled separately:
 //   EPI_PLAIN  alpha == 1, no bias, no activation, no statistics (ResNet convolutions, projections)
-//   EPI_STATS  EPI_PLAIN + fused BatchNorm batch statistics
+//   EPI_STATS  EPI_PLAIN + fused BatchNorm batch statistics: per-tile partial column sums in the tile's own slots
+//              (no atomics), folded in tile order by bn_fold_kernel: deterministic
 //   EPI_ANY    everything decided at run time (bias per column / row, ReLU, alpha)
 //   EPI_BRELU  alpha == 1, bias per column, ReLU (the folded-BatchNorm convolutions of Inception-v3; Linear+ReLU)
-//   EPI_BNSYNC bf16 only: the whole batch-statistics BatchNorm (+ residual, + ReLU) in the epilogue.  A tile adds its
-//              column sums to the group statistics (float atomics), signals an arrival counter per (group, column
-//              tile), WAITS until every tile of its group(s) has arrived — its accumulators stay in registers
-//              meanwhile — and then normalises and stores the final activation: the raw convolution never goes
-//              to HBM and there is no second pass.  Tiles of one group are dealt to neighbouring dispatch slots
-//              (see the tile map below), so the wait is the dispatch skew of a few dozen workgroups; the launcher
-//              only takes this form when a group's tiles fit the resident set several times over, and a wait that
-//              exceeds spin_ticks sets *err instead of hanging (the host then recomputes on the unfused path).
 //   EPI_BNLOCAL bf16, 256-row tiles only: the whole BatchNorm in the epilogue WITHOUT any traffic between workgroups.
 //              A tile holds floor(256 / rows_per_group) WHOLE groups (tile pitch = that many rows, the rest of the
 //              256 rows idle), so a group's statistics are sums over this tile's accumulators alone: per-wave masked
 //              column sums -> LDS across the four row-waves -> scale/shift table -> normalise (+ residual, + ReLU)
 //              -> store.  No atomics, no waiting, deterministic.  Taken when groups are at most 256 rows and fill
 //              at least 3/4 of the tile (per-frame 14x14 and 7x7 maps: 196 = 77 %, 5 x 49 = 96 %).
-enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_ANY = 2, EPI_BRELU = 3, EPI_BNSYNC = 4, EPI_BNLOCAL = 5 };
+// (A form in which tiles of larger groups exchanged statistics through float atomics and waited for each other inside
+//  one launch was built in round 1 and removed: results were not reproducible run to run and it only won for groups of
+//  two or three tiles, which the tile-local form covers.)
+enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_ANY = 2, EPI_BRELU = 3, EPI_BNLOCAL = 5 };
 constexpr int BNLOCAL_MAX_GROUPS = 6;  // groups per 256-row tile (rows_per_group >= 43)
-constexpr int BNSYNC_MAX_GROUPS = 4;  // groups one 128-row tile may overlap
+constexpr int STATS_MIN_GROUP_ROWS = 64;  // EPI_STATS: a wave's 64 rows then overlap at most two groups
 
 // PIPE: three operand buffers, the DMA of step s+2 is issued in step s; fragment reads are inline-asm
 // ds_read_b128 and the waits are hand-counted (s_waitcnt vmcnt(N) + raw s_barrier), because hipcc orders every
@@ -145,9 +145,10 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? 3 : 2) voi
   constexpr int CT_PITCH = BN * 2 + 16;      // bf16 epilogue staging tile: row pitch in bytes (16 bytes of padding)
   constexpr int CT_SLOTS = ES == 2 ? (A_ROWS * CT_PITCH) / 16 : 0;
   constexpr int NBUF = PIPE ? 3 : 2;
-  constexpr int TAB_SLOTS = EPI == EPI_BNSYNC    ? (BNSYNC_MAX_GROUPS * 2 * BN * 4) / 16
-                            : EPI == EPI_BNLOCAL ? (BNLOCAL_MAX_GROUPS * 2 * BN * 4) / 16
-                                                 : 0;  // scale/shift table (behind the staging tile)
+  // behind the staging tile: EPI_BNLOCAL's scale/shift table; EPI_STATS' per-wave column sums [WR][2 groups][2][BN]
+  constexpr int TAB_SLOTS = EPI == EPI_BNLOCAL ? (BNLOCAL_MAX_GROUPS * 2 * BN * 4) / 16
+                            : EPI == EPI_STATS ? (WR * 2 * 2 * BN * 4) / 16
+                                               : 0;
   constexpr int LDS_SLOTS = NBUF * BUF > CT_SLOTS + TAB_SLOTS ? NBUF * BUF : CT_SLOTS + TAB_SLOTS;
 
   __shared__ uint4 lds[LDS_SLOTS];
@@ -157,22 +158,8 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? 3 : 2) voi
   const unsigned nwg = gridDim.x, orig = blockIdx.x;
   const unsigned q = nwg >> 3, rr = nwg & 7, xcd = orig & 7;
   const unsigned wg = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
-  int tn = wg % p.tiles_n;
-  int tm = wg / p.tiles_n;
-  if constexpr (EPI == EPI_BNSYNC) {
-    // Dispatch-ordered map: blocks are dealt round-robin over the XCDs (orig & 7) and started in order, so the
-    // eight blocks of one dispatch level take eight consecutive row tiles and the levels walk the column tiles
-    // first: the tiles of one BatchNorm group start within a few levels of each other on every XCD (short
-    // waits), and the column tiles of one row tile share an XCD (A rows re-read from its L2).
-    const unsigned lvl = orig >> 3;
-    tn = lvl % p.tiles_n;
-    tm = (lvl / p.tiles_n) * 8 + xcd;
-    if (tm >= p.tiles_m) return;  // grid padding (rows of tiles rounded up to 8)
-    if (p.trace && threadIdx.x == 0) {
-      p.trace[4ll * orig + 0] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) ;  // HW_REG_XCC_ID[3:0]
-      p.trace[4ll * orig + 1] = wall_clock64();
-    }
-  }
+  const int tn = wg % p.tiles_n;
+  const int tm = wg / p.tiles_n;
   const int m0 = EPI == EPI_BNLOCAL ? tm * p.tile_rows : tm * A_ROWS;
   const int n0 = tn * BN;
 
@@ -226,7 +213,7 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? 3 : 2) voi
     b_base[i] = n < p.N ? w + (long long)n * p.ldb * ES : nullptr;
   }
 
-  if (p.debug & 2) {
+  if (AVS_DEBUG_BIT(p, 2)) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) a_base[i] = nullptr;
 #pragma unroll
@@ -300,11 +287,11 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? 3 : 2) voi
   }
 
   auto stage = [&](int buf) {
-    if (p.debug & 8) return;  // kernel study: no staging at all (the loop runs on whatever the LDS holds)
+    if (AVS_DEBUG_BIT(p, 8)) return;  // study build: no staging at all (the loop runs on whatever the LDS holds)
     uint4* abuf = lds + buf * BUF + wave * 64;        // wave-uniform; lane l lands at +l
     uint4* bbuf = abuf + A_ROWS * CPRR;
     if constexpr (FASTK) {
-      if (!(p.debug & 16)) {  // kernel study: bit 4 skips the A operand, bit 5 the B operand
+      if (!AVS_DEBUG_BIT(p, 16)) {  // study build: bit 4 skips the A operand, bit 5 the B operand
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
           unsigned off = aoff[i];
@@ -313,7 +300,7 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? 3 : 2) voi
                                                    (int)off, f_koff, 0, 0);
         }
       }
-      if (!(p.debug & 32)) {
+      if (!AVS_DEBUG_BIT(p, 32)) {
 #pragma unroll
         for (int i = 0; i < NB; ++i)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (__attribute__((address_space(3))) void*)(bbuf + 256 * i), 16,
@@ -532,30 +519,20 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? 3 : 2) voi
   constexpr int E_CPRW = BN / 8;           // 16-byte chunks per bf16 tile row
   constexpr int E_RSTEP = 256 / E_CPRW;    // tile rows covered by one pass of the 256 threads
   constexpr int E_NIT = A_ROWS / E_RSTEP;
-  uint4 resv[EPI == EPI_BNSYNC ? E_NIT : 1];
-  if constexpr (EPI == EPI_BNSYNC) {
-    // the residual rows this thread will add in the store phase: issued now, landed by the end of the wait
-    if (p.residual) {
-      const int srow = t / E_CPRW, sch = t - srow * E_CPRW;
-#pragma unroll
-      for (int it = 0; it < E_NIT; ++it) {
-        const int row = m0 + srow + it * E_RSTEP;
-        resv[it] = row < p.M ? *reinterpret_cast<const uint4*>(p.residual + ((long long)row * p.ldr + n0 + sch * 8) * 2)
-                             : make_uint4(0u, 0u, 0u, 0u);
-      }
-    }
-  }
-  if constexpr (EPI == EPI_STATS || EPI == EPI_BNSYNC) {
-    // Fused batch statistics.  A lane owns one column of each 32-wide tile: it sums its 2 x 16 rows per
-    // group, the two lane halves are folded by one shuffle, and lanes 0..31 issue one atomic pair per
-    // (group, column).  Rows past M hold exact zeros and add nothing.
+  // EPI_STATS: this tile's column sums per group.  A lane owns one column of each 32-wide tile: it sums its 2 x 16
+  // rows per group (fp32 accumulators, before the bf16 rounding), the two lane halves are folded by one shuffle and
+  // lanes 0..31 park the pair in LDS behind the staging tile: sred[wave row][group slot of the wave][sum | sumsq][BN].
+  // stats_fold() (after the tile's next barrier) adds the wave rows in a fixed order and stores the tile's slots.
+  // Rows past M hold exact zeros and add nothing.
+  float* const sred = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + (size_t)CT_SLOTS * 16);
+  if constexpr (EPI == EPI_STATS) {
     const int r_first = m0 + wr * 64;
     if (r_first < p.M) {
       const int r_last = (r_first + 63 < p.M ? r_first + 63 : p.M - 1);
-      const int g0 = r_first / p.rows_per_group, g1 = r_last / p.rows_per_group;
+      const int g0 = r_first / p.rows_per_group, g1 = r_last / p.rows_per_group;  // g1 - g0 <= 1 (launcher)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const int col = n0 + wc * WCOLS + nt * 32 + lr;
+        const int cc = wc * WCOLS + nt * 32 + lr;
         if (g0 == g1) {
           float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -568,9 +545,9 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? 3 : 2) voi
             }
           s1 += __shfl_xor(s1, 32, 64);
           s2 += __shfl_xor(s2, 32, 64);
-          if (lh == 0 && col < p.N) {
-            atomicAdd(p.stat_sum + (long long)g0 * p.N + col, s1);
-            atomicAdd(p.stat_sq + (long long)g0 * p.N + col, s2);
+          if (lh == 0) {
+            sred[((wr * 2 + 0) * 2 + 0) * BN + cc] = s1;
+            sred[((wr * 2 + 0) * 2 + 1) * BN + cc] = s2;
           }
         } else {
           for (int g = g0; g <= g1; ++g) {
@@ -587,15 +564,45 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? 3 : 2) voi
               }
             s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 32, 64);
-            if (lh == 0 && col < p.N) {
-              atomicAdd(p.stat_sum + (long long)g * p.N + col, s1);
-              atomicAdd(p.stat_sq + (long long)g * p.N + col, s2);
+            if (lh == 0) {
+              sred[((wr * 2 + (g - g0)) * 2 + 0) * BN + cc] = s1;
+              sred[((wr * 2 + (g - g0)) * 2 + 1) * BN + cc] = s2;
             }
           }
         }
       }
     }
   }
+  // after a barrier that follows the block above: slot j of this row tile = group (m0 / rows_per_group) + j
+  auto stats_fold = [&]() {
+    if constexpr (EPI == EPI_STATS) {
+      const int rpg = p.rows_per_group;
+      const int m_last = (m0 + A_ROWS < p.M ? m0 + A_ROWS : p.M) - 1;
+      const int g_lo = m0 / rpg;
+      const int nj = m_last / rpg - g_lo + 1;  // <= p.stat_slots
+      for (int i = t; i < nj * BN; i += 256) {
+        const int j = i / BN, cc = i - j * BN;
+        const int g = g_lo + j;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < WR; ++r) {
+          const int r_first = m0 + r * 64;
+          if (r_first >= p.M) break;
+          const int r_last = (r_first + 63 < p.M ? r_first + 63 : p.M - 1);
+          const int g0 = r_first / rpg, g1 = r_last / rpg;
+          if (g >= g0 && g <= g1) {
+            s1 += sred[((r * 2 + (g - g0)) * 2 + 0) * BN + cc];
+            s2 += sred[((r * 2 + (g - g0)) * 2 + 1) * BN + cc];
+          }
+        }
+        if (n0 + cc < p.N) {
+          float* dst = p.stat_part + (((long long)tm * p.stat_slots + j) * 2) * p.N + n0 + cc;
+          dst[0] = s1;
+          dst[p.N] = s2;
+        }
+      }
+    }
+  };
   if constexpr (EPI == EPI_BNLOCAL) {
     static_assert(EPI != EPI_BNLOCAL || (ES == 2 && WR == 4), "the local BatchNorm epilogue is built on the 256-row bf16 tiles");
     char* ct = reinterpret_cast<char*>(lds);
@@ -777,133 +784,6 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? 3 : 2) voi
     }
     return;
   }
-  if constexpr (EPI == EPI_BNSYNC) {
-    static_assert(EPI != EPI_BNSYNC || ES == 2, "the synchronised BatchNorm epilogue is the bf16 throughput path");
-    char* ct = reinterpret_cast<char*>(lds);
-    float* tab = reinterpret_cast<float*>(ct + CT_SLOTS * 16);  // [group][scale | shift][BN]
-    const int rpg = p.rows_per_group;
-    const int m_last = (m0 + A_ROWS < p.M ? m0 + A_ROWS : p.M) - 1;
-    const int g_lo = m0 / rpg;
-    const int ng = m_last / rpg - g_lo + 1;  // <= BNSYNC_MAX_GROUPS (launcher)
-    // 1. every wave's statistics atomics have been performed, then one lane per group signals and waits
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t < ng) {
-      const int g = g_lo + t;
-      const long long first = (long long)g * rpg, last = first + rpg < p.M ? first + rpg - 1 : (long long)p.M - 1;
-      const unsigned expected = (unsigned)(last / A_ROWS - first / A_ROWS + 1);
-      unsigned* ctr = p.arrive + (long long)g * p.tiles_n + tn;
-      __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const long long t0 = wall_clock64();
-      if (p.trace && t == 0) p.trace[4ll * orig + 2] = t0;
-      const int nap = (p.debug >> 2) & 3;  // kernel-study knob: poll interval (production = 0: ~1 us)
-      unsigned polls = 0;
-      while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
-        // poll sparsely: hundreds of tiles wait at any time, and their polls share the memory system with the loads
-        if (nap == 0)
-          __builtin_amdgcn_s_sleep(32);
-        else if (nap == 1)
-          __builtin_amdgcn_s_sleep(4);
-        else if (nap == 2)
-          __builtin_amdgcn_s_sleep(127);
-        else
-          __builtin_amdgcn_s_sleep(12);
-        if ((polls++ & 15u) == 0 &&
-            (wall_clock64() - t0 > p.spin_ticks ||
-             __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-          __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // results of this launch are void
-          break;
-        }
-      }
-    }
-    if (p.trace && t == 0) p.trace[4ll * orig + 3] = wall_clock64();
-    __syncthreads();
-    // 2. folded affine of the tile's groups and columns (the statistics were written by agent-scope atomics only
-    //    and are read by agent-scope loads only)
-    {
-      const float inv_n = 1.f / (float)rpg;
-      for (int i = t; i < ng * BN; i += 256) {
-        const int k = i / BN, cc = i - k * BN;
-        const long long idx = (long long)(g_lo + k) * p.N + n0 + cc;
-        const float s1 = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p.stat_sum) + idx,
-                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        const float s2 = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p.stat_sq) + idx,
-                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        const float mean = s1 * inv_n;
-        const float var = fmaxf(s2 * inv_n - mean * mean, 0.f);
-        const float sc = p.gamma[n0 + cc] / sqrtf(var + p.eps);
-        tab[(2 * k) * BN + cc] = sc;
-        tab[(2 * k + 1) * BN + cc] = p.beta[n0 + cc] - mean * sc;
-      }
-    }
-    __syncthreads();
-    // 3. normalise the accumulators into the bf16 staging tile (ReLU here when there is no residual)
-    const bool relu_now = p.act == AVS_ACT_RELU && p.residual == nullptr;
-    {
-      char* cbase = ct + (wr * 64 + 4 * lh) * CT_PITCH + (wc * WCOLS + lr) * 2;
-      const int rel0 = wr * 64 + 4 * lh;                 // tile-relative row of roff = 0
-      const int b1 = (g_lo + 1) * rpg - m0 - rel0;       // roff at which the tile's 2nd / 3rd / 4th group starts
-      const int b2 = b1 + rpg, b3 = b2 + rpg;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int cc = wc * WCOLS + nt * 32 + lr;
-        if (ng == 1) {
-          const float sc = tab[cc], sf = tab[BN + cc];
-#pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              const int roff = mt * 32 + (e & 3) + 8 * (e >> 2);
-              float v = fmaf(acc[mt][nt][e], sc, sf);
-              if (relu_now) v = fmaxf(v, 0.f);
-              *reinterpret_cast<unsigned short*>(cbase + roff * CT_PITCH + nt * 64) = avs_f32_to_bf16(v);
-            }
-        } else {
-#pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              const int roff = mt * 32 + (e & 3) + 8 * (e >> 2);
-              const int k = (roff >= b1) + (roff >= b2) + (roff >= b3);
-              float v = fmaf(acc[mt][nt][e], tab[(2 * k) * BN + cc], tab[(2 * k + 1) * BN + cc]);
-              if (relu_now) v = fmaxf(v, 0.f);
-              *reinterpret_cast<unsigned short*>(cbase + roff * CT_PITCH + nt * 64) = avs_f32_to_bf16(v);
-            }
-        }
-      }
-    }
-    __syncthreads();
-    // 4. 16-byte row-major stores (+ residual, + ReLU)
-    {
-      const int srow = t / E_CPRW, sch = t - srow * E_CPRW;
-      const char* srcp = ct + srow * CT_PITCH + sch * 16;
-      char* dst = y + ((long long)(m0 + srow) * p.ldc + n0 + sch * 8) * 2;
-      const long long dstep = (long long)E_RSTEP * p.ldc * 2;
-      const bool relu_res = p.act == AVS_ACT_RELU;
-#pragma unroll
-      for (int it = 0; it < E_NIT; ++it) {
-        if (m0 + srow + it * E_RSTEP >= p.M) break;
-        uint4 v = *reinterpret_cast<const uint4*>(srcp + it * E_RSTEP * CT_PITCH);
-        if (p.residual) {
-          unsigned vv[4] = {v.x, v.y, v.z, v.w};
-          const unsigned rv[4] = {resv[it].x, resv[it].y, resv[it].z, resv[it].w};
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float lo = __uint_as_float(vv[j] << 16) + __uint_as_float(rv[j] << 16);
-            float hi = __uint_as_float(vv[j] & 0xffff0000u) + __uint_as_float(rv[j] & 0xffff0000u);
-            if (relu_res) {
-              lo = fmaxf(lo, 0.f);
-              hi = fmaxf(hi, 0.f);
-            }
-            vv[j] = (unsigned)avs_f32_to_bf16(lo) | ((unsigned)avs_f32_to_bf16(hi) << 16);
-          }
-          v = make_uint4(vv[0], vv[1], vv[2], vv[3]);
-        }
-        *reinterpret_cast<uint4*>(dst + it * dstep) = v;
-      }
-    }
-    return;
-  }
   if constexpr (ES == 2) {
     // bf16: through LDS, then 16-byte row-major stores.  Every per-element LDS address is a per-lane base plus
     // a compile-time offset (padded pitch, no swizzle arithmetic): for the short reductions this epilogue,
@@ -950,7 +830,7 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? 3 : 2) voi
     char* dst = y + ((long long)(m0 + srow) * p.ldc + col) * 2;
     const long long dstep = (long long)RSTEP * p.ldc * 2;
     const bool vec_ok = ((p.ldc * 2) % 16 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
-    if (!(p.debug & 1)) {
+    if (!AVS_DEBUG_BIT(p, 1)) {
       if (vec_ok && m0 + A_ROWS <= p.M && n0 + BN <= p.N) {
 #pragma unroll
         for (int it = 0; it < A_ROWS / RSTEP; ++it)
@@ -970,7 +850,9 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? 3 : 2) voi
         }
       }
     }
+    stats_fold();  // behind the barrier above: every wave's column sums are in LDS
   } else {
+    if constexpr (EPI == EPI_STATS) __syncthreads();
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -1000,11 +882,14 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? 3 : 2) voi
           *reinterpret_cast<float*>(y + ((long long)row * p.ldc + col) * 4) = v;
         }
       }
+    stats_fold();
   }
 }
 
+#ifdef AVS_STUDY
 static int g_debug_flags = 0;
 extern "C" void avs_debug_flags(int flags) { g_debug_flags = flags; }
+#endif
 static int g_rowb_threshold_bytes = 2048;  // reductions of at most this many bytes per row use 64-byte steps
 
 extern "C" void avs_tune_short_reduction_bytes(int bytes) { g_rowb_threshold_bytes = bytes; }
@@ -1024,21 +909,7 @@ static int g_pipe3 = 1;  // 1: the 3-buffer hand-counted pipeline for the 64-byt
 extern "C" void avs_tune_pipeline(int enabled) { g_pipe3 = enabled; }
 
 template <int ES, int BN, bool ACC64, bool SP, int ROWB, bool PIPE, int WR, bool FK>
-static void igemm_dispatch_epi4(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p, int* occ) {
-  if constexpr (ES == 2 && WR == 2) {
-    if (epi == EPI_BNSYNC) {
-      // occ != nullptr: report how many workgroups of this variant one CU holds instead of launching it
-      if (occ) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
-                occ, igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BNSYNC, PIPE, WR, FK>, 256, 0) != hipSuccess)
-          *occ = 0;
-      } else {
-        hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BNSYNC, PIPE, WR, FK>), grid, dim3(256), 0, stream,
-                           p);
-      }
-      return;
-    }
-  }
+static void igemm_dispatch_epi4(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p) {
   if constexpr (ES == 2 && WR == 4) {
     if (epi == EPI_BNLOCAL) {
       hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BNLOCAL, PIPE, WR, FK>), grid, dim3(256), 0, stream, p);
@@ -1057,7 +928,7 @@ static void igemm_dispatch_epi4(int epi, dim3 grid, hipStream_t stream, const Ig
 
 
 template <int ES, int BN, bool ACC64, bool SP, int ROWB, bool PIPE, int WR>
-static void igemm_dispatch_epi3(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p, int* occ) {
+static void igemm_dispatch_epi3(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p) {
   constexpr int BKE = ROWB / ES;
   // the buffer window: a tile's rows (at most 256, spread over whole images) plus the tap walk must stay below 2 GiB
   const long long rows = 256;
@@ -1070,40 +941,42 @@ static void igemm_dispatch_epi3(int epi, dim3 grid, hipStream_t stream, const Ig
   const bool window_ok = extent * ES < (1ll << 31) && (long long)BN * p.ldb * ES + (long long)p.K * ES < (1ll << 31) &&
                          p.x_img_stride >= 0 && p.x_row_stride >= 0 && p.x_px_stride >= 0;
   if (g_fastk && window_ok && p.cin % BKE == 0 && p.K % BKE == 0 && p.K / p.cin <= 32 && p.K % p.cin == 0)
-    igemm_dispatch_epi4<ES, BN, ACC64, SP, ROWB, PIPE, WR, true>(epi, grid, stream, p, occ);
+    igemm_dispatch_epi4<ES, BN, ACC64, SP, ROWB, PIPE, WR, true>(epi, grid, stream, p);
   else
-    igemm_dispatch_epi4<ES, BN, ACC64, SP, ROWB, PIPE, WR, false>(epi, grid, stream, p, occ);
+    igemm_dispatch_epi4<ES, BN, ACC64, SP, ROWB, PIPE, WR, false>(epi, grid, stream, p);
 }
 
 template <int ES, int BN, bool ACC64, bool SP, int ROWB, bool PIPE>
-static void igemm_dispatch_epi2(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p, int* occ) {
+static void igemm_dispatch_epi2(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p) {
   if constexpr (ACC64) {
     hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_ANY, false>), grid, dim3(256), 0, stream, p);
   } else {
     if constexpr (ES == 2 && ROWB == 64 && PIPE) {
       if (p.tall) {  // igemm_launch only sets it for the epilogue forms compiled at WR = 4
-        igemm_dispatch_epi3<ES, BN, ACC64, SP, ROWB, PIPE, 4>(epi, grid, stream, p, occ);
+        igemm_dispatch_epi3<ES, BN, ACC64, SP, ROWB, PIPE, 4>(epi, grid, stream, p);
         return;
       }
     }
-    igemm_dispatch_epi3<ES, BN, ACC64, SP, ROWB, PIPE, 2>(epi, grid, stream, p, occ);
+    igemm_dispatch_epi3<ES, BN, ACC64, SP, ROWB, PIPE, 2>(epi, grid, stream, p);
   }
 }
 
 template <int ES, int BN, bool ACC64, bool SP, int ROWB>
-static void igemm_dispatch_epi(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p, int* occ) {
+static void igemm_dispatch_epi(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p) {
   if constexpr (ROWB == 64 && !ACC64) {
     if (g_pipe3 && p.K * ES > 2 * ROWB) {  // at least three steps, else there is nothing to pipeline
-      igemm_dispatch_epi2<ES, BN, ACC64, SP, ROWB, true>(epi, grid, stream, p, occ);
+      igemm_dispatch_epi2<ES, BN, ACC64, SP, ROWB, true>(epi, grid, stream, p);
       return;
     }
   }
-  igemm_dispatch_epi2<ES, BN, ACC64, SP, ROWB, false>(epi, grid, stream, p, occ);
+  igemm_dispatch_epi2<ES, BN, ACC64, SP, ROWB, false>(epi, grid, stream, p);
 }
 
 template <int ES, int BN, bool ACC64>
-static void igemm_dispatch(bool spatial, dim3 grid, hipStream_t stream, const IgemmParams& p, int* occ = nullptr) {
+static void igemm_dispatch(bool spatial, dim3 grid, hipStream_t stream, const IgemmParams& p) {
+#ifdef AVS_STUDY
   const_cast<IgemmParams&>(p).debug = g_debug_flags;
+#endif
   // 64-byte rows: short reductions, the 256-row tiles, and shapes whose channel count fits the scalar tap walk only
   // at the 64-byte step (cin = 96, 160, 288 ... of Inception-v3): the cheaper staging is worth more than the longer step
   const bool fast64_only = g_fastk && p.cin % (64 / ES) == 0 && p.cin % (128 / ES) != 0 && p.K / p.cin <= 32;
@@ -1111,28 +984,26 @@ static void igemm_dispatch(bool spatial, dim3 grid, hipStream_t stream, const Ig
   int epi = EPI_ANY;
   if (p.tile_rows)
     epi = EPI_BNLOCAL;
-  else if (p.arrive)
-    epi = EPI_BNSYNC;
   else if (p.bias_mode == AVS_BIAS_NONE && p.act == AVS_ACT_NONE && p.alpha == 1.0f)
-    epi = p.stat_sum ? EPI_STATS : EPI_PLAIN;
-  else if (p.bias_mode == AVS_BIAS_COL && p.act == AVS_ACT_RELU && p.alpha == 1.0f && !p.stat_sum)
+    epi = p.stat_part ? EPI_STATS : EPI_PLAIN;
+  else if (p.bias_mode == AVS_BIAS_COL && p.act == AVS_ACT_RELU && p.alpha == 1.0f && !p.stat_part)
     epi = EPI_BRELU;
   if (short_k) {
     if (spatial)
-      igemm_dispatch_epi<ES, BN, ACC64, true, 64>(epi, grid, stream, p, occ);
+      igemm_dispatch_epi<ES, BN, ACC64, true, 64>(epi, grid, stream, p);
     else
-      igemm_dispatch_epi<ES, BN, ACC64, false, 64>(epi, grid, stream, p, occ);
+      igemm_dispatch_epi<ES, BN, ACC64, false, 64>(epi, grid, stream, p);
   } else {
     if (spatial)
-      igemm_dispatch_epi<ES, BN, ACC64, true, 128>(epi, grid, stream, p, occ);
+      igemm_dispatch_epi<ES, BN, ACC64, true, 128>(epi, grid, stream, p);
     else
-      igemm_dispatch_epi<ES, BN, ACC64, false, 128>(epi, grid, stream, p, occ);
+      igemm_dispatch_epi<ES, BN, ACC64, false, 128>(epi, grid, stream, p);
   }
 }
 
-// occ != nullptr: validate and select the variant as for a launch, but only report its occupancy (EPI_BNSYNC)
+// plan_only: validate the shape and choose the tile (p.tall, p.tiles_n, *tiles_m_out) as for a launch, launch nothing
 static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream, const char* who,
-                        int* occ = nullptr) {
+                        bool plan_only = false, long long* tiles_m_out = nullptr) {
   const int es = dtype == AVS_BF16 ? 2 : 4;
   const int ce = 16 / es;
   AVS_REQUIRE(dtype == AVS_F32 || dtype == AVS_BF16 || dtype == AVS_F32_ACC64, AVS_E_ARG, "%s: bad dtype %d", who,
@@ -1140,11 +1011,12 @@ static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream
   AVS_REQUIRE(p.M >= 0 && p.N > 0 && p.K > 0 && batch > 0, AVS_E_SHAPE, "%s: bad sizes M=%d N=%d K=%d batch=%d", who,
               p.M, p.N, p.K, batch);
   if (p.M == 0) return AVS_OK;
-  AVS_REQUIRE(occ || (p.x && p.w && p.y), AVS_E_ARG, "%s: null operand", who);
+  AVS_REQUIRE(plan_only || (p.x && p.w && p.y), AVS_E_ARG, "%s: null operand", who);
   AVS_REQUIRE(p.bias_mode == AVS_BIAS_NONE || p.bias, AVS_E_ARG, "%s: bias mode %d without bias", who, p.bias_mode);
   AVS_REQUIRE(p.cin % ce == 0 && p.K % ce == 0, AVS_E_SHAPE,
               "%s: cin=%d / K=%d must be multiples of %d elements (16 bytes)", who, p.cin, p.K, ce);
-  AVS_REQUIRE(avs_aligned16(p.x) && avs_aligned16(p.w), AVS_E_ALIGN, "%s: x / w must be 16-byte aligned", who);
+  AVS_REQUIRE(plan_only || (avs_aligned16(p.x) && avs_aligned16(p.w)), AVS_E_ALIGN, "%s: x / w must be 16-byte aligned",
+              who);
   AVS_REQUIRE((p.x_img_stride * es) % 16 == 0 && (p.x_row_stride * es) % 16 == 0 && (p.x_px_stride * es) % 16 == 0 &&
                   (p.ldb * es) % 16 == 0 && (p.sA * es) % 16 == 0 && (p.sB * es) % 16 == 0,
               AVS_E_ALIGN, "%s: strides must be multiples of 16 bytes", who);
@@ -1158,9 +1030,9 @@ static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream
   // variants are built on the 3-buffer pipeline), and enough rows that the grid still fills the chip several times
   p.tall = 0;
   {
-    const bool fixed_epi = !p.arrive && p.alpha == 1.0f &&
+    const bool fixed_epi = p.alpha == 1.0f &&
                            ((p.bias_mode == AVS_BIAS_NONE && p.act == AVS_ACT_NONE) ||
-                            (p.bias_mode == AVS_BIAS_COL && p.act == AVS_ACT_RELU && !p.stat_sum));
+                            (p.bias_mode == AVS_BIAS_COL && p.act == AVS_ACT_RELU && !p.stat_part));
     const bool can = dtype == AVS_BF16 && fixed_epi && g_pipe3 && (long long)p.K * es > 128 && batch == 1;
     const long long tall_tiles = ((long long)p.M + 255) / 256 * p.tiles_n;
     if (can && (g_tall_mode == 2 || (g_tall_mode == 0 && tall_tiles >= g_tall_min_tiles &&
@@ -1170,13 +1042,10 @@ static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream
   if (p.tile_rows) p.tall = 1;  // EPI_BNLOCAL (validated by bnsync_plan): 256-row tiles at a pitch of tile_rows
   const int tile_rows = p.tile_rows ? p.tile_rows : (p.tall ? 256 : 128);
   const long long tiles_m = ((long long)p.M + tile_rows - 1) / tile_rows;
-  long long total = tiles_m * p.tiles_n;
-  if (p.arrive) {  // EPI_BNSYNC deals eight row tiles per dispatch level: pad the rows of tiles to a multiple of 8
-    p.tiles_m = (int)tiles_m;
-    total = (tiles_m + 7) / 8 * 8 * p.tiles_n;
-  }
+  const long long total = tiles_m * p.tiles_n;
   AVS_REQUIRE(total < (1ll << 31), AVS_E_SHAPE, "%s: too many tiles", who);
-  AVS_REQUIRE(!occ || dtype == AVS_BF16, AVS_E_ARG, "%s: occupancy query is for the bf16 variants", who);
+  if (tiles_m_out) *tiles_m_out = tiles_m;
+  if (plan_only) return AVS_OK;
   // the per-tap bounds tests are only needed when a tap can leave the image
   const bool spatial = !(p.ph == 0 && p.pw == 0 && (p.HoWo / p.Wo - 1) * p.sh + (p.K / (p.cin * p.KW)) - 1 < p.H &&
                          (p.Wo - 1) * p.sw + p.KW - 1 < p.W);
@@ -1191,10 +1060,9 @@ static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream
   dim3 grid((unsigned)total, 1, (unsigned)batch);
   if (dtype == AVS_BF16) {
     if (narrow)
-      igemm_dispatch<2, 64, false>(spatial, grid, stream, p, occ);
+      igemm_dispatch<2, 64, false>(spatial, grid, stream, p);
     else
-      igemm_dispatch<2, 128, false>(spatial, grid, stream, p, occ);
-    if (occ) return AVS_OK;
+      igemm_dispatch<2, 128, false>(spatial, grid, stream, p);
   } else if (dtype == AVS_F32_ACC64) {
     igemm_dispatch<4, 64, true>(spatial, grid, stream, p);
   } else {
@@ -1256,167 +1124,149 @@ extern "C" int avs_conv2d_nhwc(const avs_conv_desc* d, const void* d_x, const vo
   return igemm_launch(d->dtype, p, 1, (hipStream_t)stream, "avs_conv2d_nhwc");
 }
 
-extern "C" int avs_conv2d_nhwc_bnstats(const avs_conv_desc* d, const void* d_x, const void* d_w, void* d_y,
-                                       int64_t rows_per_group, float* d_sum, float* d_sumsq, avs_stream_t stream) {
-  IgemmParams p{};
-  int st = conv_fill_params(d, d_x, d_w, nullptr, d_y, p, "avs_conv2d_nhwc_bnstats");
-  if (st != AVS_OK) return st;
-  AVS_REQUIRE(d->act == AVS_ACT_NONE, AVS_E_ARG, "avs_conv2d_nhwc_bnstats: activation must be none");
-  AVS_REQUIRE(rows_per_group > 0 && rows_per_group < (1ll << 31) && d_sum && d_sumsq, AVS_E_ARG,
-              "avs_conv2d_nhwc_bnstats: bad statistics arguments");
-  if (p.M == 0) return AVS_OK;
-  const long long groups = ((long long)p.M + rows_per_group - 1) / rows_per_group;
-  hipError_t e = hipMemsetAsync(d_sum, 0, sizeof(float) * groups * p.N, (hipStream_t)stream);
-  if (e == hipSuccess) e = hipMemsetAsync(d_sumsq, 0, sizeof(float) * groups * p.N, (hipStream_t)stream);
-  if (e != hipSuccess) {
-    avs_set_error("avs_conv2d_nhwc_bnstats: memset failed: %s", hipGetErrorString(e));
-    return AVS_E_HIP;
-  }
-  p.stat_sum = d_sum;
-  p.stat_sq = d_sumsq;
-  p.rows_per_group = (int)rows_per_group;
-  return igemm_launch(d->dtype, p, 1, (hipStream_t)stream, "avs_conv2d_nhwc_bnstats");
-}
-
-// ---- convolution + whole BatchNorm in one launch (EPI_BNSYNC) ----
-static int g_cu_count = 0;
-static int g_bnlocal = 1;  // 1: groups of <= 256 rows take the tile-local form (EPI_BNLOCAL)
-extern "C" void avs_tune_bnlocal(int enabled) { g_bnlocal = enabled; }
-
-static int bnsync_plan(const avs_conv_desc* d, int64_t rpg, IgemmParams& p, int64_t* ws_bytes, const char* who) {
-  int st = conv_fill_params(d, (const void*)16, (const void*)16, nullptr, (void*)16, p, who);
-  if (st != AVS_OK) return st;
-  AVS_REQUIRE(rpg > 0, AVS_E_ARG, "%s: rows_per_group must be positive", who);
-  if (p.M == 0) {
-    *ws_bytes = 0;
-    return AVS_OK;
-  }
-  const int bn = p.N <= 64 ? 64 : 128;
-  const bool shape_ok = d->dtype == AVS_BF16 && p.N % bn == 0 && p.M % rpg == 0 && rpg < (1ll << 30) &&
-                        (127 + rpg - 1) / rpg + 1 <= BNSYNC_MAX_GROUPS && d->alpha == 1.0f &&
-                        (p.ldc * 2) % 16 == 0;
-  AVS_REQUIRE(shape_ok, AVS_E_UNSUPPORTED,
-              "%s: needs bf16, cout a multiple of %d, equal groups of >= 43 rows, 16-byte aligned output rows", who, bn);
-  p.tiles_n = p.N / bn;
-  // Groups that fit a 256-row tile whole (and fill >= 3/4 of it): statistics inside the tile, no workspace, no waits
-  {
-    const long long per_tile = 256 / rpg;
-    if (g_bnlocal && g_pipe3 && rpg <= 256 && per_tile * rpg * 4 >= 256 * 3 && per_tile <= BNLOCAL_MAX_GROUPS &&
-        (long long)p.K * 2 > 128) {
-      p.tile_rows = (int)(per_tile * rpg);
-      *ws_bytes = 256;  // nothing is kept there; a non-zero size keeps the caller's bookkeeping uniform
-      return AVS_OK;
-    }
-  }
-  // Forward progress: a waiting tile holds its slot, so every tile a wait depends on must get a slot while the
-  // waiters sit.  Blocks are dealt round-robin over the XCDs and started in order; one XCD runs one block of every
-  // dispatch level.  A tile only waits for tiles of its own column tile whose row tiles lie within the 8-tile
-  // blocks its groups touch, i.e. at most `span` levels away.  If an XCD holds S workgroups, a cycle of XCDs
-  // blocked on each other needs span > S - 1; the form is only taken at span <= S / 2 (also what keeps waits short).
-  if (g_cu_count == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      g_cu_count = prop.multiProcessorCount;
-    AVS_REQUIRE(g_cu_count > 0, AVS_E_HIP, "%s: cannot read the CU count", who);
-  }
-  int occ = 0;
-  p.arrive = reinterpret_cast<unsigned*>(16);  // selects the EPI_BNSYNC variant in the dispatch
-  st = igemm_launch(AVS_BF16, p, 1, nullptr, who, &occ);
-  p.arrive = nullptr;
-  if (st != AVS_OK) return st;
-  const long long tiles_per_group = (rpg + 127) / 128 + 1;         // row tiles one group can overlap
-  const long long blocks = (tiles_per_group - 1 + 7) / 8 + 1;      // 8-tile dispatch blocks those can touch
-  const long long span = (blocks - 1) * p.tiles_n;
-  const long long slots_per_xcd = (long long)(g_cu_count / 8) * occ;
-  AVS_REQUIRE(span * 2 <= slots_per_xcd, AVS_E_UNSUPPORTED,
-              "%s: the tiles of a %lld-row group start up to %lld dispatch levels apart, more than half of the %lld "
-              "workgroups an XCD holds", who, (long long)rpg, span, slots_per_xcd);
-  const long long groups = p.M / rpg;
-  *ws_bytes = (int64_t)((8 * groups * p.N + 4 * groups * p.tiles_n + 255) / 256 * 256);
-  return AVS_OK;
-}
-
-extern "C" int64_t avs_conv2d_bnsync_workspace_bytes(const avs_conv_desc* d, int64_t rows_per_group) {
-  IgemmParams p{};
-  int64_t ws = 0;
-  const int st = bnsync_plan(d, rows_per_group, p, &ws, "avs_conv2d_bnsync_workspace_bytes");
-  return st == AVS_OK ? ws : (int64_t)st;
-}
-
-static long long* g_bnsync_trace = nullptr;
-extern "C" void avs_debug_bnsync_trace(void* d_trace) { g_bnsync_trace = (long long*)d_trace; }
-static long long g_bnsync_spin_ticks = 5000000;  // 50 ms of the 100 MHz wall clock
-extern "C" void avs_tune_bnsync_timeout_ticks(int64_t ticks) { g_bnsync_spin_ticks = ticks; }
-
-extern "C" int avs_conv2d_nhwc_bnsync(const avs_conv_desc* d, const void* d_x, const void* d_w, void* d_y,
-                                      int64_t rows_per_group, const float* d_gamma, const float* d_beta, float eps,
-                                      const void* d_residual, int64_t ldr, void* d_ws_zeroed, int64_t ws_bytes,
-                                      int* d_err, avs_stream_t stream) {
-  const char* who = "avs_conv2d_nhwc_bnsync";
-  IgemmParams p{};
-  int64_t need = 0;
-  int st = bnsync_plan(d, rows_per_group, p, &need, who);
-  if (st != AVS_OK) return st;
-  if (p.M == 0) return AVS_OK;
-  AVS_REQUIRE(d_x && d_w && d_y && d_gamma && d_beta && d_ws_zeroed && d_err, AVS_E_ARG, "%s: null pointer", who);
-  AVS_REQUIRE(ws_bytes >= need, AVS_E_WORKSPACE, "%s: workspace %lld < %lld bytes", who, (long long)ws_bytes,
-              (long long)need);
-  AVS_REQUIRE(avs_aligned16(d_ws_zeroed) && avs_aligned16(d_y), AVS_E_ALIGN, "%s: workspace / y must be 16-byte aligned",
-              who);
-  AVS_REQUIRE(!d_residual || (avs_aligned16(d_residual) && (ldr * 2) % 16 == 0 && ldr >= p.N), AVS_E_ALIGN,
-              "%s: residual rows must be 16-byte aligned and at least cout long", who);
-  p.x = (const char*)d_x;
-  p.w = (const char*)d_w;
-  p.y = (char*)d_y;
-  const long long groups = p.M / rows_per_group;
-  if (!p.tile_rows) {  // the synchronised form: statistics and arrival counters in the workspace
-    p.stat_sum = reinterpret_cast<float*>(d_ws_zeroed);
-    p.stat_sq = p.stat_sum + groups * p.N;
-    p.arrive = reinterpret_cast<unsigned*>(p.stat_sq + groups * p.N);
-  }
-  p.rows_per_group = (int)rows_per_group;
-  p.err = d_err;
-  p.gamma = d_gamma;
-  p.beta = d_beta;
-  p.eps = eps;
-  p.residual = (const char*)d_residual;
-  p.ldr = ldr;
-  p.spin_ticks = g_bnsync_spin_ticks;
-  p.trace = g_bnsync_trace;
-  p.bias_mode = AVS_BIAS_NONE;
-  return igemm_launch(AVS_BF16, p, 1, (hipStream_t)stream, who);
-}
-
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sq,
-                                                          long long total, int c, float inv_n,
-                                                          const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float eps,
-                                                          float* __restrict__ scale, float* __restrict__ shift) {
+// ---- convolution + deterministic BatchNorm batch statistics (EPI_STATS) ----
+// One thread per (group, channel): the group's slots are added in row-tile order, then folded into the affine
+//   scale = gamma / sqrt(var + eps), shift = beta - mean * scale   (biased variance, E[y^2] - E[y]^2 on fp32 sums).
+__global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ part, long long total, int c, int slots,
+                                                      int tile_rows, long long rpg, long long rows,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float eps, float* __restrict__ scale, float* __restrict__ shift) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const int ch = (int)(i % c);
-    const float mean = sum[i] * inv_n;
-    const float var = fmaxf(sq[i] * inv_n - mean * mean, 0.f);
+    const long long g = i / c;
+    const int ch = (int)(i - g * c);
+    const long long first = g * rpg, last = (first + rpg < rows ? first + rpg : rows) - 1;
+    float s1 = 0.f, s2 = 0.f;
+    for (long long tl = first / tile_rows; tl <= last / tile_rows; ++tl) {
+      const long long j = g - (tl * tile_rows) / rpg;
+      const float* src = part + ((tl * slots + j) * 2) * c + ch;
+      s1 += src[0];
+      s2 += src[c];
+    }
+    const float inv_n = 1.f / (float)(last - first + 1);
+    const float mean = s1 * inv_n;
+    const float var = fmaxf(s2 * inv_n - mean * mean, 0.f);
     const float sc = gamma[ch] / sqrtf(var + eps);
     scale[i] = sc;
     shift[i] = beta[ch] - mean * sc;
   }
 }
 
-extern "C" int avs_bn_finalize(const float* d_sum, const float* d_sumsq, int groups, int c, int64_t rows_per_group,
-                               const float* d_gamma, const float* d_beta, float eps, float* d_scale, float* d_shift,
-                               avs_stream_t stream) {
-  AVS_REQUIRE(groups >= 0 && c > 0 && rows_per_group > 0, AVS_E_SHAPE, "avs_bn_finalize: bad extents");
-  if (groups == 0) return AVS_OK;
-  AVS_REQUIRE(d_sum && d_sumsq && d_gamma && d_beta && d_scale && d_shift, AVS_E_ARG, "avs_bn_finalize: null pointer");
-  const long long total = (long long)groups * c;
-  long long gx = avs_cdiv(total, 256);
-  if (gx > 4096) gx = 4096;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, d_sum, d_sumsq, total,
-                     c, 1.f / (float)rows_per_group, d_gamma, d_beta, eps, d_scale, d_shift);
-  AVS_CHECK_LAUNCH("avs_bn_finalize");
+static int bnstats_plan(const avs_conv_desc* d, int64_t rpg, IgemmParams& p, int64_t* ws_bytes, int* tile_rows,
+                        const char* who) {
+  AVS_REQUIRE(d != nullptr && (d->dtype == AVS_BF16 || d->dtype == AVS_F32), AVS_E_ARG, "%s: bf16 / fp32 only", who);
+  AVS_REQUIRE(d->act == AVS_ACT_NONE && d->alpha == 1.0f, AVS_E_ARG, "%s: no activation / scaling", who);
+  AVS_REQUIRE(rpg > 0 && rpg < (1ll << 30), AVS_E_ARG, "%s: rows_per_group must be positive", who);
+  AVS_REQUIRE(rpg >= STATS_MIN_GROUP_ROWS, AVS_E_UNSUPPORTED,
+              "%s: groups of fewer than %d rows take the separate statistics pass (avs_bn_batch_stats)", who,
+              STATS_MIN_GROUP_ROWS);
+  long long tiles_m = 0;
+  p.stat_part = reinterpret_cast<float*>(16);  // selects EPI_STATS in the plan (same tile choice as the launch)
+  const int st = igemm_launch(d->dtype, p, 1, nullptr, who, true, &tiles_m);
+  p.stat_part = nullptr;
+  if (st != AVS_OK) return st;
+  *tile_rows = p.tall ? 256 : 128;
+  p.stat_slots = (int)((*tile_rows + rpg - 2) / rpg + 1);
+  *ws_bytes = (int64_t)((tiles_m * p.stat_slots * 2 * p.N * 4 + 255) / 256 * 256);
   return AVS_OK;
+}
+
+extern "C" int64_t avs_conv2d_bnstats_workspace_bytes(const avs_conv_desc* d, int64_t rows_per_group) {
+  const char* who = "avs_conv2d_bnstats_workspace_bytes";
+  IgemmParams p{};
+  int st = conv_fill_params(d, (const void*)16, (const void*)16, nullptr, (void*)16, p, who);
+  if (st != AVS_OK) return st;
+  if (p.M == 0) return 0;
+  int64_t ws = 0;
+  int tile_rows = 0;
+  st = bnstats_plan(d, rows_per_group, p, &ws, &tile_rows, who);
+  return st == AVS_OK ? ws : (int64_t)st;
+}
+
+extern "C" int avs_conv2d_nhwc_bnstats(const avs_conv_desc* d, const void* d_x, const void* d_w, void* d_y,
+                                       int64_t rows_per_group, const float* d_gamma, const float* d_beta, float eps,
+                                       float* d_scale, float* d_shift, void* d_ws, int64_t ws_bytes,
+                                       avs_stream_t stream) {
+  const char* who = "avs_conv2d_nhwc_bnstats";
+  IgemmParams p{};
+  int st = conv_fill_params(d, d_x, d_w, nullptr, d_y, p, who);
+  if (st != AVS_OK) return st;
+  if (p.M == 0) return AVS_OK;
+  int64_t need = 0;
+  int tile_rows = 0;
+  st = bnstats_plan(d, rows_per_group, p, &need, &tile_rows, who);
+  if (st != AVS_OK) return st;
+  AVS_REQUIRE(d_gamma && d_beta && d_scale && d_shift && d_ws, AVS_E_ARG, "%s: null pointer", who);
+  AVS_REQUIRE(ws_bytes >= need, AVS_E_WORKSPACE, "%s: workspace %lld < %lld bytes", who, (long long)ws_bytes,
+              (long long)need);
+  AVS_REQUIRE(avs_aligned16(d_ws), AVS_E_ALIGN, "%s: workspace must be 16-byte aligned", who);
+  p.stat_part = reinterpret_cast<float*>(d_ws);
+  p.rows_per_group = (int)rows_per_group;
+  st = igemm_launch(d->dtype, p, 1, (hipStream_t)stream, who);
+  if (st != AVS_OK) return st;
+  AVS_REQUIRE((p.tall ? 256 : 128) == tile_rows, AVS_E_ARG, "%s: tile choice changed between plan and launch", who);
+  const long long groups = ((long long)p.M + rows_per_group - 1) / rows_per_group;
+  const long long total = groups * p.N;
+  long long gx = avs_cdiv(total, 256);
+  if (gx > 8192) gx = 8192;
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, p.stat_part, total, p.N,
+                     p.stat_slots, tile_rows, (long long)rows_per_group, (long long)p.M, d_gamma, d_beta, eps, d_scale,
+                     d_shift);
+  AVS_CHECK_LAUNCH(who);
+  return AVS_OK;
+}
+
+// ---- convolution + whole BatchNorm in one launch, statistics local to a tile (EPI_BNLOCAL) ----
+static int g_bnlocal = 1;  // 0: the query declines every shape (callers then run the unfused sequence)
+extern "C" void avs_tune_bnlocal(int enabled) { g_bnlocal = enabled; }
+
+static int bnlocal_plan(const avs_conv_desc* d, int64_t rpg, IgemmParams& p, const char* who) {
+  int st = conv_fill_params(d, (const void*)16, (const void*)16, nullptr, (void*)16, p, who);
+  if (st != AVS_OK) return st;
+  AVS_REQUIRE(rpg > 0, AVS_E_ARG, "%s: rows_per_group must be positive", who);
+  if (p.M == 0) return AVS_OK;
+  const int bn = p.N <= 64 ? 64 : 128;
+  const long long per_tile = 256 / rpg;
+  const bool ok = g_bnlocal && g_pipe3 && d->dtype == AVS_BF16 && p.N % bn == 0 && p.M % rpg == 0 && rpg <= 256 &&
+                  per_tile * rpg * 4 >= 256 * 3 && per_tile <= BNLOCAL_MAX_GROUPS && (long long)p.K * 2 > 128 &&
+                  d->alpha == 1.0f && (p.ldc * 2) % 16 == 0;
+  AVS_REQUIRE(ok, AVS_E_UNSUPPORTED,
+              "%s: needs bf16, cout a multiple of %d, equal groups of 43..256 rows that fill 3/4 of a 256-row tile, "
+              "a reduction of more than 128 bytes, 16-byte aligned output rows", who, bn);
+  p.tiles_n = p.N / bn;
+  p.tile_rows = (int)(per_tile * rpg);
+  return AVS_OK;
+}
+
+extern "C" int avs_conv2d_bnlocal_tile_rows(const avs_conv_desc* d, int64_t rows_per_group) {
+  IgemmParams p{};
+  const int st = bnlocal_plan(d, rows_per_group, p, "avs_conv2d_bnlocal_tile_rows");
+  return st == AVS_OK ? p.tile_rows : st;
+}
+
+extern "C" int avs_conv2d_nhwc_bnlocal(const avs_conv_desc* d, const void* d_x, const void* d_w, void* d_y,
+                                       int64_t rows_per_group, const float* d_gamma, const float* d_beta, float eps,
+                                       const void* d_residual, int64_t ldr, avs_stream_t stream) {
+  const char* who = "avs_conv2d_nhwc_bnlocal";
+  IgemmParams p{};
+  int st = bnlocal_plan(d, rows_per_group, p, who);
+  if (st != AVS_OK) return st;
+  if (p.M == 0) return AVS_OK;
+  AVS_REQUIRE(d_x && d_w && d_y && d_gamma && d_beta, AVS_E_ARG, "%s: null pointer", who);
+  AVS_REQUIRE(avs_aligned16(d_y), AVS_E_ALIGN, "%s: y must be 16-byte aligned", who);
+  AVS_REQUIRE(!d_residual || (avs_aligned16(d_residual) && (ldr * 2) % 16 == 0 && ldr >= p.N), AVS_E_ALIGN,
+              "%s: residual rows must be 16-byte aligned and at least cout long", who);
+  p.x = (const char*)d_x;
+  p.w = (const char*)d_w;
+  p.y = (char*)d_y;
+  p.rows_per_group = (int)rows_per_group;
+  p.gamma = d_gamma;
+  p.beta = d_beta;
+  p.eps = eps;
+  p.residual = (const char*)d_residual;
+  p.ldr = ldr;
+  p.bias_mode = AVS_BIAS_NONE;
+  return igemm_launch(AVS_BF16, p, 1, (hipStream_t)stream, who);
 }
 
 extern "C" int avs_gemm_nt(int dtype, int m, int n, int k, const void* d_a, int64_t lda, int64_t stride_a,

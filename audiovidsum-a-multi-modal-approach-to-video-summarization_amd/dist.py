@@ -42,17 +42,19 @@ def shard_videos(lengths, world):
 
 
 def broadcast_module(module, src=0):
-    """C1: weights (parameters and buffers) from rank `src` to every rank."""
+    """C1: weights (parameters and buffers) from rank `src` to every rank.  The copies go through the parameters
+    themselves (not ``.data``), so their version counters move and the kernel-layout weight caches of the runners
+    (keyed on data_ptr + _version) are rebuilt even if a forward ran before the broadcast."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return
     with torch.no_grad():
-        tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
+        tensors = list(module.parameters()) + list(module.buffers())
         # one flat bucket per dtype: few large collectives instead of hundreds of small ones
         by_dtype = {}
         for t in tensors:
             by_dtype.setdefault(t.dtype, []).append(t)
         for _, group in sorted(by_dtype.items(), key=lambda kv: str(kv[0])):
-            flat = torch.cat([t.reshape(-1) for t in group])
+            flat = torch.cat([t.detach().reshape(-1) for t in group])
             dist.broadcast(flat, src)
             o = 0
             for t in group:

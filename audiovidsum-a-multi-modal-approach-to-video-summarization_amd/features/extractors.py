@@ -232,52 +232,97 @@ class AVProcessor:
         return np.array(visual), np.array(audio)
 
     def process_video(self, video_path):
-        """extractors.py:304-362.  Decode, audio demux and shot detection are host-side third-party
-        (cv2, pydub/ffmpeg, PySceneDetect) and outside the GPU hot path."""
-        try:
-            import cv2  # noqa: F401
-            from pydub import AudioSegment  # noqa: F401
-            import scenedetect  # noqa: F401
-        except ImportError as e:
-            raise RuntimeError(
-                f"process_video needs cv2, pydub(ffmpeg) and scenedetect for decoding ({e}); "
-                "use process_decoded(frames, waveform, fps, shots) with decoded input") from e
-        import cv2
+        """extractors.py:304-362: (np[S,4096], np[S,296]) for the shots of one video file.  Decode and audio demux
+        are host-side third-party code (cv2, pydub/ffmpeg: SURVEY row A7); everything after the decoded frames and
+        PCM samples runs on the MI355X."""
         import os
         import shutil
         import tempfile
-        from pydub import AudioSegment
-        from scenedetect import ContentDetector, detect
-
+        try:
+            import cv2
+        except ImportError as e:
+            raise RuntimeError(
+                f"process_video needs cv2 to decode {video_path} ({e}); "
+                "use process_decoded(frames, waveform, fps, shots) with decoded input") from e
         cap = cv2.VideoCapture(video_path)
         fps = cap.get(cv2.CAP_PROP_FPS)
         temp_dir = tempfile.mkdtemp()
         audio_path = os.path.join(temp_dir, "audio.wav")
         try:
             try:
-                seg = AudioSegment.from_file(video_path).set_channels(1).set_frame_rate(16000)
-                seg.export(audio_path, format="wav", bitrate="256k")
+                self._extract_audio(video_path, audio_path)
             except Exception as e:
                 raise RuntimeError(f"Failed to extract audio from {video_path}") from e
             if not os.path.exists(audio_path):
                 raise FileNotFoundError(f"Audio extraction failed for {video_path}")
-            seg = AudioSegment.from_wav(audio_path)
-            samples = np.array(seg.get_array_of_samples(), dtype=np.float32) / float(1 << (8 * seg.sample_width - 1))
-            waveform = samples.reshape(-1, seg.channels).mean(axis=1)
+            waveform = self._load_wav_mono(audio_path)       # torchaudio.load(...).mean(0), extractors.py:326-328
         finally:
             shutil.rmtree(temp_dir, ignore_errors=True)
-        shots = [(s.get_frames(), e.get_frames()) for s, e in detect(video_path, ContentDetector())]
+        shots = self._detect_shots(video_path)
         visual, audio = [], []
         for start, end in shots:
-            frames = []
-            cap.set(cv2.CAP_PROP_POS_FRAMES, start)
-            for i in range(start, end):
-                ret, frame = cap.read()
-                if not ret or len(frames) >= MAX_FRAMES:
-                    break
-                if i % FRAME_INTERVAL == 0:
-                    frames.append(frame)
-            visual.append(self.visual_extractor(frames))
+            visual.append(self.visual_extractor(self._extract_frames(cap, start, end)))
             audio.append(self.audio_extractor(waveform[int(start / fps * self.sr):int(end / fps * self.sr)]))
         cap.release()
         return np.array(visual), np.array(audio)
+
+    @staticmethod
+    def _load_wav_mono(audio_path):
+        """PCM WAV -> float32 [T] in [-1, 1), channel mean (what torchaudio.load + .mean(dim=0) give, :326-328)."""
+        import wave
+        with wave.open(audio_path, "rb") as wf:
+            width, channels = wf.getsampwidth(), wf.getnchannels()
+            raw = wf.readframes(wf.getnframes())
+        if width == 1:      # 8-bit WAV is unsigned
+            pcm = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+        elif width in (2, 4):
+            pcm = np.frombuffer(raw, dtype=np.int16 if width == 2 else np.int32).astype(np.float32) / float(1 << (8 * width - 1))
+        else:
+            raise RuntimeError(f"unsupported WAV sample width {width}")
+        return pcm.reshape(-1, channels).mean(axis=1)
+
+    def _extract_audio(self, video_path, audio_path):
+        """extractors.py:364-386: demux with pydub/ffmpeg -> mono -> 16 kHz -> WAV at audio_path.  Every failure
+        (pydub or ffmpeg missing included) surfaces as RuntimeError("Audio extraction failed: ..."), as there."""
+        try:
+            from pydub import AudioSegment
+            track = AudioSegment.from_file(video_path).set_channels(1).set_frame_rate(16000)
+            track.export(audio_path, format="wav", bitrate="256k")
+            AudioSegment.from_wav(audio_path)   # the reference re-opens the export as its check (:380)
+        except Exception as e:
+            raise RuntimeError(f"Audio extraction failed: {str(e)}")
+
+    def _detect_shots(self, video_path):
+        """extractors.py:388-393: [(start_frame, end_frame)] from PySceneDetect's ContentDetector.  Where
+        PySceneDetect is not installed the same cut rule runs on the MI355X (features/shots.py) over
+        the frames cv2 decodes."""
+        try:
+            from scenedetect import ContentDetector, detect
+        except ImportError:
+            import cv2
+            from .shots import detect_shots
+            cap = cv2.VideoCapture(video_path)
+            frames = []
+            while True:
+                ok, frame = cap.read()
+                if not ok:
+                    break
+                frames.append(_as_bgr_u8(frame))
+            cap.release()
+            return detect_shots(np.stack(frames)) if frames else []
+        return [(a.get_frames(), b.get_frames()) for a, b in detect(video_path, ContentDetector())]
+
+    def _extract_frames(self, cap, start, end):
+        """extractors.py:395-413: seek to `start`, read frames start..end-1, keep those whose ABSOLUTE index is a
+        multiple of 3, stop at a failed read or once 100 are kept; grey / BGRA frames become 3-channel BGR.
+        `cap` is anything with cv2.VideoCapture's set / read."""
+        CAP_PROP_POS_FRAMES = 1   # cv2's constant (cv2 itself is not needed here)
+        cap.set(CAP_PROP_POS_FRAMES, start)
+        frames = []
+        for index in range(start, end):
+            ok, frame = cap.read()
+            if not ok or len(frames) >= MAX_FRAMES:
+                break
+            if index % FRAME_INTERVAL == 0:
+                frames.append(_as_bgr_u8(frame))
+        return frames

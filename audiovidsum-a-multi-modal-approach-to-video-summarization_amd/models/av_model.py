@@ -136,6 +136,11 @@ class AVBiLSTMModel(nn.Module):
                 keep_v = keep_a = torch.ones((t, hidden), dtype=torch.float32, device=v.device)
             scores = ScorerTrainFunction.apply(self, v, a, keep_v, keep_a, *[p for _, p in self.named_parameters()])
             return scores.view(b, t, 1).squeeze()
+        if needs_grad:
+            # eval mode, B > 1, autograd on: the inference path below builds no graph - refuse instead of returning
+            # a tensor whose .backward() would silently do nothing
+            raise NotImplementedError("gradients through AVBiLSTMModel need one sequence per call (B = 1), as the "
+                                      "reference's training loop uses it; wrap inference in torch.no_grad()")
         seq_rows = torch.arange(0, (b + 1) * t, max(t, 1), dtype=torch.int64, device=v.device)[: b + 1] if t > 0 \
             else torch.zeros(b + 1, dtype=torch.int64, device=v.device)
         scores = self.score_rows(v, a, seq_rows, attn_batch=b)

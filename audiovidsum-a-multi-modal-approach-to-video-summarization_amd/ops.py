@@ -11,7 +11,7 @@ from . import _abi
 from ._abi import ACT_NONE, ACT_RELU, AVS_BF16, AVS_F32, BIAS_COL, BIAS_NONE, BIAS_ROW, check, lib
 
 __all__ = [
-    "ACT_NONE", "ACT_RELU", "linear", "gemm_nt_batched", "conv2d", "conv2d_raw", "conv_bnsync_workspace_bytes", "conv1x1_bn", "frames_normalize", "resize_bilinear",
+    "ACT_NONE", "ACT_RELU", "linear", "gemm_nt_batched", "conv2d", "conv2d_raw", "conv_bnlocal_tile_rows", "conv1x1_bn", "frames_normalize", "resize_bilinear",
     "bn_batch_stats", "bn_apply", "bn_maxpool", "pool2d", "global_avgpool", "segment_mean", "hsv_frame_diff", "reflect_pad", "stft_f64", "power_mel",
     "clamp_topdb", "fill", "quantize", "resample", "lstm", "mha_batchaxis", "score_head", "mhsa_flash", "softmax_rows", "cdist", "dtw_path",
     "gather_scale", "dtype_code",
@@ -149,29 +149,43 @@ def linear(x, w, bias=None, act=ACT_NONE, out=None, alpha=1.0):
     return out
 
 
-def conv_bnsync_workspace_bytes(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x_img_stride,
-                                x_row_stride, x_px_stride, w_row_stride, y_px_stride, rows_per_group):
-    """Workspace bytes of the one-launch convolution + BatchNorm (avs_conv2d_nhwc_bnsync) for this shape, or None
-    when the library does not take it in that form (the caller then runs the unfused sequence)."""
+def conv_bnlocal_tile_rows(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x_img_stride,
+                           x_row_stride, x_px_stride, w_row_stride, y_px_stride, rows_per_group):
+    """Rows of a 256-row tile the one-launch convolution + BatchNorm (avs_conv2d_nhwc_bnlocal) uses for this shape,
+    or None when the library does not take it in that form (the caller then runs the unfused sequence)."""
     d = _abi.ConvDesc(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x_img_stride, x_row_stride,
                       x_px_stride, w_row_stride, y_px_stride, ACT_NONE, 1.0)
-    r = lib().avs_conv2d_bnsync_workspace_bytes(ctypes.byref(d), int(rows_per_group))
+    r = lib().avs_conv2d_bnlocal_tile_rows(ctypes.byref(d), int(rows_per_group))
     if r == _abi.E_UNSUPPORTED:
         return None
     if r < 0:
-        check(int(r), "avs_conv2d_bnsync_workspace_bytes")
+        check(int(r), "avs_conv2d_bnlocal_tile_rows")
     return int(r)
+
+
+_stats_ws = {}
+
+
+def _stats_workspace(device, nbytes):
+    """Scratch for the per-tile partial sums of avs_conv2d_nhwc_bnstats: one buffer per device, grown on demand
+    (launches on one stream are ordered, so consecutive layers can share it)."""
+    ws = _stats_ws.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _stats_ws[device] = ws
+    return ws
 
 
 def conv2d_raw(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x, x_img_stride, x_row_stride, x_px_stride,
                wt, w_row_stride, y, y_px_stride, bias=None, act=ACT_NONE, alpha=1.0, x_off=0, y_off=0, algo_k=None,
-               bnstats=None, bnsync=None, algo_in_elems=None):
+               bnstats=None, bnlocal=None, algo_in_elems=None):
     """algo_k: the algorithmic reduction length when it differs from kh*kw*cin (zero-padded stem rows);
     algo_in_elems: input elements the launch reads when the geometry does not say (the re-viewed stem image).
-    bnstats = (rows_per_group, gamma, beta, eps): accumulate the BatchNorm batch statistics of equal-sized row
-    groups in the kernel's epilogue (no bias / activation) and return the folded (scale, shift) [G, cout].
-    bnsync = (rows_per_group, gamma, beta, eps, residual2d | None, workspace uint8 (ZEROED), err int32[1]):
-    the whole BatchNorm (+ residual, then `act`) in the convolution's launch (avs_conv2d_nhwc_bnsync)."""
+    bnstats = (rows_per_group, gamma, beta, eps): the BatchNorm batch statistics of equal-sized row groups from the
+    kernel's epilogue (no bias / activation; deterministic per-tile partial sums); returns the folded
+    (scale, shift) [G, cout], or None when the library declines the shape (groups of < 64 rows).
+    bnlocal = (rows_per_group, gamma, beta, eps, residual2d | None): the whole BatchNorm (+ residual, then `act`) in
+    the convolution's launch (avs_conv2d_nhwc_bnlocal; shapes for which conv_bnlocal_tile_rows is not None)."""
     _dev(x, wt, y, bias)
     d = _abi.ConvDesc(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x_img_stride, x_row_stride,
                       x_px_stride, w_row_stride, y_px_stride, act, float(alpha))
@@ -181,22 +195,20 @@ def conv2d_raw(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x, x_i
     es = 2 if dtype == AVS_BF16 else 4
     touched = algo_in_elems if algo_in_elems is not None else n * (ho * wo if (kh == 1 and kw == 1) else h * w) * cin
     cbytes = float(es) * (touched + n * ho * wo * cout)
-    if bnsync is not None:
-        rpg, gamma, beta, eps, residual, ws, err = bnsync
-        _dev(gamma, beta, residual, ws, err)
+    if bnlocal is not None:
+        rpg, gamma, beta, eps, residual = bnlocal
+        _dev(gamma, beta, residual)
         if bias is not None or bnstats is not None:
             raise ValueError("the one-launch convolution + BatchNorm takes no bias / separate statistics")
         if residual is not None:
             _rowmajor2d(residual, "residual")
             if residual.dtype != y.dtype or residual.shape != (n * ho * wo, cout):
                 raise ValueError("residual must be [rows, cout] in the activation dtype")
-        if err.dtype != torch.int32 or ws.dtype != torch.uint8:
-            raise TypeError("err must be int32, workspace uint8")
         _timed("conv", dtype, flops, lambda: check(
-            lib().avs_conv2d_nhwc_bnsync(ctypes.byref(d), _p(x, x_off), _p(wt), _p(y, y_off), int(rpg), _p(gamma),
-                                         _p(beta), float(eps), _p(residual),
-                                         residual.stride(0) if residual is not None else 0, _p(ws), ws.numel(),
-                                         _p(err), _stream()), "avs_conv2d_nhwc_bnsync"),
+            lib().avs_conv2d_nhwc_bnlocal(ctypes.byref(d), _p(x, x_off), _p(wt), _p(y, y_off), int(rpg), _p(gamma),
+                                          _p(beta), float(eps), _p(residual),
+                                          residual.stride(0) if residual is not None else 0, _stream()),
+            "avs_conv2d_nhwc_bnlocal"),
                cbytes + (float(es) * n * ho * wo * cout if residual is not None else 0.0))
         return None
     if bnstats is None:
@@ -209,15 +221,18 @@ def conv2d_raw(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x, x_i
         raise ValueError("the fused-statistics convolution takes no bias / activation")
     rows = n * ho * wo
     groups = (rows + rpg - 1) // rpg
-    ssum = torch.empty((groups, cout), dtype=torch.float32, device=x.device)
-    ssq = torch.empty((groups, cout), dtype=torch.float32, device=x.device)
-    _timed("conv", dtype, flops, lambda: check(
-        lib().avs_conv2d_nhwc_bnstats(ctypes.byref(d), _p(x, x_off), _p(wt), _p(y, y_off), rpg, _p(ssum), _p(ssq),
-                                      _stream()), "avs_conv2d_nhwc_bnstats"), cbytes)
+    need = lib().avs_conv2d_bnstats_workspace_bytes(ctypes.byref(d), int(rpg))
+    if need == _abi.E_UNSUPPORTED:
+        return None
+    if need < 0:
+        check(int(need), "avs_conv2d_bnstats_workspace_bytes")
+    ws = _stats_workspace(x.device, need)
     scale = torch.empty((groups, cout), dtype=torch.float32, device=x.device)
     shift = torch.empty((groups, cout), dtype=torch.float32, device=x.device)
-    check(lib().avs_bn_finalize(_p(ssum), _p(ssq), groups, cout, rpg, _p(gamma), _p(beta), float(eps), _p(scale),
-                                _p(shift), _stream()), "avs_bn_finalize")
+    _timed("conv", dtype, flops, lambda: check(
+        lib().avs_conv2d_nhwc_bnstats(ctypes.byref(d), _p(x, x_off), _p(wt), _p(y, y_off), int(rpg), _p(gamma),
+                                      _p(beta), float(eps), _p(scale), _p(shift), _p(ws), ws.numel(), _stream()),
+        "avs_conv2d_nhwc_bnstats"), cbytes)
     return scale, shift
 
 

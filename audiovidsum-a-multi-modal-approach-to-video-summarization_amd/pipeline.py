@@ -62,9 +62,8 @@ class FrameScoringPipeline:
                 sets.append((r, np.concatenate(tails)))
         return sets
 
-    def embed(self, frames_u8, video_offsets, check=True):
-        """uint8 [N,224,224,3] on device -> fp32 [N,4096] (ResNet-50 | Inception-v3 halves).
-        check=False leaves the time-out poll of the one-launch convolution + BatchNorm (a host sync) to the caller."""
+    def embed(self, frames_u8, video_offsets):
+        """uint8 [N,224,224,3] on device -> fp32 [N,4096] (ResNet-50 | Inception-v3 halves)."""
         n = frames_u8.shape[0]
         dev = frames_u8.device
         visual = torch.zeros((n, 4096), dtype=torch.float32, device=dev)
@@ -83,42 +82,25 @@ class FrameScoringPipeline:
                     if not self.use_inception:
                         out[:, 2048:].zero_()
                 groups = torch.arange(0, b - a + 1, gsz, dtype=torch.int64)
-                self.visual._resnet_runner.forward(chunk, groups, out=out[:, :2048], check=False)
+                self.visual._resnet_runner.forward(chunk, groups, out=out[:, :2048])
                 if self.use_inception:
                     big = ops.resize_bilinear(chunk, 299, 299)
                     self.visual._inception_runner.forward(big, out=out[:, 2048:])
                 if not contiguous:
                     visual.index_copy_(0, idx, out)
-        if check and self._sync_timed_out():
-            return self.embed(frames_u8, video_offsets, check)
         return visual
-
-    def _sync_timed_out(self):
-        """A group wait of the one-launch convolution + BatchNorm timed out somewhere in this batch (its results are
-        void): never silently wrong - switch the runner to the two-pass path; the caller redoes the batch."""
-        runner = self.visual._resnet_runner
-        if not runner.sync_failed():
-            return False
-        import warnings
-        warnings.warn("avsum_amd: a BatchNorm group wait timed out on the device; recomputing the batch on the "
-                      "two-pass path")
-        runner.bn_sync = False
-        return True
 
     @torch.no_grad()
     def score(self, frames_u8, video_offsets, audio_rows=None):
         """Per-frame importance scores fp32 [N] for videos given as frame offsets [V+1]."""
         video_offsets = [int(v) for v in video_offsets]
-        visual = self.embed(frames_u8, video_offsets, check=False)
+        visual = self.embed(frames_u8, video_offsets)
         if audio_rows is None:
             # AudioFeatureExtractor.forward literally returns zeros(296) (SURVEY Q5)
             audio_rows = torch.zeros((visual.shape[0], self.scorer.audio_fc[0].in_features), dtype=torch.float32,
                                      device=visual.device)
         seq = torch.tensor(video_offsets, dtype=torch.int64, device=visual.device)
-        scores = self.scorer.score_rows(visual, audio_rows, seq, attn_batch=1)
-        if self._sync_timed_out():  # polled after the scorer has been queued: the host sync costs nothing extra
-            return self.score(frames_u8, video_offsets, audio_rows)
-        return scores
+        return self.scorer.score_rows(visual, audio_rows, seq, attn_batch=1)
 
     @staticmethod
     def select(scores, video_offsets):

@@ -17,15 +17,15 @@ from ..models.av_model import AVBiLSTMModel
 from ..utils.alignments import align_shots_to_annotations
 
 
-def train_step(model, optimizer, features, frame_scores):
+def train_step(model, optimizer, features, frame_scores, device="cuda"):
     """Lines 72-96 of the reference for one (features, frame_scores) item.  Returns the loss value."""
     num_shots = features["visual"].shape[0]
     shot_scores = align_shots_to_annotations(shot_boundaries=[(0, num_shots)], annotations=frame_scores.numpy(),
                                              fps=30)
-    visual = features["visual"].unsqueeze(0).cuda()
-    audio = features["audio"].unsqueeze(0).cuda()
+    visual = features["visual"].unsqueeze(0).to(device)
+    audio = features["audio"].unsqueeze(0).to(device)
     preds = model(visual, audio)
-    loss = F.mse_loss(preds, shot_scores.cuda().float())
+    loss = F.mse_loss(preds, shot_scores.to(device).float())
     optimizer.zero_grad()
     loss.backward()
     avd.allreduce_gradients(model)
@@ -33,14 +33,28 @@ def train_step(model, optimizer, features, frame_scores):
     return float(loss.item())
 
 
-def train_on_dataset(dataset, epochs=100, lr=1e-4, model=None, on_step=None):
-    loader = DataLoader(dataset, batch_size=8, shuffle=True, collate_fn=lambda x: x[0])
-    model = (model or AVBiLSTMModel()).cuda()
+def train_on_dataset(dataset, epochs=100, lr=1e-4, model=None, on_step=None, device="cuda"):
+    """One process: the reference's loop exactly (its DataLoader, its global-RNG shuffle, item 0 of every batch of 8).
+    With torch.distributed initialised (one process per GPU) it is data-parallel over that loop: rank 0's weights are
+    broadcast first (C1), every rank draws the SAME shuffled batches of 8 (the shuffle seed comes from rank 0) and
+    takes item `rank` of each (rank 0 the item the reference would take), gradients are averaged (C3) before every
+    AdamW step - so the replicas and their optimiser states stay identical."""
+    import torch.distributed as tdist
+    model = (model or AVBiLSTMModel()).to(device)
+    rank, world, gen = 0, 1, None
+    if tdist.is_initialized() and tdist.get_world_size() > 1:
+        rank, world = tdist.get_rank(), tdist.get_world_size()
+        avd.broadcast_module(model, 0)
+        seed = torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int64).to(device)
+        tdist.broadcast(seed, 0)
+        gen = torch.Generator().manual_seed(int(seed.item()))
+    loader = DataLoader(dataset, batch_size=8, shuffle=True, generator=gen,
+                        collate_fn=lambda items: items[rank % len(items)])
     optimizer = torch.optim.AdamW(model.parameters(), lr=lr)
     for _ in range(epochs):
         model.train()
         for features, frame_scores in loader:
-            loss = train_step(model, optimizer, features, frame_scores)
+            loss = train_step(model, optimizer, features, frame_scores, device)
             if on_step is not None:
                 on_step(loss)
     return model

@@ -108,8 +108,8 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--profile-every", type=int, default=1,
                     help="bracket every n-th launch of each kernel kind with HIP events (1 = all: ~3%% slower)")
-    ap.add_argument("--bn-sync", default="auto", choices=["auto", "on", "off"],
-                    help="tuning: one-launch convolution + BatchNorm (auto = the runner's per-layer choice)")
+    ap.add_argument("--bn-local", default="on", choices=["on", "off"],
+                    help="tuning: one-launch tile-local convolution + BatchNorm on the layers that take it")
     ap.add_argument("--short-k-bytes", type=int, default=None, help="tuning: avs_tune_short_reduction_bytes")
     ap.add_argument("--tall", default=None, help="tuning: mode[,min_tiles[,min_k_bytes]] of avs_tune_tall_tiles")
     ap.add_argument("--fuse", default=None, help="tuning: min_rows,ratio_num,ratio_den of the one-kernel conv+BN")
@@ -146,8 +146,7 @@ def main():
         sd_cpu = ({k: v.clone() for k, v in extractor.resnet.state_dict().items()},
                   {k: v.clone() for k, v in scorer.state_dict().items()},
                   {k: v.clone() for k, v in extractor.inception.state_dict().items()} if use_inception else None)
-    if args.bn_sync != "auto":
-        extractor._resnet_runner.bn_sync = args.bn_sync == "on"
+    extractor._resnet_runner.bn_local = args.bn_local == "on"
     if args.fuse is not None:
         r = extractor._resnet_runner
         r.fuse_min_rows, r.fuse_ratio_num, r.fuse_ratio_den = [int(v) for v in args.fuse.split(",")]
@@ -231,7 +230,7 @@ def main():
                         traffic = json.load(open(PMC_TRAFFIC_FILE)).get("igemm_kernel", {}).get("hbm_bytes_per_launch")
                     except (OSError, ValueError):
                         traffic = None
-                roofline = {"bound": "mfma", "kernel": "igemm_kernel (avs_conv2d_nhwc[_bnstats|_bnsync])",
+                roofline = {"bound": "mfma", "kernel": "igemm_kernel (avs_conv2d_nhwc[_bnstats|_bnlocal])",
                             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                             "frac": round(achieved / peak, 4), "traffic": traffic,
                             "launches": prof.seen.get(("conv", code), conv["launches"]),

@@ -86,51 +86,44 @@ typedef struct {
 int avs_conv2d_nhwc(const avs_conv_desc* desc, const void* d_x, const void* d_w,
                     const float* d_bias, void* d_y, avs_stream_t stream);
 
-/* The same convolution (no bias, no activation) that also accumulates BatchNorm batch statistics in its
- * epilogue: for every group g = output_row / rows_per_group (equal-sized micro-batch groups) and channel c,
- * d_sum[g,c] += y and d_sumsq[g,c] += y*y over the group's rows (values as stored; the two buffers are
- * zeroed on the stream first).  avs_bn_finalize turns them into the folded affine of avs_bn_batch_stats.
- * Saves the separate read pass of avs_bn_batch_stats (features/extractors.py:65, train-mode BN).            */
+/* The same convolution (no bias, no activation) that also produces the BatchNorm batch statistics of its output
+ * in its epilogue and folds them into the affine of avs_bn_batch_stats: for every group g = output_row /
+ * rows_per_group (equal-sized micro-batch groups; a shorter last group is allowed) and channel c,
+ *   d_scale[g,c] = gamma[c] / sqrt(var + eps),  d_shift[g,c] = beta[c] - mean * d_scale[g,c],
+ * mean / biased variance of the group's rows (fp32 accumulators, before the output is rounded).  DETERMINISTIC:
+ * every row tile stores its column sums into its own slots of the workspace (no atomics) and a second small
+ * kernel adds a group's slots in tile order.  Saves the separate read pass of avs_bn_batch_stats
+ * (features/extractors.py:29,65: the ResNet trunk's train-mode BatchNorm).
+ * avs_conv2d_bnstats_workspace_bytes: bytes of d_ws (uninitialised, 16-byte aligned) for this shape, or
+ * AVS_E_UNSUPPORTED when rows_per_group < 64 (use avs_bn_batch_stats then).                                   */
+int64_t avs_conv2d_bnstats_workspace_bytes(const avs_conv_desc* desc, int64_t rows_per_group);
 int avs_conv2d_nhwc_bnstats(const avs_conv_desc* desc, const void* d_x, const void* d_w, void* d_y,
-                            int64_t rows_per_group, float* d_sum, float* d_sumsq, avs_stream_t stream);
-int avs_bn_finalize(const float* d_sum, const float* d_sumsq, int groups, int c, int64_t rows_per_group,
-                    const float* d_gamma, const float* d_beta, float eps, float* d_scale, float* d_shift,
-                    avs_stream_t stream);
+                            int64_t rows_per_group, const float* d_gamma, const float* d_beta, float eps,
+                            float* d_scale, float* d_shift, void* d_ws, int64_t ws_bytes, avs_stream_t stream);
 
-/* Convolution + the WHOLE batch-statistics BatchNorm (+ residual, + ReLU) in one launch, bf16, equal-sized groups:
+/* Convolution + the WHOLE batch-statistics BatchNorm (+ residual, + ReLU) in one launch, bf16, for equal-sized
+ * groups that fit a 256-row output tile whole:
  *   y[m,:] = act( bn_g(conv(x)[m,:]) + residual[m,:] ),  g = m / rows_per_group,  act = desc->act.
- * Every output tile adds its column sums to the group statistics, signals a per-group arrival counter, waits
- * (accumulators in registers) until the group's other tiles have arrived, then normalises and stores: one read of
- * x, one write of y, nothing raw in HBM.  Replaces avs_conv2d_nhwc_bnstats + avs_bn_finalize + avs_bn_apply for
- * the train-mode ResNet trunk (features/extractors.py:29,65).
- * avs_conv2d_bnsync_workspace_bytes returns the workspace size (the caller ZEROES it on the stream before every
- * call) or AVS_E_UNSUPPORTED when the shape cannot take this form: not bf16; cout not a multiple of the column
- * tile; groups of fewer than 43 rows; or a group so long that its tiles would not be co-resident several times
- * over (the wait needs them to be) — use the unfused sequence then.  d_err is a device int the caller zeroes once:
- * a wait that exceeds the time-out sets it to 1 instead of hanging, and the results of every launch since are void.*/
-int64_t avs_conv2d_bnsync_workspace_bytes(const avs_conv_desc* desc, int64_t rows_per_group);
-int avs_conv2d_nhwc_bnsync(const avs_conv_desc* desc, const void* d_x, const void* d_w, void* d_y,
-                           int64_t rows_per_group, const float* d_gamma, const float* d_beta, float eps,
-                           const void* d_residual, int64_t ldr, void* d_ws_zeroed, int64_t ws_bytes,
-                           int* d_err, avs_stream_t stream);
-/* Groups of at most 256 rows that fill >= 3/4 of a 256-row tile (per-frame 14x14 / 7x7 maps) take a tile-LOCAL form
- * of the same entry point instead: a tile holds whole groups, the statistics are sums over its own accumulators, and
- * there is no traffic between workgroups at all (no atomics, no waits, deterministic; the workspace is unused).
- * Tuning knob: 0 switches that form off (every supported shape then takes the synchronised form).              */
+ * A tile holds floor(256 / rows_per_group) whole groups, so a group's statistics are sums over that tile's own
+ * accumulators: no traffic between workgroups, no atomics, deterministic; one read of x, one write of y, nothing
+ * raw in HBM.  Replaces avs_conv2d_nhwc_bnstats + avs_bn_apply for the 14x14 / 7x7 layers of the train-mode
+ * ResNet trunk (features/extractors.py:29,65).
+ * avs_conv2d_bnlocal_tile_rows returns the rows of a tile that are used (> 0) when the shape takes this form, or
+ * AVS_E_UNSUPPORTED: not bf16; cout not a multiple of the column tile; groups of fewer than 43 or more than 256
+ * rows or filling less than 3/4 of a tile; a reduction of at most 128 bytes; unaligned output rows.          */
+int avs_conv2d_bnlocal_tile_rows(const avs_conv_desc* desc, int64_t rows_per_group);
+int avs_conv2d_nhwc_bnlocal(const avs_conv_desc* desc, const void* d_x, const void* d_w, void* d_y,
+                            int64_t rows_per_group, const float* d_gamma, const float* d_beta, float eps,
+                            const void* d_residual, int64_t ldr, avs_stream_t stream);
+/* Tuning knob: 0 makes avs_conv2d_bnlocal_tile_rows decline every shape.                                      */
 void avs_tune_bnlocal(int enabled);
-/* Tuning knob: time-out of the group wait in ticks of the 100 MHz device wall clock (default 5 000 000 = 50 ms). */
-void avs_tune_bnsync_timeout_ticks(int64_t ticks);
-
-/* Kernel study only (tools/): when non-NULL, every block of avs_conv2d_nhwc_bnsync writes four int64 to
- * d_trace[4*block ..]: XCC id, start, arrival, end of wait (100 MHz wall-clock ticks).  NULL (default) = off. */
-void avs_debug_bnsync_trace(void* d_trace);
 
 /* 1x1 convolution + batch-statistics BatchNorm (+ residual, + ReLU) in one kernel, bf16, for equal-sized
  * groups of rows_per_group consecutive rows (a micro-batch of frames at one resolution):
  *   y[m,:] = act( bn_g(x[m,:] . w^T) + residual[m,:] ),  statistics of group g = m / rows_per_group.
  * One workgroup owns a whole group for a slab of channels and walks it twice (statistics, then the
  * normalised output), so the raw convolution never goes to HBM: replaces avs_conv2d_nhwc_bnstats +
- * avs_bn_finalize + avs_bn_apply for the 1x1 layers of the train-mode ResNet trunk
+ * avs_bn_apply for the 1x1 layers of the train-mode ResNet trunk
  * (features/extractors.py:65).  x rows at stride lin_stride; k, n and strides multiples of 8 elements.    */
 int avs_conv1x1_bn_bf16(const void* d_x, int64_t lin_stride, int k, const void* d_w, int64_t ldb, int n,
                         int64_t rows_per_group, int groups, const float* d_gamma, const float* d_beta,
@@ -141,7 +134,7 @@ int avs_conv1x1_bn_bf16(const void* d_x, int64_t lin_stride, int k, const void* 
  * on the way in,  a[m,k] = bf16( relu( x[m,k] * d_in_scale[g,k] + d_in_shift[g,k] ) )  (avs_bn_apply's arithmetic:
  * bit-identical to running avs_bn_apply on x first), so the previous layer needs no apply pass at all: the
  * conv2 -> bn2 -> relu -> conv3 -> bn3 -> +identity -> relu tail of a ResNet bottleneck in two launches.
- * d_in_scale / d_in_shift are [groups, k] fp32 (avs_bn_finalize output); k <= 512 (else AVS_E_UNSUPPORTED).                      */
+ * d_in_scale / d_in_shift are [groups, k] fp32 (avs_conv2d_nhwc_bnstats output); k <= 512 (else AVS_E_UNSUPPORTED).                      */
 int avs_conv1x1_bn_in_bf16(const void* d_x, int64_t lin_stride, int k, const float* d_in_scale,
                            const float* d_in_shift, const void* d_w, int64_t ldb, int n,
                            int64_t rows_per_group, int groups, const float* d_gamma, const float* d_beta,
@@ -165,9 +158,8 @@ void avs_tune_tall_tiles(int mode, int64_t min_tiles, int64_t min_k_bytes);
  * multiple of one reduction step and the kernel has at most 32 taps); the general staging code then serves every
  * shape.  Default on.                                                                                        */
 void avs_tune_fast_staging(int enabled);
-/* Kernel-study ablation switches for the contraction kernel (0 = production): bit 0 skips the output
- * stores, bit 1 skips the operand loads.  Results are wrong while set; tools/ only.                       */
-void avs_debug_flags(int flags);
+/* (The kernel-study build, `make study` -> lib/libavsum_hip_study.so, additionally exports
+ * void avs_debug_flags(int): ablation switches for tools/; the shipped library has no such code paths.)     */
 
 /* Batched C[b] = act(alpha * A[b] . B[b]^T + bias):  A [M,K] (row stride lda),
  * B [N,K] (row stride ldb; the nn.Linear weight layout), C [M,N] (ldc).

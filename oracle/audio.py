@@ -9,7 +9,7 @@ and is not version-pinned anywhere (no requirements file): torchaudio
 create_dct).  Its published algorithm is restated here in torchaudio's own
 float32 op order.  The reference holds no fixtures for
 it => PARITY UNPINNED for the torchaudio-defined numbers; what pins this file
-are analytic known-answer tests (tests/test_oracle_audio.py: single-bin sine,
+are analytic known-answer tests (tests/test_oracle_analytic.py: single-bin sine,
 Parseval, filterbank structure 4 empty filters / 394 non-zeros / <= 2 filters
 per bin, DCT orthonormality) and the reference call sites' shapes.
 """

@@ -15,7 +15,7 @@ version-pinned: torchvision.models.resnet50 / inception_v3):
 cv2.resize is absent too; `cv_resize_linear_u8` restates OpenCV's 8-bit
 INTER_LINEAR (11-bit fixed point).  PARITY UNPINNED for everything third-party
 here: the reference holds no fixtures and its pretrained weights are not
-available offline.  Pins: tests/test_oracle_cnn.py checks FLOP/parameter
+available offline.  Pins: tests/test_oracle_analytic.py checks FLOP/parameter
 counts (23 508 032 / 21 785 568 parameters), BN batch-stat identities, and
 torch's own nn.BatchNorm2d(train) / F.conv2d as the arithmetic reference.
 """

@@ -7,9 +7,12 @@
                            exact DTW over the cost matrix with fastdtw's documented recursion and
                            tie order (i-1,j), (i,j-1), (i-1,j-1) (third-party fastdtw, absent and
                            unpinned => PARITY UNPINNED; pinned by brute-force path enumeration on
-                           small matrices in tests/test_oracle_fusion.py)
+                           small matrices in tests/test_oracle_pins.py::test_dtw_path_is_optimal_bruteforce)
   * interpolate_features   features/fusion.py:21-32 (pinned against the reference function itself,
                            imported with a stub `fastdtw` module, in tests/test_oracle_pins.py)
+  * align_features         features/extractors.py:248-290 (AudioFeatureExtractor._align_features) with the
+                           fastdtw call (which raises and falls back to zeros in the reference)
+                           restated as its intent: exact DTW on the Euclidean cost matrix; PARITY UNPINNED
 """
 import numpy as np
 import torch
@@ -67,3 +70,23 @@ def interpolate_features(features, path, target_length):
     weights = counts / counts.sum()
     aligned = [features[idx] * weight for idx, weight in zip(unique_indices, weights)]
     return torch.stack(aligned)[:target_length]
+
+
+def align_features(mfcc, mel, vggish):
+    """features/extractors.py:248-290: atleast_2d, empty -> zeros(128); truncate the three streams to the common
+    feature dimension and the common length; warp mfcc and mel onto vggish: rows feat[p[1]] along the path."""
+    vggish, mfcc, mel = np.atleast_2d(vggish), np.atleast_2d(mfcc), np.atleast_2d(mel)
+    if vggish.size == 0 or mfcc.size == 0 or mel.size == 0:
+        return np.zeros(128), np.zeros(128)
+    dim = min(vggish.shape[1], mfcc.shape[1], mel.shape[1])
+    vggish, mfcc, mel = vggish[:, :dim], mfcc[:, :dim], mel[:, :dim]
+    length = min(vggish.shape[0], mfcc.shape[0], mel.shape[0])
+    if length == 0:
+        return np.zeros(dim), np.zeros(dim)
+    vggish, mfcc, mel = vggish[:length], mfcc[:length], mel[:length]
+    out = []
+    for feat in (mfcc, mel):
+        cost = cdist(np.asarray(vggish, dtype=np.float32), np.asarray(feat, dtype=np.float32), metric="euclidean")
+        path = dtw_path(cost)[1]
+        out.append(np.array([feat[j] for _, j in path]))
+    return out[0], out[1]

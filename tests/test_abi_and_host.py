@@ -188,3 +188,67 @@ def test_audio_constants_match_oracle_formulas():
     assert b.shape == (402, 400)
     w = torch.hann_window(400).double().numpy()
     assert np.abs(b[0] - w).max() < 1e-12 and np.abs(b[201]).max() == 0  # k=0: cos=1, sin=0
+
+
+class _FakeCapture:
+    """Stands in for cv2.VideoCapture: frame i is filled with the value i; reads fail past `total`."""
+
+    def __init__(self, total, shape=(4, 4, 3)):
+        self.total, self.shape, self.pos, self.sets = total, shape, 0, []
+
+    def set(self, prop, value):
+        self.sets.append((prop, value))
+        self.pos = int(value)
+        return True
+
+    def read(self):
+        if self.pos >= self.total:
+            return False, None
+        frame = np.full(self.shape, self.pos % 256, dtype=np.uint8)
+        self.pos += 1
+        return True, frame
+
+
+def test_avprocessor_extract_frames_follows_the_reference_rule():
+    """AVProcessor._extract_frames (features/extractors.py:395-413): seek, absolute index % 3, <= 100 frames, stop at
+    a failed read, 1-/4-channel frames forced to 3 channels."""
+    from avsum_amd.features.extractors import AVProcessor, sample_shot_indices
+    extract = AVProcessor._extract_frames
+    cap = _FakeCapture(1000)
+    got = extract(None, cap, 4, 20)
+    assert cap.sets == [(1, 4)]                                   # cv2.CAP_PROP_POS_FRAMES == 1
+    assert [int(f[0, 0, 0]) for f in got] == [6, 9, 12, 15, 18] == sample_shot_indices(4, 20)
+    assert all(f.shape == (4, 4, 3) and f.dtype == np.uint8 for f in got)
+    assert len(extract(None, _FakeCapture(1000), 0, 1000)) == 100  # max_frames
+    assert [int(f[0, 0, 0]) for f in extract(None, _FakeCapture(8), 3, 50)] == [3, 6]   # the video ends at frame 8
+    assert extract(None, _FakeCapture(10), 5, 5) == []
+    grey = extract(None, _FakeCapture(4, (4, 4, 1)), 0, 4)
+    assert grey[0].shape == (4, 4, 3) and (grey[1] == 3).all()
+    assert extract(None, _FakeCapture(4, (4, 4, 4)), 0, 1)[0].shape == (4, 4, 3)
+
+
+def test_avprocessor_audio_boundary_errors_and_wav_reader(tmp_path):
+    """_extract_audio wraps every failure as the reference does (:385-386: RuntimeError 'Audio extraction failed');
+    the WAV reader reproduces torchaudio.load(...).mean(0) for PCM16 (:326-328)."""
+    import wave
+    from avsum_amd.features.extractors import AVProcessor
+    with pytest.raises(RuntimeError, match="Audio extraction failed"):
+        AVProcessor._extract_audio(None, str(tmp_path / "missing.mp4"), str(tmp_path / "a.wav"))
+    pcm = (np.arange(-8, 8, dtype=np.int16) * 1000).reshape(-1, 2)       # 8 stereo frames
+    path = str(tmp_path / "s.wav")
+    with wave.open(path, "wb") as wf:
+        wf.setnchannels(2)
+        wf.setsampwidth(2)
+        wf.setframerate(16000)
+        wf.writeframes(pcm.tobytes())
+    got = AVProcessor._load_wav_mono(path)
+    assert got.dtype == np.float32 and np.array_equal(got, (pcm.astype(np.float32) / 32768.0).mean(axis=1))
+
+
+def test_avprocessor_has_the_reference_surface():
+    """the drop-in surface of features/extractors.py:298-413."""
+    import inspect
+    from avsum_amd.features.extractors import AVProcessor
+    for name, params in (("process_video", ["self", "video_path"]), ("_extract_audio", ["self", "video_path", "audio_path"]),
+                         ("_detect_shots", ["self", "video_path"]), ("_extract_frames", ["self", "cap", "start", "end"])):
+        assert list(inspect.signature(getattr(AVProcessor, name)).parameters) == params

@@ -169,10 +169,11 @@ def test_conv2d_bf16_tall_tiles(dev, cfg):
         ho, wo = (h + 2 * ph - kh) // stride + 1, (w + 2 * pw - kw) // stride + 1
         gamma, beta = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
         tall = torch.empty((n, ho, wo, cout), dtype=torch.bfloat16, device=dev)
-        sc_t, sh_t = ops.conv2d(x, wk, kh, kw, stride, pad, tall, bnstats=(ho * wo, gamma, beta, 1e-5))
+        rpg = max(64, ho * wo)  # groups of fewer than 64 rows are declined by the fused-statistics form
+        sc_t, sh_t = ops.conv2d(x, wk, kh, kw, stride, pad, tall, bnstats=(rpg, gamma, beta, 1e-5))
         L.avs_tune_tall_tiles(1, 0, -1)
         base = torch.empty_like(tall)
-        sc_b, sh_b = ops.conv2d(x, wk, kh, kw, stride, pad, base, bnstats=(ho * wo, gamma, beta, 1e-5))
+        sc_b, sh_b = ops.conv2d(x, wk, kh, kw, stride, pad, base, bnstats=(rpg, gamma, beta, 1e-5))
         assert torch.equal(tall, base)          # same products, same k order per output element
         assert (sc_t - sc_b).abs().max().item() < 2e-3 * sc_b.abs().max().item()
         assert (sh_t - sh_b).abs().max().item() < 2e-3 * max(1.0, sh_b.abs().max().item())
@@ -486,13 +487,12 @@ def test_empty_and_degenerate_inputs(dev):
     sc = torch.ones((1, 64), device=dev)
     assert ops.bn_maxpool(x, sc, sc, None, True, 3, 2, 1, y).shape == (0, 7, 7, 64)
     geom, xs = (0, 14, 14, 64, 1, 1, 1, 1, 0, 0, 14, 14, 64), (14 * 14 * 64, 14 * 64, 64)
-    assert ops.conv_bnsync_workspace_bytes(code, *geom, *xs, 64, 64, 196) == 0
-    ws = torch.zeros(256, dtype=torch.uint8, device=dev)
-    err = torch.zeros(1, dtype=torch.int32, device=dev)
     w = torch.zeros((64, 64), dtype=bf, device=dev)
     ops.conv2d_raw(code, *geom, x, *xs, w, 64, torch.empty((0, 14, 14, 64), dtype=bf, device=dev), 64,
-                   bnsync=(196, sc[0], sc[0], 1e-5, None, ws, err))
-    assert err.item() == 0
+                   bnlocal=(196, sc[0], sc[0], 1e-5, None))
+    sc0, sh0 = ops.conv2d_raw(code, *geom, x, *xs, w, 64, torch.empty((0, 14, 14, 64), dtype=bf, device=dev), 64,
+                              bnstats=(196, sc[0], sc[0], 1e-5))
+    assert sc0.shape == (0, 64) and sh0.shape == (0, 64)
     assert ops.hsv_frame_diff(torch.empty((0, 8, 8, 3), dtype=torch.uint8, device=dev)).shape == (0, 3)
     assert detect_shots(torch.zeros((1, 8, 8, 3), dtype=torch.uint8, device=dev)) == []
     assert resample_to(torch.zeros(0, device=dev), 48000, 16000).shape == (0,)
@@ -533,3 +533,26 @@ def test_shot_scan_vs_oracle(dev):
     assert gshots.downscale_factor(600) == 2
     assert np.array_equal(gshots.content_scores(torch.from_numpy(wide).to(dev)), oshots.content_scores(wide, 2))
     assert gshots.detect_shots(torch.from_numpy(_synthetic_video(30, 16, 16, set(), 9)).to(dev)) == []
+
+
+def test_align_features_against_oracle(dev):
+    """AudioFeatureExtractor._align_features (features/extractors.py:248-290) on seeded arrays: common feature
+    dimension / length, DTW of vggish against mfcc and mel on the GPU cost matrix, rows gathered along the path.
+    Parity unpinned (the reference's fastdtw call raises): the oracle restates the intent."""
+    from avsum_amd.features.extractors import AudioFeatureExtractor
+    from oracle import fusion as ofu
+    rng = np.random.default_rng(77)
+    ext = AudioFeatureExtractor()
+    for (tm, dm), (tl, dl), (tv, dv) in (((30, 128), (30, 128), (9, 128)), ((17, 40), (25, 128), (12, 128)),
+                                          ((6, 128), (6, 128), (6, 128)), ((1, 128), (4, 128), (3, 128))):
+        mfcc, mel, vg = rng.normal(size=(tm, dm)), rng.normal(size=(tl, dl)), rng.normal(size=(tv, dv))
+        a_mfcc, a_mel = ext._align_features(mfcc, mel, vg)
+        r_mfcc, r_mel = ofu.align_features(mfcc, mel, vg)
+        assert a_mfcc.shape == r_mfcc.shape and a_mel.shape == r_mel.shape
+        assert np.array_equal(a_mfcc, r_mfcc) and np.array_equal(a_mel, r_mel)     # index work: bit-exact
+    # 1-D inputs are promoted (np.atleast_2d); empty inputs give zeros(128) (extractors.py:252-259)
+    a, b = ext._align_features(rng.normal(size=128), rng.normal(size=128), rng.normal(size=128))
+    ra, rb = ofu.align_features(*[rng.normal(size=128)] * 3)
+    assert a.shape == ra.shape == (1, 128) and b.shape == rb.shape
+    z1, z2 = ext._align_features(np.zeros((0, 128)), rng.normal(size=(3, 128)), rng.normal(size=(3, 128)))
+    assert np.array_equal(z1, np.zeros(128)) and np.array_equal(z2, np.zeros(128))

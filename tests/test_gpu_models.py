@@ -66,6 +66,10 @@ def test_av_bilstm_unsupported_calls_fail_loudly(dev):
         m(torch.zeros(2, 4, 64, device=dev), torch.zeros(2, 4, 24, device=dev))
     with pytest.raises(RuntimeError):
         m.eval()(torch.zeros(1, 4, 64), torch.zeros(1, 4, 24))  # host tensors: no CPU fallback
+    with pytest.raises(NotImplementedError):  # eval mode, B > 1, autograd on: no silent graph-less result
+        m.eval()(torch.zeros(2, 4, 64, device=dev), torch.zeros(2, 4, 24, device=dev))
+    with torch.no_grad():
+        assert m.eval()(torch.zeros(2, 4, 64, device=dev), torch.zeros(2, 4, 24, device=dev)).shape == (2, 4)
 
 
 def _train_case(dev, dims, t, seed):
@@ -213,24 +217,37 @@ def test_resnet50_trunk_equal_groups(dev, gsize):
 
 
 def test_conv_bnstats_epilogue_matches_separate_pass(dev):
+    """Statistics from the convolution's epilogue (per-tile partial sums folded in tile order) against the separate
+    statistics pass over the stored output; groups that straddle tiles, a ragged last tile, a shorter last group.
+    The fused form is deterministic: a second run gives bit-identical scale / shift."""
     from avsum_amd import ops
     g = torch.Generator().manual_seed(6)
     for dtype, tol in ((torch.float32, 1e-5), (torch.bfloat16, 2e-3)):
-        for hw, cin, cout, k in ((7, 64, 128, 3), (14, 32, 64, 1), (5, 64, 192, 1)):
-            n = 6
+        # (frames, hw, cin, cout, kernel, frames per group)
+        for n, hw, cin, cout, k, gf in ((6, 7, 64, 128, 3, 2), (6, 14, 32, 64, 1, 2), (6, 6, 64, 192, 1, 2),
+                                        (5, 28, 64, 64, 3, 1), (7, 14, 64, 256, 1, 3), (9, 10, 32, 64, 1, 1)):
+            rpg = gf * hw * hw
             x = (torch.randn(n, hw, hw, cin, generator=g) + 0.5).to(dtype).to(dev)
             wt = (torch.randn(cout, k * k * cin, generator=g) / (k * k * cin) ** 0.5).to(dtype).to(dev)
             gamma = (torch.rand(cout, generator=g) + 0.5).to(dev)
             beta = torch.randn(cout, generator=g).to(dev)
             y1 = torch.empty((n, hw, hw, cout), dtype=dtype, device=dev)
-            sc1, sh1 = ops.conv2d(x, wt, k, k, 1, k // 2, y1, bnstats=(2 * hw * hw, gamma, beta, 1e-5))
+            sc1, sh1 = ops.conv2d(x, wt, k, k, 1, k // 2, y1, bnstats=(rpg, gamma, beta, 1e-5))
             y2 = torch.empty_like(y1)
             ops.conv2d(x, wt, k, k, 1, k // 2, y2)
-            rows = torch.arange(0, n + 1, 2, dtype=torch.int64, device=dev) * hw * hw
+            bounds = list(range(0, n, gf)) + [n]           # the last group may be shorter
+            rows = torch.tensor(bounds, dtype=torch.int64, device=dev) * hw * hw
             sc2, sh2 = ops.bn_batch_stats(y2.view(-1, cout), rows, gamma, beta, 1e-5)
             assert torch.equal(y1, y2)
+            assert sc1.shape == sc2.shape
             assert (sc1 - sc2).abs().max().item() < tol * sc2.abs().max().item()
             assert (sh1 - sh2).abs().max().item() < tol * max(1.0, sh2.abs().max().item())
+            sc3, sh3 = ops.conv2d(x, wt, k, k, 1, k // 2, y1, bnstats=(rpg, gamma, beta, 1e-5))
+            assert torch.equal(sc1, sc3) and torch.equal(sh1, sh3)
+    # groups of fewer than 64 rows are declined (None): the caller runs the separate statistics pass
+    x = torch.zeros((4, 5, 5, 64), dtype=torch.bfloat16, device=dev)
+    wt = torch.zeros((64, 64), dtype=torch.bfloat16, device=dev)
+    assert ops.conv2d(x, wt, 1, 1, 1, 0, torch.empty_like(x), bnstats=(25, gamma[:64], beta[:64], 1e-5)) is None
 
 
 @pytest.mark.parametrize("rpg,k,n,with_res,relu", [(196, 256, 1024, True, True), (3136, 64, 256, True, True),
@@ -288,8 +305,8 @@ def test_conv1x1_bn_input_affine_is_bn_apply_first(dev, rpg, k, n, with_res):
 
 
 def test_resnet50_bf16_deferred_bn_apply_close(dev):
-    """Whole trunk with bn2 applied inside conv3's kernel vs applied by its own pass: the same arithmetic; the runs
-    differ only by the order of the float atomics that sum conv2's statistics."""
+    """Whole trunk with bn2 applied inside conv3's kernel vs applied by its own pass: the same arithmetic, every
+    kernel on the path deterministic => bit-identical features."""
     from avsum_amd.cnn import ResNet50Runner, resnet50_trunk
     torch.manual_seed(29)
     trunk = resnet50_trunk().to(dev)
@@ -298,8 +315,23 @@ def test_resnet50_bf16_deferred_bn_apply_close(dev):
     b = ResNet50Runner(trunk, torch.bfloat16)
     b.defer_bn_apply = False
     fa, fb = a.forward(frames).cpu(), b.forward(frames).cpu()
-    assert ((fa - fb).norm() / fb.norm()).item() < 0.05
-    assert torch.nn.functional.cosine_similarity(fa, fb, dim=1).min().item() > 0.995
+    assert torch.equal(fa, fb)
+
+
+@pytest.mark.parametrize("gsize", [1, 3, 4])
+def test_resnet50_bf16_is_deterministic(dev, gsize):
+    """No float atomics anywhere on the throughput path: two runs of the same frames give bit-identical features
+    (per-frame groups, the reference's 4-frame micro-batches, and an odd group size that no fused form takes)."""
+    from avsum_amd.cnn import ResNet50Runner, resnet50_trunk
+    torch.manual_seed(31)
+    trunk = resnet50_trunk().to(dev)
+    frames = torch.from_numpy(_frames(24, 8)).to(dev)
+    runner = ResNet50Runner(trunk, torch.bfloat16)
+    groups = list(range(0, 25, gsize))
+    a = runner.forward(frames, groups).clone()
+    b = runner.forward(frames, groups)
+    assert torch.equal(a, b)
+    assert torch.isfinite(a).all()
 
 
 def _bn_reference(raw, rpg, gamma, beta, res, relu):
@@ -315,41 +347,29 @@ def _bn_reference(raw, rpg, gamma, beta, res, relu):
 
 
 # (frames, hw in, cin, cout, kernel, stride, frames per BatchNorm group, residual, relu)
-_SYNC_CASES = [
-    (12, 56, 64, 256, 1, 1, 1, True, True),     # layer1 conv3: two column tiles, tiles straddle groups (3136 % 128 != 0)
-    (12, 56, 64, 64, 3, 1, 1, False, True),     # layer1 conv2: 64-wide tile, spatial taps
-    (9, 7, 512, 2048, 1, 1, 1, True, True),     # layer4 conv3: 49-row groups, up to 4 groups per tile, ragged last tile
-    (8, 28, 128, 128, 3, 2, 4, False, True),    # long reduction (128-byte rows), stride 2, 4-frame groups
-    (8, 28, 256, 512, 1, 2, 2, False, False),   # strided downsample, no ReLU
-    (5, 14, 1024, 256, 1, 1, 5, False, True),   # ONE group for the whole call (980 rows)
-    (64, 56, 64, 256, 1, 1, 4, True, True),     # the reference's 4-frame micro-batches, 200k rows: many tiles waiting
-    # groups that fit a 256-row tile whole -> the tile-local form (no traffic between workgroups) when it is on
+# groups that fit a 256-row tile whole -> the tile-local one-launch form
+_LOCAL_CASES = [
     (11, 14, 256, 1024, 1, 1, 1, True, True),   # 196 rows: one group per tile
     (11, 14, 256, 256, 3, 1, 1, False, True),   # 3x3 taps, 196-row groups
     (7, 14, 1024, 256, 1, 1, 1, False, False),  # long reduction
     (13, 8, 128, 128, 3, 1, 1, True, True),     # 64-row groups: four per tile, the tile exactly full
-    (6, 10, 64, 64, 1, 1, 1, False, True),      # 100-row groups: two per tile; 64-wide tile
+    (6, 10, 128, 64, 1, 1, 1, False, True),     # 100-row groups: two per tile; 64-wide tile
     (9, 7, 2048, 512, 1, 1, 1, False, True),    # 49-row groups: five per tile, last tile 4 groups
+    (9, 7, 512, 2048, 1, 1, 1, True, True),     # layer4 conv3: 49-row groups, residual
     (8, 7, 512, 512, 3, 2, 4, False, True),     # stride 2 to 4x4 maps, 4-frame groups of 64 rows
+    (8, 28, 256, 512, 1, 2, 1, False, False),   # strided downsample to 14x14, no ReLU
+]
+# larger groups -> the split path (statistics in the convolution's epilogue + avs_bn_apply)
+_SPLIT_CASES = [
+    (12, 56, 64, 256, 1, 1, 1, True, True),     # layer1 conv3: two column tiles, tiles straddle groups (3136 % 128 != 0)
+    (12, 56, 64, 64, 3, 1, 1, False, True),     # layer1 conv2: 64-wide tile, spatial taps
+    (8, 28, 128, 128, 3, 2, 4, False, True),    # long reduction (128-byte rows), stride 2, 4-frame groups
+    (5, 14, 1024, 256, 1, 1, 5, False, True),   # ONE group for the whole call (980 rows)
+    (64, 56, 64, 256, 1, 1, 4, True, True),     # the reference's 4-frame micro-batches, 200k rows
 ]
 
 
-@pytest.mark.parametrize("local", [1, 0])
-@pytest.mark.parametrize("cfg", _SYNC_CASES)
-def test_conv_bnsync_one_launch(dev, cfg, local):
-    """Convolution + whole batch-statistics BatchNorm (+residual, +ReLU) in one launch - tiles that wait for their
-    group's statistics, or (local = 1, groups of <= 256 rows) tiles that hold whole groups - against the same arithmetic
-    in fp32 on the bf16-rounded operands, and against the split HIP path."""
-    from avsum_amd import _abi, ops
-    _abi.lib().avs_tune_bnlocal(local)
-    try:
-        _bnsync_case(dev, cfg)
-    finally:
-        _abi.lib().avs_tune_bnlocal(1)
-
-
-def _bnsync_case(dev, cfg):
-    from avsum_amd import ops
+def _conv_bn_operands(cfg):
     frames, hw, cin, cout, k, s, gf, with_res, relu = cfg
     g = torch.Generator().manual_seed(sum(cfg[:6]))
     pad = k // 2
@@ -362,92 +382,118 @@ def _bnsync_case(dev, cfg):
     res = torch.randn(frames * ho * ho, cout, generator=g).bfloat16() if with_res else None
     raw = F.conv2d(x.float().permute(0, 3, 1, 2), w4.float(), stride=s, padding=pad).permute(0, 2, 3, 1).reshape(-1, cout)
     ref = _bn_reference(raw, rpg, gamma, beta, res, relu)
+    return x, wt, gamma, beta, res, ref, pad, ho, rpg
 
+
+def _split_path(dev, cfg, xd, wd, gamma, beta, res, pad, ho, rpg):
+    from avsum_amd import ops
+    frames, hw, cin, cout, k, s, gf, with_res, relu = cfg
+    y2 = torch.empty((frames, ho, ho, cout), dtype=torch.bfloat16, device=dev)
+    rows = torch.arange(0, frames * ho * ho + 1, rpg, dtype=torch.int64, device=dev)
+    affine = ops.conv2d(xd, wd, k, k, s, pad, y2, bnstats=(rpg, gamma.to(dev), beta.to(dev), 1e-5))
+    if affine is None:   # groups of fewer than 64 rows: the separate statistics pass (what the runner does)
+        ops.conv2d(xd, wd, k, k, s, pad, y2)
+        affine = ops.bn_batch_stats(y2.view(-1, cout), rows, gamma.to(dev), beta.to(dev), 1e-5)
+    sc, sh = affine
+    ops.bn_apply(y2.view(-1, cout), sc, sh, rows, rpg, res.to(dev) if with_res else None,
+                 ops.ACT_RELU if relu else ops.ACT_NONE, y2.view(-1, cout))
+    return y2.float().cpu().view(-1, cout)
+
+
+@pytest.mark.parametrize("cfg", _LOCAL_CASES)
+def test_conv_bnlocal_one_launch(dev, cfg):
+    """Convolution + whole batch-statistics BatchNorm (+residual, +ReLU) in one launch, tiles that hold whole groups,
+    against the same arithmetic in fp32 on the bf16-rounded operands and against the split HIP path; deterministic."""
+    from avsum_amd import ops
+    frames, hw, cin, cout, k, s, gf, with_res, relu = cfg
+    x, wt, gamma, beta, res, ref, pad, ho, rpg = _conv_bn_operands(cfg)
     geom = (frames, hw, hw, cin, k, k, s, s, pad, pad, ho, ho, cout)
     xs = (hw * hw * cin, hw * cin, cin)
     code = ops.dtype_code(torch.bfloat16)
-    nbytes = ops.conv_bnsync_workspace_bytes(code, *geom, *xs, wt.shape[1], cout, rpg)
-    assert nbytes is not None and nbytes > 0
-    ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
-    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    tile_rows = ops.conv_bnlocal_tile_rows(code, *geom, *xs, wt.shape[1], cout, rpg)
+    assert tile_rows == 256 // rpg * rpg
     xd, wd = x.to(dev), wt.to(dev)
-    y = torch.empty((frames, ho, ho, cout), dtype=torch.bfloat16, device=dev)
-    ops.conv2d_raw(code, *geom, xd, *xs, wd, wd.stride(0), y, cout, act=ops.ACT_RELU if relu else ops.ACT_NONE,
-                   bnsync=(rpg, gamma.to(dev), beta.to(dev), 1e-5, res.to(dev) if with_res else None, ws, err))
-    assert err.item() == 0, "a group wait timed out"
-    got = y.float().cpu().view(-1, cout)
+    outs = []
+    for _ in range(2):
+        y = torch.empty((frames, ho, ho, cout), dtype=torch.bfloat16, device=dev)
+        ops.conv2d_raw(code, *geom, xd, *xs, wd, wd.stride(0), y, cout, act=ops.ACT_RELU if relu else ops.ACT_NONE,
+                       bnlocal=(rpg, gamma.to(dev), beta.to(dev), 1e-5, res.to(dev) if with_res else None))
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
+    got = outs[0].float().cpu().view(-1, cout)
     scale = max(1.0, ref.abs().max().item())
     assert (got - ref).abs().max().item() < 0.03 * scale
-    # split path (statistics in the epilogue of a raw bf16 convolution, then avs_bn_apply): same to bf16 rounding
-    y2 = torch.empty_like(y)
-    sc, sh = ops.conv2d(xd, wd, k, k, s, pad, y2, bnstats=(rpg, gamma.to(dev), beta.to(dev), 1e-5))
-    rows = torch.arange(0, frames * ho * ho + 1, rpg, dtype=torch.int64, device=dev)
-    ops.bn_apply(y2.view(-1, cout), sc, sh, rows, rpg, res.to(dev) if with_res else None,
-                 ops.ACT_RELU if relu else ops.ACT_NONE, y2.view(-1, cout))
-    assert (got - y2.float().cpu().view(-1, cout)).abs().max().item() < 0.03 * scale
+    assert (got - ref).abs().mean().item() < 0.004 * scale
+    split = _split_path(dev, cfg, xd, wd, gamma, beta, res, pad, ho, rpg)
+    assert (got - split).abs().max().item() < 0.03 * scale
+
+
+@pytest.mark.parametrize("cfg", _SPLIT_CASES)
+def test_conv_bn_split_path(dev, cfg):
+    """Groups too large for a tile: statistics from the convolution's epilogue + avs_bn_apply against the same
+    arithmetic in fp32 on the bf16-rounded operands; the one-launch form declines these shapes."""
+    from avsum_amd import ops
+    frames, hw, cin, cout, k, s, gf, with_res, relu = cfg
+    x, wt, gamma, beta, res, ref, pad, ho, rpg = _conv_bn_operands(cfg)
+    geom = (frames, hw, hw, cin, k, k, s, s, pad, pad, ho, ho, cout)
+    xs = (hw * hw * cin, hw * cin, cin)
+    assert ops.conv_bnlocal_tile_rows(ops.dtype_code(torch.bfloat16), *geom, *xs, wt.shape[1], cout, rpg) is None
+    xd, wd = x.to(dev), wt.to(dev)
+    got = _split_path(dev, cfg, xd, wd, gamma, beta, res, pad, ho, rpg)
+    again = _split_path(dev, cfg, xd, wd, gamma, beta, res, pad, ho, rpg)
+    assert torch.equal(got, again)
+    scale = max(1.0, ref.abs().max().item())
+    assert (got - ref).abs().max().item() < 0.03 * scale
     assert (got - ref).abs().mean().item() < 0.004 * scale
 
 
-def test_conv_bnsync_declines_and_times_out_loudly(dev):
-    """Shapes the one-launch form cannot take are declined up front (None -> the caller uses the split path); a wait
-    that times out sets the error word, and the runner then recomputes on the two-pass path."""
+def test_conv_bnlocal_declines(dev):
+    """Shapes the one-launch form cannot take are declined up front (None -> the caller uses the split path)."""
     from avsum_amd import _abi, ops
-    from avsum_amd.cnn import ResNet50Runner, resnet50_trunk
     code = ops.dtype_code(torch.bfloat16)
     geom = lambda n, hw, cin, cout: ((n, hw, hw, cin, 1, 1, 1, 1, 0, 0, hw, hw, cout), (hw * hw * cin, hw * cin, cin))
-    g, xs = geom(8, 4, 64, 64)
-    assert ops.conv_bnsync_workspace_bytes(code, *g, *xs, 64, 64, 16) is None          # 16-row groups
-    g, xs = geom(4, 8, 64, 96)
-    assert ops.conv_bnsync_workspace_bytes(code, *g, *xs, 64, 96, 64) is None          # cout not a tile multiple
-    g, xs = geom(128, 112, 32, 64)
-    assert ops.conv_bnsync_workspace_bytes(code, *g, *xs, 32, 64, 128 * 112 * 112) is None  # a group too long to co-reside
-    assert ops.conv_bnsync_workspace_bytes(ops.dtype_code(torch.float32), *g, *xs, 32, 64, 112 * 112) is None
-
-    torch.manual_seed(3)
-    trunk = resnet50_trunk().to(dev)
-    frames = torch.from_numpy(_frames(6, 9)).to(dev)
-    plain = ResNet50Runner(trunk, torch.bfloat16)
-    plain.bn_sync = False
-    want = plain.forward(frames).cpu()
-    runner = ResNet50Runner(trunk, torch.bfloat16)
-    runner.sync_max_group_rows = 1 << 30                # the waiting form on every layer the library takes
+    g, xs = geom(8, 4, 128, 64)
+    assert ops.conv_bnlocal_tile_rows(code, *g, *xs, 128, 64, 16) is None          # 16-row groups
+    g, xs = geom(4, 8, 128, 96)
+    assert ops.conv_bnlocal_tile_rows(code, *g, *xs, 128, 96, 64) is None          # cout not a tile multiple
+    g, xs = geom(4, 12, 128, 64)
+    assert ops.conv_bnlocal_tile_rows(code, *g, *xs, 128, 64, 144) is None         # 144 rows fill 56 % of a tile
+    g, xs = geom(4, 28, 128, 64)
+    assert ops.conv_bnlocal_tile_rows(code, *g, *xs, 128, 64, 784) is None         # a group larger than a tile
+    g, xs = geom(4, 14, 128, 64)
+    assert ops.conv_bnlocal_tile_rows(ops.dtype_code(torch.float32), *g, *xs, 128, 64, 196) is None
+    assert ops.conv_bnlocal_tile_rows(code, *g, *xs, 128, 64, 196) == 196
     try:
         _abi.lib().avs_tune_bnlocal(0)
-        _abi.lib().avs_tune_bnsync_timeout_ticks(-1)   # every wait that is not already satisfied times out
-        with pytest.warns(UserWarning, match="timed out"):
-            got = runner.forward(frames).cpu()
+        assert ops.conv_bnlocal_tile_rows(code, *g, *xs, 128, 64, 196) is None
     finally:
-        _abi.lib().avs_tune_bnsync_timeout_ticks(5000000)
         _abi.lib().avs_tune_bnlocal(1)
-    # (statistics summed by float atomics: two runs of the split path agree to bf16 rounding noise, not bit for bit)
-    assert runner.bn_sync is False and ((got - want).norm() / want.norm()).item() < 0.05
 
 
 @pytest.mark.parametrize("gsize", [1, 4])
-def test_resnet50_bf16_sync_form_close_to_split_form(dev, gsize):
-    """Whole trunk: one-launch convolution + BatchNorm against the two-pass / split forms (both bf16) and fp32."""
+def test_resnet50_bf16_local_form_close_to_split_form(dev, gsize):
+    """Whole trunk: one-launch convolution + BatchNorm on the layers that take it against the two-pass / split forms
+    (both bf16) and fp32."""
     from avsum_amd.cnn import ResNet50Runner, resnet50_trunk
     torch.manual_seed(23)
     trunk = resnet50_trunk().to(dev)
     frames = torch.from_numpy(_frames(16, 4)).to(dev)
     groups = list(range(0, 17, gsize))
-    sync = ResNet50Runner(trunk, torch.bfloat16)
-    sync.sync_max_group_rows = 1 << 30          # every layer the library takes, not only the small-group ones
-    got = sync.forward(frames, groups).cpu()
-    assert sync.bn_sync and not sync.sync_failed()
-    plan = sync._plans[(16, gsize, 1 << 30)]
-    assert sum(p is not None for p in plan[:-1]) >= (53 if gsize == 1 else 50)   # the form really ran
+    local = ResNet50Runner(trunk, torch.bfloat16)
+    got = local.forward(frames, groups).cpu()
+    plan = local._plans[(16, gsize)]
+    assert sum(plan) >= (29 if gsize == 1 else 10)   # the form really ran (14x14 + 7x7 layers / 7x7 layers)
     split = ResNet50Runner(trunk, torch.bfloat16)
-    split.bn_sync = False
+    split.bn_local = False
     ref_bf = split.forward(frames, groups).cpu()
     ref32 = ResNet50Runner(trunk, torch.float32).forward(frames, groups).cpu()
     cos = lambda a, b: torch.nn.functional.cosine_similarity(a, b, dim=1).min().item()
     assert cos(got, ref32) > 0.98 and cos(got, ref_bf) > 0.98
     # the one-launch form normalises the fp32 accumulators (no bf16 rounding of the raw convolution in between):
     # it must not be further from fp32 than the split form is
-    e_sync = ((got - ref32).norm() / ref32.norm()).item()
+    e_local = ((got - ref32).norm() / ref32.norm()).item()
     e_split = ((ref_bf - ref32).norm() / ref32.norm()).item()
-    assert e_sync < 0.2 and e_sync < 1.25 * e_split, (e_sync, e_split)
+    assert e_local < 0.2 and e_local < 1.25 * e_split, (e_local, e_split)
 
 
 @pytest.mark.parametrize("groups", [[0, 4, 8], [0, 4, 7, 8]])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel study: convolution + batch-statistics BatchNorm forms on the ResNet-50 layer shapes (1024-frame chunk,
-per-frame groups unless --gf): plain convolution (floor) | split (conv+stats, finalize, apply) | two-pass 1x1 |
-one-launch sync form.  Usage: python tools/bn_study.py [--gf 1] [--nap 0]"""
+per-frame groups unless --gf): plain convolution (floor) | split (conv + per-tile statistics, fold, apply) | two-pass 1x1 |
+one-launch tile-local form.  Usage: python tools/bn_study.py [--gf 1]"""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,7 +9,6 @@ from avsum_amd import ops, _abi
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--gf", type=int, default=1)
-ap.add_argument("--nap", type=int, default=0)
 ap.add_argument("--n", type=int, default=1024)
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -47,8 +46,7 @@ def timeit(fn, reps=5):
 
 
 n = args.n
-err = torch.zeros(1, dtype=torch.int32, device=dev)
-tot = {"plain": 0.0, "split": 0.0, "best_old": 0.0, "sync": 0.0}
+tot = {"plain": 0.0, "split": 0.0, "best_old": 0.0, "local": 0.0}
 for name, hw, cin, cout, k, s, with_res in shapes:
     if hw == 0:
         geom, xs, wrs = (n, 230, 112, 32, 7, 1, 2, 1, 0, 0, 112, 112, 64), (230 * 232 * 4, 232 * 4, 8), 224
@@ -79,22 +77,17 @@ for name, hw, cin, cout, k, s, with_res in shapes:
     def twopass():
         ops.conv1x1_bn(x.view(-1, cin), w, rpg, gamma, beta, 1e-5, y2, res, True)
 
-    nbytes = ops.conv_bnsync_workspace_bytes(code, *geom, *xs, wrs, cout, rpg)
-    ws = torch.zeros(max(nbytes or 0, 256), dtype=torch.uint8, device=dev)
+    tile_rows = ops.conv_bnlocal_tile_rows(code, *geom, *xs, wrs, cout, rpg)
 
-    def sync():
-        ws.zero_()
-        ops.conv2d_raw(code, *geom, x, *xs, w, wrs, y, cout, act=ops.ACT_RELU,
-                       bnsync=(rpg, gamma, beta, 1e-5, res, ws, err))
+    def local():
+        ops.conv2d_raw(code, *geom, x, *xs, w, wrs, y, cout, act=ops.ACT_RELU, bnlocal=(rpg, gamma, beta, 1e-5, res))
 
     t_plain, t_split = timeit(plain), timeit(split)
     t_two = timeit(twopass) if (k == 1 and s == 1 and hw) else float("nan")
-    L.avs_debug_flags(args.nap << 2)
-    t_sync = timeit(sync) if nbytes is not None else float("nan")
-    L.avs_debug_flags(0)
+    t_loc = timeit(local) if tile_rows is not None else float("nan")
     best_old = min(t_split, t_two) if t_two == t_two else t_split
     tot["plain"] += t_plain; tot["split"] += t_split; tot["best_old"] += best_old
-    tot["sync"] += t_sync if t_sync == t_sync else best_old
+    tot["local"] += t_loc if t_loc == t_loc else best_old
     print(f"{name:28s} plain {t_plain:7.1f}us {byts / t_plain / 1e6:5.2f}TB/s | split {t_split:7.1f} | twopass {t_two:7.1f} "
-          f"| sync {t_sync:7.1f}us {byts / t_sync / 1e6:5.2f}TB/s  x{best_old / t_sync:4.2f} vs best old", flush=True)
-print("err word:", err.item(), "totals (one conv of each shape):", {k: round(v, 1) for k, v in tot.items()})
+          f"| local {t_loc:7.1f}us {byts / t_loc / 1e6:5.2f}TB/s  x{best_old / t_loc:4.2f} vs best other", flush=True)
+print("totals (one conv of each shape):", {k: round(v, 1) for k, v in tot.items()})

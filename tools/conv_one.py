@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Run one convolution shape a few times (for rocprofv3 --pmc studies). usage: conv_one.py n hw cin cout k"""
-import sys, os
+import os
+os.environ["AVS_STUDY_LIB"] = "1"  # the ablation switches live in the study build only (make -C <pkg>/csrc study)
+import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from avsum_amd import ops, _abi

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Kernel study: time single convolution shapes of the ResNet-50 trunk (1024-frame chunk) with ablations."""
-import sys, os, time
+import os
+os.environ["AVS_STUDY_LIB"] = "1"  # the ablation switches live in the study build only (make -C <pkg>/csrc study)
+import sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from avsum_amd import ops, _abi
