@@ -243,9 +243,9 @@ class ResNet50Runner:
             # tile order (E[x^2]-E[x]^2: fine for bf16 activations); None = groups too small for that form
             affine = conv(bnstats=(gmax, gamma, beta, eps))
         if affine is None:
-            # fp32 parity mode / ragged groups / tiny groups: the shifted statistics pass over the stored output
-            if not fast:
-                conv()
+            # fp32 parity mode / ragged groups / tiny groups (the fused form declined before launching anything):
+            # plain convolution, then the shifted statistics pass over the stored output
+            conv()
             affine = ops.bn_batch_stats(y2d, grows, gamma, beta, eps)
         if defer:
             return y, affine

@@ -12,6 +12,46 @@ from . import ops
 from .evaluation.metrics import select_frames
 
 
+class _HostStager:
+    """Double-buffered upload of passes of frames from pinned host memory: a copy stream fills buffer i % 2 while the
+    compute stream works on the other one; events order the two streams, nothing blocks the host."""
+
+    def __init__(self, host_frames, max_frames, device):
+        self.host = host_frames
+        self.bufs = [torch.empty((max_frames,) + tuple(host_frames.shape[1:]), dtype=torch.uint8, device=device)
+                     for _ in range(2)]
+        self.copy_stream = torch.cuda.Stream(device=device)
+        self.filled = [torch.cuda.Event(), torch.cuda.Event()]
+        self.freed = [None, None]
+        self.counts = [0, 0]
+
+    def upload(self, i, one_pass):
+        _, where, contiguous = one_pass
+        k = i % 2
+        with torch.cuda.stream(self.copy_stream):
+            if self.freed[k] is not None:
+                self.copy_stream.wait_event(self.freed[k])    # the pass that used this buffer has finished
+            if contiguous:
+                cnt = where[1] - where[0]
+                self.bufs[k][:cnt].copy_(self.host[where[0]:where[1]], non_blocking=True)
+            else:
+                cnt = len(where)
+                for j, src in enumerate(where.tolist()):      # ragged tails: a few frames, copied one by one
+                    self.bufs[k][j].copy_(self.host[src], non_blocking=True)
+            self.filled[k].record(self.copy_stream)
+        self.counts[k] = cnt
+
+    def ready(self, i):
+        k = i % 2
+        torch.cuda.current_stream().wait_event(self.filled[k])
+        return self.bufs[k][:self.counts[k]]
+
+    def release(self, i):
+        k = i % 2
+        self.freed[k] = torch.cuda.Event()
+        self.freed[k].record(torch.cuda.current_stream())
+
+
 class FrameScoringPipeline:
     def __init__(self, visual_extractor, scorer, use_inception=True, chunk_frames=256, frames_per_group=1):
         """visual_extractor: features.extractors.VisualFeatureExtractor (on the device);
@@ -63,31 +103,58 @@ class FrameScoringPipeline:
         return sets
 
     def embed(self, frames_u8, video_offsets):
-        """uint8 [N,224,224,3] on device -> fp32 [N,4096] (ResNet-50 | Inception-v3 halves)."""
+        """uint8 [N,224,224,3] -> fp32 [N,4096] on the device (ResNet-50 | Inception-v3 halves).
+        frames_u8 on the device: read in place.  frames_u8 in PINNED host memory: every pass's frames are uploaded
+        by a copy stream into one of two staging buffers while the previous pass computes (PCIe-inclusive path)."""
         n = frames_u8.shape[0]
-        dev = frames_u8.device
+        host = not frames_u8.is_cuda
+        if host and not frames_u8.is_pinned():
+            raise ValueError("host frames must be in pinned memory (tensor.pin_memory()) for the overlapped upload")
+        dev = self.visual._resnet_runner.trunk[0].weight.device if host else frames_u8.device
         visual = torch.zeros((n, 4096), dtype=torch.float32, device=dev)
+        passes = []   # (group size, frame slice | index array, contiguous)
         for gsz, where in self._uniform_sets(video_offsets):
             per_pass = max(gsz, self.chunk_frames // gsz * gsz)
             contiguous = isinstance(where, tuple)
             lo, hi = where if contiguous else (0, len(where))
             for a in range(lo, hi, per_pass):
                 b = min(a + per_pass, hi)
+                passes.append((gsz, (a, b) if contiguous else where[a:b], contiguous))
+        stage = _HostStager(frames_u8, max((p[1][1] - p[1][0]) if p[2] else len(p[1]) for p in passes), dev) \
+            if host and passes else None
+        if stage is not None:
+            stage.upload(0, passes[0])
+        for i, (gsz, where, contiguous) in enumerate(passes):
+            idx = None
+            if stage is not None:
+                if i + 1 < len(passes):
+                    stage.upload(i + 1, passes[i + 1])     # overlaps with this pass's kernels
+                chunk = stage.ready(i)
+                cnt = chunk.shape[0]
                 if contiguous:
-                    chunk, out = frames_u8[a:b], visual[a:b]
+                    out = visual[where[0]:where[1]]
                 else:
-                    idx = torch.from_numpy(where[a:b]).to(dev)
-                    chunk = frames_u8.index_select(0, idx)     # memory plumbing: gather the pass's frames
-                    out = torch.empty((b - a, 4096), dtype=torch.float32, device=dev)
-                    if not self.use_inception:
-                        out[:, 2048:].zero_()
-                groups = torch.arange(0, b - a + 1, gsz, dtype=torch.int64)
-                self.visual._resnet_runner.forward(chunk, groups, out=out[:, :2048])
-                if self.use_inception:
-                    big = ops.resize_bilinear(chunk, 299, 299)
-                    self.visual._inception_runner.forward(big, out=out[:, 2048:])
-                if not contiguous:
-                    visual.index_copy_(0, idx, out)
+                    idx = torch.from_numpy(where).to(dev)
+            elif contiguous:
+                chunk, out = frames_u8[where[0]:where[1]], visual[where[0]:where[1]]
+                cnt = where[1] - where[0]
+            else:
+                idx = torch.from_numpy(where).to(dev)
+                chunk = frames_u8.index_select(0, idx)     # memory plumbing: gather the pass's frames
+                cnt = len(where)
+            if idx is not None:
+                out = torch.empty((cnt, 4096), dtype=torch.float32, device=dev)
+                if not self.use_inception:
+                    out[:, 2048:].zero_()
+            groups = torch.arange(0, cnt + 1, gsz, dtype=torch.int64)
+            self.visual._resnet_runner.forward(chunk, groups, out=out[:, :2048])
+            if self.use_inception:
+                big = ops.resize_bilinear(chunk, 299, 299)
+                self.visual._inception_runner.forward(big, out=out[:, 2048:])
+            if idx is not None:
+                visual.index_copy_(0, idx, out)
+            if stage is not None:
+                stage.release(i)
         return visual
 
     @torch.no_grad()

@@ -17,7 +17,13 @@ def load(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        name = re.sub(r"<.*", "", r["Kernel_Name"].replace("void ", "")).split("(")[0]
+        full = r["Kernel_Name"].replace("void ", "")
+        name = re.sub(r"<.*", "", full).split("(")[0]
+        # the contraction kernel serves the bf16 convolutions (element size 2) AND the fp32 scorer GEMMs (4): keep
+        # them apart, or the per-launch average mixes 180 convolutions with 7 small GEMMs
+        m = re.match(r"igemm_kernel<(\d+)", full)
+        if m:
+            name = f"igemm_kernel<{m.group(1)}>"
         agg[name][0] += 1
         agg[name][1] += float(r["Counter_Value"])
     return agg
