@@ -12,6 +12,11 @@ REFERENCE = "/root/reference"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the oracle runs on torch-CPU: a GPU box grants 16 cores per GPU but shows all 256 of the host, and a thread per
+    # visible core oversubscribes that share by orders of magnitude (same rule as bench.py's cpu_baseline leg)
+    import torch
+    visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(max(1, min(16, visible)))
 
 
 @pytest.fixture(scope="session")

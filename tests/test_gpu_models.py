@@ -482,7 +482,7 @@ def test_resnet50_bf16_local_form_close_to_split_form(dev, gsize):
     local = ResNet50Runner(trunk, torch.bfloat16)
     got = local.forward(frames, groups).cpu()
     plan = local._plans[(16, gsize)]
-    assert sum(plan) >= (29 if gsize == 1 else 10)   # the form really ran (14x14 + 7x7 layers / 7x7 layers)
+    assert sum(plan) == (28 if gsize == 1 else 9)     # the form really ran (14x14 + 7x7 layers / 7x7 layers)
     split = ResNet50Runner(trunk, torch.bfloat16)
     split.bn_local = False
     ref_bf = split.forward(frames, groups).cpu()
