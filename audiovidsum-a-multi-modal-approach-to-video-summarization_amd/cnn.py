@@ -97,7 +97,10 @@ class ResNet50Runner:
     of them is deterministic (no float atomics: two runs give bit-identical features):
       local   bf16, equal-sized groups of <= 256 rows (14x14 / 7x7 maps): convolution + whole BatchNorm (+ residual
               + ReLU) in ONE launch, statistics inside a tile (avs_conv2d_nhwc_bnlocal) - nothing raw in HBM;
-      twopass bf16 1x1 layers: one workgroup walks a group twice (avs_conv1x1_bn_bf16);
+      gram    bf16 expanding 1x1 layers with 64 / 128 input channels (conv3 / downsample of layers 1-2): statistics
+              from the input's Gram matrix (avs_bn_gram_affine_bf16), then ONE streaming pass with the affine in the
+              epilogue (avs_conv1x1_affine_bf16);
+      twopass other bf16 1x1 layers: one workgroup walks a group twice (avs_conv1x1_bn_bf16);
       split   convolution (+ per-tile partial statistics in its epilogue for bf16, folded in tile order) or
               avs_bn_batch_stats -> avs_bn_apply (fp32 parity mode, ragged groups, shapes the other forms decline)."""
 
@@ -108,6 +111,7 @@ class ResNet50Runner:
         self.fuse_conv_bn = True
         self.fuse_min_rows, self.fuse_ratio_num, self.fuse_ratio_den = 128, 2, 1
         self.bn_local = True         # the one-launch tile-local form where the library takes the shape
+        self.gram_stats = True       # conv3 / downsample of layers 1-2: Gram-matrix statistics + one streaming pass
         self.defer_bn_apply = True   # bn2 + ReLU applied inside conv3's two-pass kernel (avs_conv1x1_bn_in_bf16)
         self._key = None
         self._w = None
@@ -235,7 +239,10 @@ class ResNet50Runner:
                 return ops.pool2d(y, "max", k, s, p, out)
             return y
         if in_affine is not None or (fast and self._twopass_ok(cin, cout, kh, sh, gmax)):
-            ops.conv1x1_bn(x.view(-1, cin), wt, gmax, gamma, beta, eps, y2d, residual, relu, in_affine)
+            # statistics from the input's Gram matrix + ONE streaming pass where the shape allows it (the expanding
+            # 1x1 layers of layers 1-2), else the two-pass kernel
+            form = ops.conv1x1_gram_bn if (self.gram_stats and ops.gram_supported(cin, cout)) else ops.conv1x1_bn
+            form(x.view(-1, cin), wt, gmax, gamma, beta, eps, y2d, residual, relu, in_affine)
             return y
         affine = None
         if fast:

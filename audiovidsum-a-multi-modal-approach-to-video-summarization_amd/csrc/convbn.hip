@@ -37,6 +37,10 @@ struct ConvBnParams {
   // a[m,k] = relu(x[m,k] * in_scale[g,k] + in_shift[g,k]) rounded to bf16 (avs_bn_apply's arithmetic)
   const float* in_scale;
   const float* in_shift;
+  // PRE: the output BatchNorm's folded affine [groups, N] is given (avs_bn_gram_affine_bf16 computed it from the
+  // input's Gram matrix), so the statistics pass is skipped: one streaming pass over the group
+  const float* pre_scale;
+  const float* pre_shift;
 };
 
 #define AVS_CONVBN_MAX_K 512
@@ -45,7 +49,7 @@ struct ConvBnParams {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),            \
                                    (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
-template <int BN, bool XF>
+template <int BN, bool XF, bool PRE = false>
 __global__ __launch_bounds__(256, 3) void conv1x1_bn_kernel(ConvBnParams p) {
   constexpr int ES = 2, ROWB = 64;
   constexpr int CE = 16 / ES, BKE = ROWB / ES, CPRR = ROWB / 16, RPP = 256 / CPRR, SH = 2, KS = ROWB / 32;
@@ -104,7 +108,15 @@ __global__ __launch_bounds__(256, 3) void conv1x1_bn_kernel(ConvBnParams p) {
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) s1[nt] = s2[nt] = scale[nt] = shift[nt] = 0.f;
 
-  for (int pass = 0; pass < 2; ++pass) {
+  if constexpr (PRE) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = n0 + wc * (BN / 2) + nt * 32 + lr;
+      scale[nt] = col < p.N ? p.pre_scale[(long long)g * p.N + col] : 0.f;
+      shift[nt] = col < p.N ? p.pre_shift[(long long)g * p.N + col] : 0.f;
+    }
+  }
+  for (int pass = PRE ? 1 : 0; pass < 2; ++pass) {
     for (int tm = 0; tm < tiles_m; ++tm) {
       const long long m0 = m_lo + (long long)tm * A_ROWS;
       const char* a_base[NA];
@@ -239,15 +251,34 @@ __global__ __launch_bounds__(256, 3) void conv1x1_bn_kernel(ConvBnParams p) {
         const int srow = t / CPRW, sch = t - srow * CPRW;
         const int col = n0 + sch * 8;
         if (col < p.N) {  // N is a multiple of 8 (checked on the host)
+          constexpr int NIT = A_ROWS / RSTEP;
+          // every residual row of this thread in flight at once (the accumulators are dead: registers are free), then
+          // the adds and stores: one memory latency per tile instead of one per row
+          // (the streaming form only: the two-pass variants sit at their register cap and would spill)
+          uint4 rv[PRE ? NIT : 1];
+          if constexpr (PRE) {
+            if (p.res != nullptr) {
 #pragma unroll
-          for (int it = 0; it < A_ROWS / RSTEP; ++it) {
+              for (int it = 0; it < NIT; ++it) {
+                const long long row = m0 + srow + it * RSTEP;
+                rv[it] = row < m_hi ? *reinterpret_cast<const uint4*>(p.res + (row * p.ldr + col) * 2)
+                                    : make_uint4(0u, 0u, 0u, 0u);
+              }
+            }
+          }
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) {
             const long long row = m0 + srow + it * RSTEP;
             if (row >= m_hi) break;
             uint4 v = *reinterpret_cast<const uint4*>(ct + (srow + it * RSTEP) * CT_PITCH + sch * 16);
             if (p.res != nullptr) {
-              const uint4 rv = *reinterpret_cast<const uint4*>(p.res + (row * p.ldr + col) * 2);
               unsigned vv[4] = {v.x, v.y, v.z, v.w};
-              const unsigned rw[4] = {rv.x, rv.y, rv.z, rv.w};
+              uint4 r1;
+              if constexpr (PRE)
+                r1 = rv[it];
+              else
+                r1 = *reinterpret_cast<const uint4*>(p.res + (row * p.ldr + col) * 2);
+              const unsigned rw[4] = {r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
                 float a0 = __uint_as_float(vv[j] << 16) + __uint_as_float(rw[j] << 16);
@@ -301,45 +332,29 @@ __global__ __launch_bounds__(256, 3) void conv1x1_bn_kernel(ConvBnParams p) {
 static int g_convbn_narrow = 0;
 extern "C" void avs_tune_convbn_narrow(int enabled) { g_convbn_narrow = enabled; }
 
-static int conv1x1_bn_launch(const void* d_x, int64_t lin_stride, int k, const void* d_w, int64_t ldb, int n,
-                             int64_t rows_per_group, int groups, const float* d_gamma, const float* d_beta, float eps,
-                             const void* d_residual, int64_t ldr, int relu, void* d_y, int64_t ldc,
-                             const float* d_in_scale, const float* d_in_shift, avs_stream_t stream);
-
-extern "C" int avs_conv1x1_bn_bf16(const void* d_x, int64_t lin_stride, int k, const void* d_w, int64_t ldb, int n,
-                                   int64_t rows_per_group, int groups, const float* d_gamma, const float* d_beta,
-                                   float eps, const void* d_residual, int64_t ldr, int relu, void* d_y, int64_t ldc,
-                                   avs_stream_t stream) {
-  return conv1x1_bn_launch(d_x, lin_stride, k, d_w, ldb, n, rows_per_group, groups, d_gamma, d_beta, eps, d_residual,
-                           ldr, relu, d_y, ldc, nullptr, nullptr, stream);
-}
-
-extern "C" int avs_conv1x1_bn_in_bf16(const void* d_x, int64_t lin_stride, int k, const float* d_in_scale,
-                                      const float* d_in_shift, const void* d_w, int64_t ldb, int n,
-                                      int64_t rows_per_group, int groups, const float* d_gamma, const float* d_beta,
-                                      float eps, const void* d_residual, int64_t ldr, int relu, void* d_y,
-                                      int64_t ldc, avs_stream_t stream) {
-  AVS_REQUIRE(d_in_scale && d_in_shift, AVS_E_ARG, "avs_conv1x1_bn_in_bf16: null input scale / shift");
-  AVS_REQUIRE(k <= AVS_CONVBN_MAX_K, AVS_E_UNSUPPORTED, "avs_conv1x1_bn_in_bf16: k=%d > %d", k, AVS_CONVBN_MAX_K);
-  AVS_REQUIRE(avs_aligned16(d_in_scale) && avs_aligned16(d_in_shift), AVS_E_ALIGN,
-              "avs_conv1x1_bn_in_bf16: input scale / shift must be 16-byte aligned");
-  return conv1x1_bn_launch(d_x, lin_stride, k, d_w, ldb, n, rows_per_group, groups, d_gamma, d_beta, eps, d_residual,
-                           ldr, relu, d_y, ldc, d_in_scale, d_in_shift, stream);
-}
-
-static int conv1x1_bn_launch(const void* d_x, int64_t lin_stride, int k, const void* d_w, int64_t ldb, int n,
-                             int64_t rows_per_group, int groups, const float* d_gamma, const float* d_beta, float eps,
-                             const void* d_residual, int64_t ldr, int relu, void* d_y, int64_t ldc,
-                             const float* d_in_scale, const float* d_in_shift, avs_stream_t stream) {
+static int conv1x1_bn_launch(const char* who, const void* d_x, int64_t lin_stride, int k, const void* d_w, int64_t ldb,
+                             int n, int64_t rows_per_group, int groups, const float* d_gamma, const float* d_beta,
+                             float eps, const void* d_residual, int64_t ldr, int relu, void* d_y, int64_t ldc,
+                             const float* d_in_scale, const float* d_in_shift, const float* d_pre_scale,
+                             const float* d_pre_shift, avs_stream_t stream) {
   AVS_REQUIRE(k > 0 && n > 0 && groups >= 0 && rows_per_group > 0 && rows_per_group < (1ll << 30), AVS_E_SHAPE,
-              "avs_conv1x1_bn_bf16: k=%d n=%d groups=%d rows_per_group=%lld", k, n, groups, (long long)rows_per_group);
+              "%s: k=%d n=%d groups=%d rows_per_group=%lld", who, k, n, groups, (long long)rows_per_group);
   if (groups == 0) return AVS_OK;
-  AVS_REQUIRE(d_x && d_w && d_gamma && d_beta && d_y, AVS_E_ARG, "avs_conv1x1_bn_bf16: null pointer");
+  const bool pre = d_pre_scale != nullptr;
+  AVS_REQUIRE(d_x && d_w && d_y && (pre ? d_pre_shift != nullptr : (d_gamma && d_beta)), AVS_E_ARG, "%s: null pointer",
+              who);
   AVS_REQUIRE(k % 8 == 0 && n % 8 == 0 && lin_stride % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && ldb >= k &&
                   ldc >= n && (!d_residual || (ldr % 8 == 0 && ldr >= n)),
-              AVS_E_SHAPE, "avs_conv1x1_bn_bf16: k, n and every stride must be multiples of 8 elements (16 bytes)");
+              AVS_E_SHAPE, "%s: k, n and every stride must be multiples of 8 elements (16 bytes)", who);
   AVS_REQUIRE(avs_aligned16(d_x) && avs_aligned16(d_w) && avs_aligned16(d_y) && avs_aligned16(d_residual),
-              AVS_E_ALIGN, "avs_conv1x1_bn_bf16: operands must be 16-byte aligned");
+              AVS_E_ALIGN, "%s: operands must be 16-byte aligned", who);
+  const bool xf = d_in_scale != nullptr;
+  if (xf) {
+    AVS_REQUIRE(d_in_shift, AVS_E_ARG, "%s: null input shift", who);
+    AVS_REQUIRE(k <= AVS_CONVBN_MAX_K, AVS_E_UNSUPPORTED, "%s: k=%d > %d", who, k, AVS_CONVBN_MAX_K);
+    AVS_REQUIRE(avs_aligned16(d_in_scale) && avs_aligned16(d_in_shift), AVS_E_ALIGN,
+                "%s: input scale / shift must be 16-byte aligned", who);
+  }
   ConvBnParams p{};
   p.x = (const char*)d_x;
   p.w = (const char*)d_w;
@@ -359,20 +374,350 @@ static int conv1x1_bn_launch(const void* d_x, int64_t lin_stride, int k, const v
   p.relu = relu;
   p.in_scale = d_in_scale;
   p.in_shift = d_in_shift;
-  const bool xf = d_in_scale != nullptr;
+  p.pre_scale = d_pre_scale;
+  p.pre_shift = d_pre_shift;
   const bool narrow = n <= 64 || g_convbn_narrow;
   const int bn = narrow ? 64 : 128;
   p.tiles_n = (n + bn - 1) / bn;
   const long long total = (long long)groups * p.tiles_n;
-  AVS_REQUIRE(total < (1ll << 31), AVS_E_SHAPE, "avs_conv1x1_bn_bf16: too many workgroups");
-  if (narrow && xf)
-    hipLaunchKernelGGL((conv1x1_bn_kernel<64, true>), dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, p);
-  else if (narrow)
-    hipLaunchKernelGGL((conv1x1_bn_kernel<64, false>), dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, p);
-  else if (xf)
-    hipLaunchKernelGGL((conv1x1_bn_kernel<128, true>), dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, p);
-  else
-    hipLaunchKernelGGL((conv1x1_bn_kernel<128, false>), dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, p);
-  AVS_CHECK_LAUNCH("avs_conv1x1_bn_bf16");
+  AVS_REQUIRE(total < (1ll << 31), AVS_E_SHAPE, "%s: too many workgroups", who);
+  const dim3 grid((unsigned)total), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define AVS_CONVBN_LAUNCH(BN_, XF_, PRE_) hipLaunchKernelGGL((conv1x1_bn_kernel<BN_, XF_, PRE_>), grid, block, 0, st, p)
+  if (pre) {
+    if (narrow && xf) AVS_CONVBN_LAUNCH(64, true, true);
+    else if (narrow) AVS_CONVBN_LAUNCH(64, false, true);
+    else if (xf) AVS_CONVBN_LAUNCH(128, true, true);
+    else AVS_CONVBN_LAUNCH(128, false, true);
+  } else {
+    if (narrow && xf) AVS_CONVBN_LAUNCH(64, true, false);
+    else if (narrow) AVS_CONVBN_LAUNCH(64, false, false);
+    else if (xf) AVS_CONVBN_LAUNCH(128, true, false);
+    else AVS_CONVBN_LAUNCH(128, false, false);
+  }
+#undef AVS_CONVBN_LAUNCH
+  AVS_CHECK_LAUNCH(who);
+  return AVS_OK;
+}
+
+extern "C" int avs_conv1x1_bn_bf16(const void* d_x, int64_t lin_stride, int k, const void* d_w, int64_t ldb, int n,
+                                   int64_t rows_per_group, int groups, const float* d_gamma, const float* d_beta,
+                                   float eps, const void* d_residual, int64_t ldr, int relu, void* d_y, int64_t ldc,
+                                   avs_stream_t stream) {
+  return conv1x1_bn_launch("avs_conv1x1_bn_bf16", d_x, lin_stride, k, d_w, ldb, n, rows_per_group, groups, d_gamma,
+                           d_beta, eps, d_residual, ldr, relu, d_y, ldc, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int avs_conv1x1_bn_in_bf16(const void* d_x, int64_t lin_stride, int k, const float* d_in_scale,
+                                      const float* d_in_shift, const void* d_w, int64_t ldb, int n,
+                                      int64_t rows_per_group, int groups, const float* d_gamma, const float* d_beta,
+                                      float eps, const void* d_residual, int64_t ldr, int relu, void* d_y,
+                                      int64_t ldc, avs_stream_t stream) {
+  AVS_REQUIRE(d_in_scale && d_in_shift, AVS_E_ARG, "avs_conv1x1_bn_in_bf16: null input scale / shift");
+  return conv1x1_bn_launch("avs_conv1x1_bn_in_bf16", d_x, lin_stride, k, d_w, ldb, n, rows_per_group, groups, d_gamma,
+                           d_beta, eps, d_residual, ldr, relu, d_y, ldc, d_in_scale, d_in_shift, nullptr, nullptr,
+                           stream);
+}
+
+extern "C" int avs_conv1x1_affine_bf16(const void* d_x, int64_t lin_stride, int k, const float* d_in_scale,
+                                       const float* d_in_shift, const void* d_w, int64_t ldb, int n,
+                                       int64_t rows_per_group, int groups, const float* d_scale, const float* d_shift,
+                                       const void* d_residual, int64_t ldr, int relu, void* d_y, int64_t ldc,
+                                       avs_stream_t stream) {
+  AVS_REQUIRE(d_scale && d_shift, AVS_E_ARG, "avs_conv1x1_affine_bf16: null output scale / shift");
+  return conv1x1_bn_launch("avs_conv1x1_affine_bf16", d_x, lin_stride, k, d_w, ldb, n, rows_per_group, groups, nullptr,
+                           nullptr, 0.f, d_residual, ldr, relu, d_y, ldc, d_in_scale, d_in_shift, d_scale, d_shift,
+                           stream);
+}
+
+// ============================================================================================================
+// BatchNorm batch statistics of y = a . w^T WITHOUT computing y: from the Gram matrix of a.
+//
+//   mean_y[n] = w_n . mean(a),   var_y[n] = w_n^T C w_n,   C = a^T a / R - mean(a) mean(a)^T   (K x K, per group)
+//
+// For the expanding 1x1 layers of ResNet layers 1-2 (K = 64 / 128 input channels, N = 4K outputs) the Gram matrix
+// costs K/N = 1/4 of the convolution's MACs and reads only the narrow input, so the convolution itself becomes ONE
+// streaming pass with the affine in its epilogue (avs_conv1x1_affine_bf16) instead of a statistics pass + an output
+// pass over the same group (avs_conv1x1_bn_bf16).  One workgroup per group:
+//   1. rows staged through registers (16-byte loads; the previous layer's BatchNorm + ReLU applied on the way, as in
+//      conv1x1_bn_kernel<XF>) into [64 rows][K] LDS tiles; per-channel sums on the VALU; a^T a on the matrix cores
+//      (v_mfma_f32_32x32x16_bf16: both operands are 32 channels x 16 ROWS, gathered from the row-major tile with
+//      2-byte LDS reads - the reduction index is the row);
+//   2. C in fp32 from the accumulators, split into bf16 hi + lo (16 significant bits) in LDS;
+//   3. T = W . C on the matrix cores (2 MFMAs per step: hi, lo; C is symmetric, so its rows are the B operand),
+//      var_y[n] = sum_l T[n,l] W[n,l] by a lane reduction, mean_y from the same W fragments, then the folded affine.
+// Deterministic (fixed reduction orders, no atomics).
+struct GramParams {
+  const char* x;
+  const char* w;
+  const float* in_scale;
+  const float* in_shift;
+  const float* gamma;
+  const float* beta;
+  float* scale;
+  float* shift;
+  long long lin_stride, ldb;
+  int N, rows_per_group;
+  float eps;
+};
+
+template <int K, bool XF>
+__global__ __launch_bounds__(256, 2) void bn_gram_affine_kernel(GramParams p) {
+  static_assert(K == 64 || K == 128, "input widths of the layer-1 / layer-2 expanding convolutions");
+  constexpr int CPR = K / 8;              // 16-byte chunks per row
+  constexpr int TR = 64;                  // rows per LDS tile
+  constexpr int RPT = 256 / CPR;          // rows one pass of the 256 threads stages
+  constexpr int NP = TR / RPT;            // chunks per thread per tile
+  constexpr int PITCH = K * 2 + 16;       // bytes per LDS row (tiles and C images)
+  constexpr int KB = K / 32;              // 32-channel blocks per side
+  constexpr int NBLK = (KB * KB) / 4;     // Gram blocks per wave: 1 (K = 64) or 4 (K = 128: one block row)
+  constexpr int TILE_BYTES = TR * PITCH;
+  constexpr int C_BYTES = K * PITCH;      // one bf16 K x K image
+  constexpr int MAIN_BYTES = 2 * C_BYTES > 2 * TILE_BYTES + RPT * K * 4 ? 2 * C_BYTES : 2 * TILE_BYTES + RPT * K * 4;
+  __shared__ __attribute__((aligned(16))) char lds[MAIN_BYTES];
+  __shared__ float mbar[K];
+  __shared__ float qbuf[4][32];
+
+  const int t = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int c = t % CPR, r0t = t / CPR;
+  const long long g = blockIdx.x;
+  const int R = p.rows_per_group;
+  const char* __restrict__ xg = p.x + g * R * p.lin_stride * 2;
+
+  float xsc[8], xsh[8];
+  if constexpr (XF) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      xsc[j] = p.in_scale[g * K + 8 * c + j];
+      xsh[j] = p.in_shift[g * K + 8 * c + j];
+    }
+  }
+  float cs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cs[j] = 0.f;
+
+  uint4 regs[NP];
+  auto gload = [&](int tile) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int row = tile * TR + r0t + RPT * q;
+      regs[q] = row < R ? *reinterpret_cast<const uint4*>(xg + (long long)row * p.lin_stride * 2 + c * 16)
+                        : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  auto xform_store = [&](int buf, int tile) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int row = tile * TR + r0t + RPT * q;
+      uint4 v = regs[q];
+      if (row < R) {
+        unsigned vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float lo = __uint_as_float(vv[j] << 16), hi = __uint_as_float(vv[j] & 0xffff0000u);
+          if constexpr (XF) {   // conv1x1_bn_kernel<XF>'s arithmetic: a = bf16(relu(x * scale + shift))
+            lo = fmaxf(lo * xsc[2 * j] + xsh[2 * j], 0.f);
+            hi = fmaxf(hi * xsc[2 * j + 1] + xsh[2 * j + 1], 0.f);
+            const unsigned short blo = avs_f32_to_bf16(lo), bhi = avs_f32_to_bf16(hi);
+            vv[j] = (unsigned)blo | ((unsigned)bhi << 16);
+            lo = avs_bf16_to_f32(blo);
+            hi = avs_bf16_to_f32(bhi);
+          }
+          cs[2 * j] += lo;
+          cs[2 * j + 1] += hi;
+        }
+        v = make_uint4(vv[0], vv[1], vv[2], vv[3]);
+      }
+      *reinterpret_cast<uint4*>(lds + buf * TILE_BYTES + (r0t + RPT * q) * PITCH + c * 16) = v;
+    }
+  };
+  // 32 channels (block b) x 16 rows (step s) of a tile as an MFMA operand: lane (lr, lh) takes channel 32 b + lr of
+  // rows 16 s + 8 lh .. + 7
+  auto gather = [&](const char* tile, int b, int s) -> bf16x8 {
+    const char* base = tile + (16 * s + 8 * lh) * PITCH + (32 * b + lr) * 2;
+    unsigned w4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned lo = *reinterpret_cast<const unsigned short*>(base + (2 * j) * PITCH);
+      const unsigned hi = *reinterpret_cast<const unsigned short*>(base + (2 * j + 1) * PITCH);
+      w4[j] = lo | (hi << 16);
+    }
+    return __builtin_bit_cast(bf16x8, make_uint4(w4[0], w4[1], w4[2], w4[3]));
+  };
+
+  f32x16 acc[NBLK];
+#pragma unroll
+  for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+
+  // ---- 1. a^T a and the channel sums over the group's rows
+  const int tiles = (R + TR - 1) / TR;
+  gload(0);
+  xform_store(0, 0);
+  __syncthreads();
+  for (int tile = 0; tile < tiles; ++tile) {
+    const int buf = tile & 1;
+    if (tile + 1 < tiles) gload(tile + 1);   // in flight during the matrix work below
+    const char* tb = lds + buf * TILE_BYTES;
+#pragma unroll
+    for (int s = 0; s < TR / 16; ++s) {
+      if constexpr (K == 64) {
+        const bf16x8 a = gather(tb, wave >> 1, s);
+        const bf16x8 b = gather(tb, wave & 1, s);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[0], 0, 0, 0);
+      } else {
+        const bf16x8 a = gather(tb, wave, s);
+#pragma unroll
+        for (int bj = 0; bj < KB; ++bj) {
+          const bf16x8 b = gather(tb, bj, s);
+          acc[bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[bj], 0, 0, 0);
+        }
+      }
+    }
+    if (tile + 1 < tiles) xform_store(buf ^ 1, tile + 1);
+    __syncthreads();
+  }
+
+  // channel sums: the RPT threads that share a chunk column, added in a fixed order
+  float* scratch = reinterpret_cast<float*>(lds + 2 * TILE_BYTES);   // [RPT][K]
+#pragma unroll
+  for (int j = 0; j < 8; ++j) scratch[r0t * K + 8 * c + j] = cs[j];
+  __syncthreads();
+  const float inv_r = 1.f / (float)R;
+  if (t < K) {
+    float m = 0.f;
+    for (int r = 0; r < RPT; ++r) m += scratch[r * K + t];
+    mbar[t] = m * inv_r;
+  }
+  __syncthreads();   // mbar visible; tiles and scratch are dead from here on
+
+  // ---- 2. C = a^T a / R - mean mean^T, as bf16 hi + lo images [K][PITCH] (symmetric)
+  char* chi = lds;
+  char* clo = lds + C_BYTES;
+#pragma unroll
+  for (int b = 0; b < NBLK; ++b) {
+    const int bi = K == 64 ? (wave >> 1) : wave;
+    const int bj = K == 64 ? (wave & 1) : b;
+    const int l = 32 * bj + lr;
+    const float ml = mbar[l];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int k = 32 * bi + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      const float cv = acc[b][e] * inv_r - mbar[k] * ml;
+      const unsigned short h = avs_f32_to_bf16(cv);
+      const unsigned short lo = avs_f32_to_bf16(cv - avs_bf16_to_f32(h));
+      *reinterpret_cast<unsigned short*>(chi + k * PITCH + l * 2) = h;
+      *reinterpret_cast<unsigned short*>(clo + k * PITCH + l * 2) = lo;
+    }
+  }
+  __syncthreads();
+
+  // ---- 3. var_y[n] = w_n^T C w_n, mean_y[n] = w_n . mean: 32 output channels per wave and turn
+  const char* __restrict__ w = p.w;
+  for (int n0 = wave * 32; n0 < p.N; n0 += 128) {
+    const int nrow = n0 + lr;   // N is a multiple of 32 (launcher)
+    uint4 wf[K / 16];           // this lane's W fragments: W[nrow][16 s + 8 lh .. + 7]
+#pragma unroll
+    for (int s = 0; s < K / 16; ++s)
+      wf[s] = *reinterpret_cast<const uint4*>(w + ((long long)nrow * p.ldb + 16 * s + 8 * lh) * 2);
+    float my = 0.f;
+#pragma unroll
+    for (int s = 0; s < K / 16; ++s) {
+      const unsigned vv[4] = {wf[s].x, wf[s].y, wf[s].z, wf[s].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        my = fmaf(__uint_as_float(vv[j] << 16), mbar[16 * s + 8 * lh + 2 * j], my);
+        my = fmaf(__uint_as_float(vv[j] & 0xffff0000u), mbar[16 * s + 8 * lh + 2 * j + 1], my);
+      }
+    }
+    my += __shfl_xor(my, 32, 64);
+    float part[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) part[e] = 0.f;
+#pragma unroll
+    for (int lt = 0; lt < KB; ++lt) {
+      f32x16 tt;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) tt[e] = 0.f;
+#pragma unroll
+      for (int s = 0; s < K / 16; ++s) {
+        const int off = (32 * lt + lr) * PITCH + (16 * s + 8 * lh) * 2;
+        const uint4 bh = *reinterpret_cast<const uint4*>(chi + off);
+        const uint4 bl = *reinterpret_cast<const uint4*>(clo + off);
+        tt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[s]), __builtin_bit_cast(bf16x8, bh),
+                                                     tt, 0, 0, 0);
+        tt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[s]), __builtin_bit_cast(bf16x8, bl),
+                                                     tt, 0, 0, 0);
+      }
+      // tt[e] = T[n0 + rowoff(e) + 4 lh][32 lt + lr]; times W at the same place
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = n0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const unsigned short wb = *reinterpret_cast<const unsigned short*>(w + ((long long)n * p.ldb + 32 * lt + lr) * 2);
+        part[e] = fmaf(tt[e], avs_bf16_to_f32(wb), part[e]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      float v = part[e];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lr == 0) qbuf[wave][(e & 3) + 8 * (e >> 2) + 4 * lh] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lh == 0) {
+      const float var = fmaxf(qbuf[wave][lr], 0.f);
+      const float sc = p.gamma[nrow] / sqrtf(var + p.eps);
+      p.scale[g * p.N + nrow] = sc;
+      p.shift[g * p.N + nrow] = p.beta[nrow] - my * sc;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+extern "C" int avs_bn_gram_affine_bf16(const void* d_x, int64_t lin_stride, int k, const float* d_in_scale,
+                                       const float* d_in_shift, const void* d_w, int64_t ldb, int n,
+                                       int64_t rows_per_group, int groups, const float* d_gamma, const float* d_beta,
+                                       float eps, float* d_scale, float* d_shift, avs_stream_t stream) {
+  const char* who = "avs_bn_gram_affine_bf16";
+  AVS_REQUIRE(k == 64 || k == 128, AVS_E_UNSUPPORTED, "%s: k = %d (built for 64 and 128 input channels)", who, k);
+  AVS_REQUIRE(n > 0 && n % 32 == 0, AVS_E_UNSUPPORTED, "%s: n = %d must be a multiple of 32", who, n);
+  AVS_REQUIRE(groups >= 0 && rows_per_group > 0 && rows_per_group < (1ll << 30), AVS_E_SHAPE,
+              "%s: groups=%d rows_per_group=%lld", who, groups, (long long)rows_per_group);
+  if (groups == 0) return AVS_OK;
+  AVS_REQUIRE(d_x && d_w && d_gamma && d_beta && d_scale && d_shift, AVS_E_ARG, "%s: null pointer", who);
+  AVS_REQUIRE((d_in_scale == nullptr) == (d_in_shift == nullptr), AVS_E_ARG, "%s: input scale and shift go together", who);
+  AVS_REQUIRE(lin_stride % 8 == 0 && lin_stride >= k && ldb % 8 == 0 && ldb >= k, AVS_E_SHAPE,
+              "%s: strides must be multiples of 8 elements (16 bytes) and at least k", who);
+  AVS_REQUIRE(avs_aligned16(d_x) && avs_aligned16(d_w), AVS_E_ALIGN, "%s: x / w must be 16-byte aligned", who);
+  GramParams p{};
+  p.x = (const char*)d_x;
+  p.w = (const char*)d_w;
+  p.in_scale = d_in_scale;
+  p.in_shift = d_in_shift;
+  p.gamma = d_gamma;
+  p.beta = d_beta;
+  p.scale = d_scale;
+  p.shift = d_shift;
+  p.lin_stride = lin_stride;
+  p.ldb = ldb;
+  p.N = n;
+  p.rows_per_group = (int)rows_per_group;
+  p.eps = eps;
+  const dim3 grid((unsigned)groups), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const bool xf = d_in_scale != nullptr;
+  if (k == 64) {
+    if (xf) hipLaunchKernelGGL((bn_gram_affine_kernel<64, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((bn_gram_affine_kernel<64, false>), grid, block, 0, st, p);
+  } else {
+    if (xf) hipLaunchKernelGGL((bn_gram_affine_kernel<128, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((bn_gram_affine_kernel<128, false>), grid, block, 0, st, p);
+  }
+  AVS_CHECK_LAUNCH(who);
   return AVS_OK;
 }

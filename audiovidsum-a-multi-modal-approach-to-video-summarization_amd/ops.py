@@ -11,7 +11,7 @@ from . import _abi
 from ._abi import ACT_NONE, ACT_RELU, AVS_BF16, AVS_F32, BIAS_COL, BIAS_NONE, BIAS_ROW, check, lib
 
 __all__ = [
-    "ACT_NONE", "ACT_RELU", "linear", "gemm_nt_batched", "conv2d", "conv2d_raw", "conv_bnlocal_tile_rows", "conv1x1_bn", "frames_normalize", "resize_bilinear",
+    "ACT_NONE", "ACT_RELU", "linear", "gemm_nt_batched", "conv2d", "conv2d_raw", "conv_bnlocal_tile_rows", "conv1x1_bn", "conv1x1_gram_bn", "bn_gram_affine", "gram_supported", "frames_normalize", "resize_bilinear",
     "bn_batch_stats", "bn_apply", "bn_maxpool", "pool2d", "global_avgpool", "segment_mean", "hsv_frame_diff", "reflect_pad", "stft_f64", "power_mel",
     "clamp_topdb", "fill", "quantize", "resample", "lstm", "mha_batchaxis", "score_head", "mhsa_flash", "softmax_rows", "cdist", "dtw_path",
     "gather_scale", "dtype_code",
@@ -272,6 +272,66 @@ def conv1x1_bn(x2d, wt, rows_per_group, gamma, beta, eps, out2d, residual=None, 
                                   _p(gamma), _p(beta), float(eps), _p(residual),
                                   residual.stride(0) if residual is not None else 0, 1 if relu else 0, _p(out2d),
                                   out2d.stride(0), _stream()), "avs_conv1x1_bn_bf16"))
+    return out2d
+
+
+def gram_supported(k, n):
+    """Shapes avs_bn_gram_affine_bf16 takes (the expanding 1x1 layers of ResNet layers 1-2)."""
+    return k in (64, 128) and n % 32 == 0
+
+
+def bn_gram_affine(x2d, wt, rows_per_group, gamma, beta, eps, in_affine=None):
+    """Folded BatchNorm affine (scale, shift) fp32 [groups, N] of y = a . wt^T per group of rows, computed from the
+    Gram matrix of a WITHOUT forming y (avs_bn_gram_affine_bf16).  a = x2d, or bf16(relu(x2d * isc + ish)) with
+    in_affine = (isc, ish) fp32 [groups, K].  K in {64, 128}, N a multiple of 32."""
+    _dev(x2d, wt, gamma, beta)
+    _rowmajor2d(x2d, "x")
+    _rowmajor2d(wt, "w")
+    rows, k = x2d.shape
+    n = wt.shape[0]
+    if x2d.dtype != torch.bfloat16 or wt.dtype != torch.bfloat16:
+        raise TypeError("bn_gram_affine is the bf16 throughput path")
+    if rows % rows_per_group or wt.shape[1] != k:
+        raise ValueError("bn_gram_affine: shapes do not match")
+    groups = rows // rows_per_group
+    isc = ish = None
+    if in_affine is not None:
+        isc, ish = in_affine
+        _dev(isc, ish)
+        if isc.shape != (groups, k) or ish.shape != (groups, k) or not isc.is_contiguous() or not ish.is_contiguous():
+            raise ValueError("in_affine must be contiguous fp32 [groups, K]")
+    scale = torch.empty((groups, n), dtype=torch.float32, device=x2d.device)
+    shift = torch.empty((groups, n), dtype=torch.float32, device=x2d.device)
+    # algorithmic HBM bytes: x read once
+    _timed("gram", AVS_BF16, 2.0 * rows * k, lambda: check(
+        lib().avs_bn_gram_affine_bf16(_p(x2d), x2d.stride(0), k, _p(isc), _p(ish), _p(wt), wt.stride(0), n,
+                                      rows_per_group, groups, _p(gamma), _p(beta), float(eps), _p(scale), _p(shift),
+                                      _stream()), "avs_bn_gram_affine_bf16"))
+    return scale, shift
+
+
+def conv1x1_gram_bn(x2d, wt, rows_per_group, gamma, beta, eps, out2d, residual=None, relu=True, in_affine=None):
+    """1x1 convolution + batch-statistics BatchNorm (+residual, +ReLU), bf16, same operands as conv1x1_bn, in ONE
+    streaming pass over the output: the statistics come from the Gram matrix of the narrow input (bn_gram_affine),
+    the convolution applies the folded affine in its epilogue (avs_conv1x1_affine_bf16)."""
+    _dev(out2d, residual)
+    _rowmajor2d(out2d, "out")
+    rows, k = x2d.shape
+    n = wt.shape[0]
+    if out2d.dtype != torch.bfloat16 or out2d.shape != (rows, n):
+        raise ValueError("conv1x1_gram_bn: out must be bf16 [rows, N]")
+    if residual is not None:
+        _rowmajor2d(residual, "residual")
+    scale, shift = bn_gram_affine(x2d, wt, rows_per_group, gamma, beta, eps, in_affine)
+    groups = rows // rows_per_group
+    isc, ish = in_affine if in_affine is not None else (None, None)
+    # algorithmic HBM bytes: read x, write y (+ read the residual)
+    nbytes = 2.0 * rows * (k + n * (2 if residual is not None else 1))
+    _timed("convbn", AVS_BF16, nbytes, lambda: check(
+        lib().avs_conv1x1_affine_bf16(_p(x2d), x2d.stride(0), k, _p(isc), _p(ish), _p(wt), wt.stride(0), n,
+                                      rows_per_group, groups, _p(scale), _p(shift), _p(residual),
+                                      residual.stride(0) if residual is not None else 0, 1 if relu else 0, _p(out2d),
+                                      out2d.stride(0), _stream()), "avs_conv1x1_affine_bf16"))
     return out2d
 
 

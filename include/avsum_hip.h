@@ -141,6 +141,26 @@ int avs_conv1x1_bn_in_bf16(const void* d_x, int64_t lin_stride, int k, const flo
                            float eps, const void* d_residual, int64_t ldr, int relu, void* d_y, int64_t ldc,
                            avs_stream_t stream);
 
+/* The expanding 1x1 layers of ResNet layers 1-2 in ONE streaming pass: the BatchNorm statistics of y = a . w^T
+ * follow from the Gram matrix of the (narrow) input,
+ *   mean_y[n] = w_n . mean(a),  var_y[n] = w_n^T C w_n,  C = a^T a / R - mean(a) mean(a)^T  per group of R rows,
+ * so avs_bn_gram_affine_bf16 reads only a (k = 64 or 128 channels; a^T a and W . C on the matrix cores, C carried as
+ * bf16 hi + lo = 16 significant bits, everything else fp32; deterministic) and writes the folded affine
+ * d_scale / d_shift [groups, n] of bn(conv(a)); avs_conv1x1_affine_bf16 is then the convolution with that affine
+ * (+ residual, + ReLU) in its epilogue - no statistics pass over the wide output.  Same operands and meaning as
+ * avs_conv1x1_bn_in_bf16 (d_in_scale / d_in_shift = NULL: a is x itself; else a = bf16(relu(x * in_scale + in_shift)),
+ * the previous layer's BatchNorm applied on the way in).  Replaces avs_conv1x1_bn[_in]_bf16 for k in {64, 128},
+ * n % 32 == 0 (features/extractors.py:29,65: conv3 / downsample of the train-mode ResNet bottlenecks); other
+ * shapes: AVS_E_UNSUPPORTED.  Statistics agree with the two-pass kernel's to fp32 rounding, not bit for bit.     */
+int avs_bn_gram_affine_bf16(const void* d_x, int64_t lin_stride, int k, const float* d_in_scale,
+                            const float* d_in_shift, const void* d_w, int64_t ldb, int n, int64_t rows_per_group,
+                            int groups, const float* d_gamma, const float* d_beta, float eps, float* d_scale,
+                            float* d_shift, avs_stream_t stream);
+int avs_conv1x1_affine_bf16(const void* d_x, int64_t lin_stride, int k, const float* d_in_scale,
+                            const float* d_in_shift, const void* d_w, int64_t ldb, int n, int64_t rows_per_group,
+                            int groups, const float* d_scale, const float* d_shift, const void* d_residual,
+                            int64_t ldr, int relu, void* d_y, int64_t ldc, avs_stream_t stream);
+
 /* Tuning knob: 1 = 64-channel slabs (4 workgroups per CU) in avs_conv1x1_bn_bf16 whatever n is.          */
 void avs_tune_convbn_narrow(int enabled);
 

@@ -304,6 +304,57 @@ def test_conv1x1_bn_input_affine_is_bn_apply_first(dev, rpg, k, n, with_res):
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("rpg,k,n,with_res,xf", [(3136, 64, 256, True, True), (784, 128, 512, True, True),
+                                                  (3136, 64, 256, False, False), (300, 64, 64, False, True),
+                                                  (100, 128, 224, True, False), (64, 128, 32, False, True)])
+def test_conv1x1_gram_statistics_and_streaming_pass(dev, rpg, k, n, with_res, xf):
+    """avs_bn_gram_affine_bf16 (BatchNorm statistics of a 1x1 convolution from the Gram matrix of its input) against
+    float64 statistics of the actual products, and the one-pass convolution with that affine against (i) the same
+    arithmetic in fp32 and (ii) the two-pass kernel.  Groups whose row count is not a multiple of the 64-row tile,
+    input affine (previous BatchNorm + ReLU) on and off; deterministic."""
+    from avsum_amd import ops
+    g = torch.Generator().manual_seed(rpg + k + n)
+    groups = 3
+    rows = groups * rpg
+    raw = (torch.randn(rows, k, generator=g) * 1.5 + 0.3).bfloat16()
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).bfloat16()
+    gamma, beta = torch.rand(n, generator=g) + 0.5, torch.randn(n, generator=g)
+    res = torch.randn(rows, n, generator=g).bfloat16() if with_res else None
+    in_aff = None
+    a = raw.float()
+    if xf:
+        isc, ish = torch.randn(groups, k, generator=g), torch.randn(groups, k, generator=g)
+        in_aff = (isc.to(dev), ish.to(dev))
+        a = torch.relu(raw.float().view(groups, rpg, k) * isc[:, None, :] + ish[:, None, :]).bfloat16().float().view(rows, k)
+    y = a.double() @ w.double().t()
+    yg = y.view(groups, rpg, n)
+    mean, var = yg.mean(1), yg.var(1, unbiased=False)
+    sc_ref = gamma.double() / torch.sqrt(var + 1e-5)
+    sh_ref = beta.double() - mean * sc_ref
+    xd, wd, gd, bd = raw.to(dev), w.to(dev), gamma.to(dev), beta.to(dev)
+    sc, sh = ops.bn_gram_affine(xd, wd, rpg, gd, bd, 1e-5, in_aff)
+    assert sc.shape == (groups, n)
+    assert ((sc.cpu().double() - sc_ref).abs() / sc_ref.abs()).max().item() < 2e-4
+    assert (sh.cpu().double() - sh_ref).abs().max().item() < 2e-4 * max(1.0, sh_ref.abs().max().item())
+    sc2, sh2 = ops.bn_gram_affine(xd, wd, rpg, gd, bd, 1e-5, in_aff)
+    assert torch.equal(sc, sc2) and torch.equal(sh, sh2)
+    ref = (yg * sc_ref[:, None, :] + sh_ref[:, None, :]).view(rows, n).float()
+    if with_res:
+        ref = ref + res.float()
+    ref = torch.relu(ref)
+    out = torch.empty(rows, n, dtype=torch.bfloat16, device=dev)
+    rd = res.to(dev) if with_res else None
+    ops.conv1x1_gram_bn(xd, wd, rpg, gd, bd, 1e-5, out, rd, True, in_aff)
+    got = out.float().cpu()
+    scale = max(1.0, ref.abs().max().item())
+    assert (got - ref).abs().max().item() < 0.03 * scale and (got - ref).abs().mean().item() < 0.004 * scale
+    two = torch.empty_like(out)
+    ops.conv1x1_bn(xd, wd, rpg, gd, bd, 1e-5, two, rd, True, in_aff)
+    # same products, affines equal to fp32 rounding: outputs differ by at most one bf16 step here and there
+    diff = (got - two.float().cpu()).abs()
+    assert diff.max().item() < 0.02 * scale and (diff > 0).float().mean().item() < 0.05
+
+
 def test_resnet50_bf16_deferred_bn_apply_close(dev):
     """Whole trunk with bn2 applied inside conv3's kernel vs applied by its own pass: the same arithmetic, every
     kernel on the path deterministic => bit-identical features."""
