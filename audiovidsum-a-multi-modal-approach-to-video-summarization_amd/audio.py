@@ -6,11 +6,15 @@ not in the reference tree; its defaults are restated in SURVEY Appendix A.1-A.4:
 n_fft = win = 400, periodic Hann, hop 200, center/reflect, power 2, HTK mel
 scale 0..sr/2, norm None, DCT-II ortho, AmplitudeToDB('power', top_db=80)).
 
-Constants are built once per (sample_rate, device) in float64 and rounded to
-fp32 (filterbank, DCT) or kept in float64 (the windowed DFT basis); the Hann
-window is folded into the basis so the STFT is one dense contraction on the
-fp64 matrix cores whose rows are the overlapping frames of the reflect-padded
-waveform, read in place (row stride = hop).
+Constants are built once per (sample_rate, device): filterbank and DCT in fp32
+(the reference's own fp32 evaluation), the window's fp32 values and the cos / -sin
+tables of the 400-point DFT in float64.  log2-mel, mel power and the dB spectrogram
+come from ONE fused kernel (avs_stft_mel_fused_f32): a block stages the waveform
+span of its 32 frames in LDS (reflect padding by index, no padded copy), runs the
+real DFT - folded to half its length by the symmetry of the window and the
+cosines - on the fp64 matrix cores, and applies |.|^2, the sparse mel sum and the
+log without the spectrum ever leaving the chip.  ``spectrum`` keeps the unfused
+dense-DFT kernel (the form VGGish's 512-point front end uses) for tests.
 """
 import math
 
@@ -63,6 +67,24 @@ def windowed_dft_basis():
     return np.concatenate([np.cos(ang) * window, -np.sin(ang) * window], 0)
 
 
+FUSED_COLS = 208      # 201 bins padded to 13 tiles of 16 (avs_stft_mel_fused_f32)
+FUSED_RE_ROWS = 204   # n = 0 .. 200 padded to a multiple of 4
+FUSED_IM_ROWS = 200   # n = 1 .. 199 padded to a multiple of 4
+
+
+def folded_dft_tables():
+    """Tables of the folded real DFT: cos[n, k] = cos(2 pi k n / 400) for n = 0..200, -sin[n - 1, k] for n = 1..199
+    (k = 0..200), zero elsewhere; float64, the argument reduced mod 400 before the evaluation."""
+    k = np.arange(N_BINS)[None, :]
+    cos_t = np.zeros((FUSED_RE_ROWS, FUSED_COLS), dtype=np.float64)
+    n = np.arange(0, N_FFT // 2 + 1)[:, None]
+    cos_t[:N_FFT // 2 + 1, :N_BINS] = np.cos(2.0 * math.pi * ((k * n) % N_FFT) / N_FFT)
+    sin_t = np.zeros((FUSED_IM_ROWS, FUSED_COLS), dtype=np.float64)
+    n = np.arange(1, N_FFT // 2)[:, None]
+    sin_t[:N_FFT // 2 - 1, :N_BINS] = -np.sin(2.0 * math.pi * ((k * n) % N_FFT) / N_FFT)
+    return cos_t, sin_t
+
+
 class MelPlan:
     """Device-resident constants + the launch sequence for log2-mel and MFCC."""
 
@@ -82,6 +104,11 @@ class MelPlan:
         self.fb_lo = torch.from_numpy(lo).to(device)
         self.fb_hi = torch.from_numpy(hi).to(device)
         self.dct = torch.from_numpy(dct_matrix(n_mfcc, n_mels).astype(np.float32)).to(device)
+        cos_t, sin_t = folded_dft_tables()
+        self.cos_t = torch.from_numpy(cos_t).to(device)
+        self.sin_t = torch.from_numpy(sin_t).to(device)
+        # the float32 values of torch.hann_window(400) (periodic): the window the reference multiplies by
+        self.window = torch.hann_window(N_FFT).double().to(device)
 
     @classmethod
     def get(cls, sample_rate, n_mels, n_mfcc, device):
@@ -105,19 +132,36 @@ class MelPlan:
         padded = ops.reflect_pad(wave.contiguous(), N_FFT // 2, t + N_FFT)
         return ops.stft_f64(padded, frames, HOP, N_FFT, self.basis_t, 2 * N_BINS)
 
+    def _fused(self, wave, log2=False, db=False, power=False):
+        t = wave.numel()
+        if t <= N_FFT // 2:
+            # torch.stft(center=True, pad_mode="reflect") raises for T <= pad as well
+            raise RuntimeError(f"Argument #4: Padding size should be less than the corresponding input dimension, "
+                               f"but got: padding ({N_FFT // 2}, {N_FFT // 2}) at dimension 1 of input [1, {t}]")
+        wave = wave.contiguous()
+        if wave.data_ptr() % 16:
+            wave = wave.clone()   # a slice that starts off a 16-byte boundary: the kernel stages with 16-byte loads
+        return ops.stft_mel_fused(wave, self.window, self.cos_t, self.sin_t, self.fb, self.fb_lo,
+                                  self.fb_hi, log2, db, power)
+
     def log2_mel(self, wave):
         """[frames, n_mels] = log2(mel + 1e-6)  (features/extractors.py:241-246)."""
-        return ops.power_mel(self.spectrum(wave), N_BINS, self.fb, self.fb_lo, self.fb_hi, 0)
+        return self._fused(wave, log2=True)[0]
 
     def mel_power(self, wave):
-        return ops.power_mel(self.spectrum(wave), N_BINS, self.fb, self.fb_lo, self.fb_hi, 2)
+        return self._fused(wave, power=True)[2]
 
     def mfcc(self, wave, top_db=80.0):
         """[frames, n_mfcc] (torchaudio MFCC, log_mels=False)."""
-        gmax = torch.zeros(1, dtype=torch.float32, device=wave.device)
-        db = ops.power_mel(self.spectrum(wave), N_BINS, self.fb, self.fb_lo, self.fb_hi, 1, gmax)
+        _, db, _, gmax = self._fused(wave, db=True)
         ops.clamp_topdb(db, gmax, top_db)
         return ops.linear(db, self.dct)
+
+    def log2_mel_and_mfcc(self, wave, top_db=80.0):
+        """Both features of one waveform from ONE pass over it (the spectrum is shared): ([frames, n_mels], [frames, n_mfcc])."""
+        mel, db, _, gmax = self._fused(wave, log2=True, db=True)
+        ops.clamp_topdb(db, gmax, top_db)
+        return mel, ops.linear(db, self.dct)
 
 
 # --------------------------------------------------------------------------- channel mix-down + resampling (F4)

@@ -163,6 +163,154 @@ extern "C" int avs_power_mel_f32(const float* d_spec, int64_t frames, int nbins,
   return AVS_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Fused front end of torchaudio's MelSpectrogram / MFCC defaults (n_fft = win = 400, hop 200, center / reflect,
+// power 2; features/extractors.py:236-246): waveform -> log2(mel + 1e-6) and / or 10 log10(mel) in ONE kernel.
+//   * a block owns 32 STFT frames: its waveform span (32 * 200 + 200 samples, reflect padding resolved by index) is
+//     staged ONCE in LDS with 16-byte loads; no padded copy of the waveform, no spectrum in HBM;
+//   * the 400-point real DFT is folded: with e[n] = w[n] x[n] + w[400-n] x[400-n] and o[n] = w[n] x[n] - w[400-n] x[400-n]
+//     (fp64: products of fp32 values are exact)   Re X[k] = w0 x0 + (-1)^k w200 x200 + sum_{n=1..199} e[n] cos(2 pi k n / 400),
+//     Im X[k] = - sum_{n=1..199} o[n] sin(2 pi k n / 400): half the reduction length of the dense DFT, the same exact
+//     arithmetic (v_mfma_f64_16x16x4_f64, tables of cos / -sin in fp64);
+//   * |X|^2 (fp32, from the fp32-rounded re / im as before) goes to LDS, the sparse mel sum (<= 2 filters per bin,
+//     ascending bin order) and the log run on it, and only the [frames, n_mels] results are written.
+// Wave w: frames 16 (w & 1) .. + 15, column tiles 7 (w >> 1) .. of the 13 16-bin tiles (208 >= 201 bins).
+// ---------------------------------------------------------------------------
+#define AVS_FUSED_FPB 32
+#define AVS_FUSED_NFFT 400
+#define AVS_FUSED_HOP 200
+#define AVS_FUSED_BINS 201
+#define AVS_FUSED_COLS 208   // bins padded to 13 tiles of 16
+#define AVS_FUSED_RE_ROWS 204  // n = 0 .. 200 padded to a multiple of 4
+#define AVS_FUSED_IM_ROWS 200  // n = 1 .. 199 padded to a multiple of 4
+
+__global__ __launch_bounds__(256, 2) void stft_mel_fused_kernel(
+    const float* __restrict__ x, long long t, long long frames, const double* __restrict__ window,
+    const double* __restrict__ cos_t, const double* __restrict__ sin_t, const float* __restrict__ fb,
+    const int* __restrict__ fb_lo, const int* __restrict__ fb_hi, int nmel, float* __restrict__ out_log2,
+    float* __restrict__ out_db, float* __restrict__ out_pow, float* __restrict__ gmax) {
+  constexpr int SPAN = AVS_FUSED_FPB * AVS_FUSED_HOP + (AVS_FUSED_NFFT - AVS_FUSED_HOP);   // 6600 samples
+  __shared__ __attribute__((aligned(16))) float span[SPAN];
+  __shared__ double win[AVS_FUSED_NFFT];
+  __shared__ float pw[AVS_FUSED_FPB][AVS_FUSED_BINS + 3];
+  const int tid = threadIdx.x;
+  const long long f0 = (long long)blockIdx.x * AVS_FUSED_FPB;
+  // ---- stage the span: padded position q = f0 * 200 + i is sample q - 200, reflected at both ends
+  const long long q0 = f0 * AVS_FUSED_HOP - AVS_FUSED_NFFT / 2;
+  for (int i = tid * 4; i < SPAN; i += 256 * 4) {
+    const long long j = q0 + i;
+    float4 v;
+    if (j >= 0 && j + 3 < t) {
+      v = *reinterpret_cast<const float4*>(x + j);   // q0 and i are multiples of 4, x is 16-byte aligned
+    } else {
+      float e[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        long long jj = j + u;
+        if (jj < 0) jj = -jj;
+        if (jj >= t) jj = 2 * (t - 1) - jj;
+        e[u] = (jj >= 0 && jj < t) ? x[jj] : 0.f;   // beyond the last frame's window: unused
+      }
+      v = make_float4(e[0], e[1], e[2], e[3]);
+    }
+    *reinterpret_cast<float4*>(span + i) = v;
+  }
+  for (int i = tid; i < AVS_FUSED_NFFT; i += 256) win[i] = window[i];
+  __syncthreads();
+
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int fg = wave & 1;
+  const int tile0 = (wave >> 1) * 7, ntile = (wave >> 1) ? 6 : 7;   // 13 tiles = 7 + 6
+  const float* __restrict__ srow = span + (fg * 16 + lr) * AVS_FUSED_HOP;
+  f64x4 re[7], im[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    re[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    im[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  }
+  // real part: n = 0 .. 203 (n = 0 and 200 unfolded, 201 .. 203 zero rows of the table)
+  for (int k0 = 0; k0 < AVS_FUSED_RE_ROWS; k0 += 4) {
+    const int n = k0 + lq;
+    double a = 0.0;
+    if (n <= 200) {
+      a = win[n] * (double)srow[n];
+      if (n >= 1 && n <= 199) a += win[AVS_FUSED_NFFT - n] * (double)srow[AVS_FUSED_NFFT - n];
+    }
+    const double* __restrict__ brow = cos_t + (long long)n * AVS_FUSED_COLS + tile0 * 16 + lr;
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+      if (i < ntile) re[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, brow[i * 16], re[i], 0, 0, 0);
+  }
+  // imaginary part: n = 1 .. 200 (the n = 200 row of the table is zero)
+  for (int k0 = 0; k0 < AVS_FUSED_IM_ROWS; k0 += 4) {
+    const int n = 1 + k0 + lq;
+    double a = 0.0;
+    if (n <= 199) a = win[n] * (double)srow[n] - win[AVS_FUSED_NFFT - n] * (double)srow[AVS_FUSED_NFFT - n];
+    const double* __restrict__ brow = sin_t + (long long)(n - 1) * AVS_FUSED_COLS + tile0 * 16 + lr;
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+      if (i < ntile) im[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, brow[i * 16], im[i], 0, 0, 0);
+  }
+  // |X|^2 of the fp32-rounded spectrum: result register j of a lane is frame lq + 4 j, bin tile * 16 + lr
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    if (i >= ntile) continue;
+    const int bin = (tile0 + i) * 16 + lr;
+    if (bin >= AVS_FUSED_BINS) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float r = (float)re[i][j], m = (float)im[i][j];
+      pw[fg * 16 + lq + 4 * j][bin] = r * r + m * m;
+    }
+  }
+  __syncthreads();
+  // ---- mel + log: a thread owns (frame, mel) pairs and sums its filter's non-zero bins in ascending order
+  const int nf = (int)((frames - f0) < AVS_FUSED_FPB ? (frames - f0) : AVS_FUSED_FPB);
+  float lmax = 0.f;
+  for (int i = tid; i < nf * nmel; i += 256) {
+    const int f = i / nmel, m = i - f * nmel;
+    const int lo = fb_lo[m], hi = fb_hi[m];
+    float a = 0.f;
+    for (int k = lo; k < hi; ++k) a += pw[f][k] * fb[(long long)k * nmel + m];
+    const long long o = (f0 + f) * nmel + m;
+    if (out_log2) out_log2[o] = log2f(a + 1e-6f);
+    if (out_db) {
+      const float cl = fmaxf(a, 1e-10f);
+      lmax = fmaxf(lmax, cl);
+      out_db[o] = 10.f * log10f(cl);
+    }
+    if (out_pow) out_pow[o] = a;
+  }
+  if (out_db) {
+    lmax = avs_wave_max(lmax);
+    // positive floats order like their bit patterns: an integer max, order-independent
+    if ((tid & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(gmax), __float_as_uint(lmax));
+  }
+}
+
+extern "C" int avs_stft_mel_fused_f32(const float* d_wave, int64_t t, const double* d_window, const double* d_cos,
+                                      const double* d_sin, const float* d_fb, const int* d_fb_lo, const int* d_fb_hi,
+                                      int nmel, float* d_log2mel, float* d_db, float* d_power, float* d_max,
+                                      avs_stream_t stream) {
+  const char* who = "avs_stft_mel_fused_f32";
+  AVS_REQUIRE(t > AVS_FUSED_NFFT / 2, AVS_E_SHAPE, "%s: reflect padding needs more than %d samples, got %lld", who,
+              AVS_FUSED_NFFT / 2, (long long)t);
+  AVS_REQUIRE(nmel > 0 && nmel <= 1024, AVS_E_SHAPE, "%s: nmel=%d", who, nmel);
+  AVS_REQUIRE(d_wave && d_window && d_cos && d_sin && d_fb && d_fb_lo && d_fb_hi, AVS_E_ARG, "%s: null pointer", who);
+  AVS_REQUIRE(d_log2mel || d_db || d_power, AVS_E_ARG, "%s: no output requested", who);
+  AVS_REQUIRE(!d_db || d_max, AVS_E_ARG, "%s: the dB output needs d_max", who);
+  AVS_REQUIRE(avs_aligned16(d_wave), AVS_E_ALIGN, "%s: the waveform must be 16-byte aligned", who);
+  const long long frames = 1 + t / AVS_FUSED_HOP;
+  const long long blocks = avs_cdiv(frames, AVS_FUSED_FPB);
+  AVS_REQUIRE(blocks < (1ll << 31), AVS_E_SHAPE, "%s: too many frames", who);
+  hipLaunchKernelGGL(stft_mel_fused_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_wave,
+                     (long long)t, frames, d_window, d_cos, d_sin, d_fb, d_fb_lo, d_fb_hi, nmel, d_log2mel, d_db, d_power,
+                     d_max);
+  AVS_CHECK_LAUNCH(who);
+  return AVS_OK;
+}
+
 __global__ __launch_bounds__(256) void clamp_topdb_kernel(float* __restrict__ x, long long count,
                                                           const float* __restrict__ gmax, float top_db) {
   const float thr = 10.f * log10f(*gmax) - top_db;

@@ -12,7 +12,7 @@ from ._abi import ACT_NONE, ACT_RELU, AVS_BF16, AVS_F32, BIAS_COL, BIAS_NONE, BI
 
 __all__ = [
     "ACT_NONE", "ACT_RELU", "linear", "gemm_nt_batched", "conv2d", "conv2d_raw", "conv_bnlocal_tile_rows", "conv1x1_bn", "conv1x1_gram_bn", "bn_gram_affine", "gram_supported", "frames_normalize", "resize_bilinear",
-    "bn_batch_stats", "bn_apply", "bn_maxpool", "pool2d", "global_avgpool", "segment_mean", "hsv_frame_diff", "reflect_pad", "stft_f64", "power_mel",
+    "bn_batch_stats", "bn_apply", "bn_maxpool", "pool2d", "global_avgpool", "segment_mean", "hsv_frame_diff", "reflect_pad", "stft_f64", "stft_mel_fused", "power_mel",
     "clamp_topdb", "fill", "quantize", "resample", "lstm", "mha_batchaxis", "score_head", "mhsa_flash", "softmax_rows", "cdist", "dtw_path",
     "gather_scale", "dtype_code",
 ]
@@ -502,6 +502,31 @@ def power_mel(spec, nbins, fb, fb_lo, fb_hi, mode, gmax=None):
     check(lib().avs_power_mel_f32(_p(spec), frames, nbins, _p(fb), _p(fb_lo), _p(fb_hi), nmel, mode, _p(out),
                                   _p(gmax), _stream()), "avs_power_mel_f32")
     return out
+
+
+def stft_mel_fused(wave, window, cos_t, sin_t, fb, fb_lo, fb_hi, log2=False, db=False, power=False):
+    """wave fp32 [T] on device (T > 200) -> (log2(mel + 1e-6) | None, 10 log10(max(mel, 1e-10)) | None, mel | None,
+    max of the clamped mel power fp32 [1] | None), each [1 + T // 200, n_mels]: torchaudio's MelSpectrogram defaults
+    (n_fft = win = 400, hop 200, center / reflect, power 2) in one kernel (avs_stft_mel_fused_f32)."""
+    _dev(wave, window, cos_t, sin_t, fb)
+    _f32(wave, "wave")
+    if wave.dim() != 1 or not wave.is_contiguous():
+        raise ValueError("wave must be a contiguous 1-D tensor")
+    if window.dtype != torch.float64 or cos_t.dtype != torch.float64 or sin_t.dtype != torch.float64:
+        raise TypeError("window and DFT tables must be float64")
+    if tuple(cos_t.shape) != (204, 208) or tuple(sin_t.shape) != (200, 208) or window.numel() != 400:
+        raise ValueError("tables must be cos [204, 208], -sin [200, 208], window [400]")
+    t = wave.numel()
+    frames = 1 + t // 200
+    nmel = fb.shape[1]
+    mk = lambda on: torch.empty((frames, nmel), dtype=torch.float32, device=wave.device) if on else None
+    o_log2, o_db, o_pow = mk(log2), mk(db), mk(power)
+    gmax = torch.zeros(1, dtype=torch.float32, device=wave.device) if db else None
+    nbytes = 4.0 * t + 4.0 * frames * nmel * (int(log2) + int(db) + int(power))   # algorithmic: read x, write outputs
+    _timed("audio", AVS_F32, nbytes, lambda: check(
+        lib().avs_stft_mel_fused_f32(_p(wave), t, _p(window), _p(cos_t), _p(sin_t), _p(fb), _p(fb_lo), _p(fb_hi), nmel,
+                                     _p(o_log2), _p(o_db), _p(o_pow), _p(gmax), _stream()), "avs_stft_mel_fused_f32"))
+    return o_log2, o_db, o_pow, gmax
 
 
 def clamp_topdb(x, gmax, top_db):

@@ -282,6 +282,20 @@ int avs_stft_f64(const float* d_xpad, int64_t xpad_len, int64_t frames, int hop,
                  const double* d_basis_t, int ncols, int ncols_pad, float* d_spec,
                  avs_stream_t stream);
 
+/* torchaudio MelSpectrogram / MFCC front end in ONE kernel (features/extractors.py:236-246: MelSpectrogram(sr,
+ * n_mels) and MFCC(sr, n_mfcc) defaults: n_fft = win = 400, periodic Hann, hop 200, center + reflect padding, power
+ * 2, onesided 201 bins): d_wave fp32 [t] (t > 200, 16-byte aligned) -> [1 + t / 200, nmel] each, any subset of
+ *   d_log2mel = log2(mel + 1e-6)   (:245),   d_db = 10 log10(max(mel, 1e-10))   (AmplitudeToDB before its top_db
+ *   clamp; d_max receives max(max(mel, 1e-10)) over the call for avs_clamp_topdb_f32; zero it first),   d_power = mel.
+ * A workgroup stages the waveform span of its 32 frames in LDS (reflect padding by index, 16-byte loads), runs the
+ * real DFT folded to half its length (d_window = the fp32 window values as float64 [400]; d_cos [204, 208] / d_sin
+ * [200, 208] = cos / -sin(2 pi k n / 400), float64) on the fp64 matrix cores, then |X|^2, the sparse mel sum
+ * (d_fb [201, nmel], filter m non-zero on bins d_fb_lo[m] .. d_fb_hi[m] - 1) and the log on chip: the spectrum
+ * never reaches HBM.  Replaces avs_reflect_pad_f32 + avs_stft_f64 + avs_power_mel_f32 for this front end.          */
+int avs_stft_mel_fused_f32(const float* d_wave, int64_t t, const double* d_window, const double* d_cos,
+                           const double* d_sin, const float* d_fb, const int* d_fb_lo, const int* d_fb_hi, int nmel,
+                           float* d_log2mel, float* d_db, float* d_power, float* d_max, avs_stream_t stream);
+
 /* Power spectrum -> mel filterbank -> log.  d_spec is [frames, 2*nbins]
  * (re | im per frame, from avs_gemm_nt against the windowed DFT basis);
  * d_fb is [nbins, nmel] (torchaudio melscale_fbanks layout).

@@ -363,6 +363,32 @@ def test_mfcc_vs_oracle(dev):
     assert (got - ref).abs().max().item() < 1e-4 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("t", [201, 399, 400, 6399, 6400, 6601, 50000])
+def test_fused_front_end_matches_the_unfused_kernels(dev, t):
+    """avs_stft_mel_fused_f32 (span in LDS, folded DFT, |.|^2 + mel + log on chip) against the three-kernel sequence
+    it replaces (reflect pad -> dense fp64 DFT -> power/mel): the same exact-product fp64 arithmetic summed in a
+    different order, so the fp32 spectrum and everything after it agree to an fp32 rounding step; frame counts on
+    both sides of the 32-frame block, the shortest legal clip, an unaligned slice; both outputs from one pass."""
+    from avsum_amd import ops
+    from avsum_amd.audio import HOP, N_BINS, N_FFT, MelPlan
+    plan = MelPlan.get(16000, 128, 40, dev)
+    wave = _wave("multi", t, seed=t).to(dev)
+    old_power = ops.power_mel(plan.spectrum(wave), N_BINS, plan.fb, plan.fb_lo, plan.fb_hi, 2).cpu()
+    new_power = plan.mel_power(wave).cpu()
+    assert new_power.shape == (1 + t // HOP, 128)
+    assert (new_power - old_power).abs().max().item() <= 2e-6 * old_power.max().item()
+    old_log = ops.power_mel(plan.spectrum(wave), N_BINS, plan.fb, plan.fb_lo, plan.fb_hi, 0).cpu()
+    assert (plan.log2_mel(wave).cpu() - old_log).abs().max().item() < 2e-5
+    mel, mfcc = plan.log2_mel_and_mfcc(wave)
+    assert torch.equal(mel, plan.log2_mel(wave)) and torch.equal(mfcc, plan.mfcc(wave))
+    if t > 1000:
+        shifted = torch.cat([torch.zeros(3, device=dev), wave])[3:]          # storage offset of 12 bytes
+        assert shifted.data_ptr() % 16 != 0
+        assert torch.equal(plan.log2_mel(shifted), plan.log2_mel(wave))
+    with pytest.raises(RuntimeError, match="Padding size"):
+        plan.log2_mel(wave[:N_FFT // 2])
+
+
 # ----------------------------------------------------------------------------- scorer pieces
 def test_lstm_vs_oracle(dev):
     ops = _ops()
