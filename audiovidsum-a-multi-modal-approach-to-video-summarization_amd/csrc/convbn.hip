@@ -50,6 +50,8 @@ struct ConvBnParams {
                                    (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
 template <int BN, bool XF, bool PRE = false>
+// (Four workgroups per CU for the streaming form - 40 KB of LDS each fits - need <= 128 VGPRs: the 128-column
+//  variants then spill 11-16 registers and the kernel ran at 3.1 instead of 4.2 TB/s; three it is.)
 __global__ __launch_bounds__(256, 3) void conv1x1_bn_kernel(ConvBnParams p) {
   constexpr int ES = 2, ROWB = 64;
   constexpr int CE = 16 / ES, BKE = ROWB / ES, CPRR = ROWB / 16, RPP = 256 / CPRR, SH = 2, KS = ROWB / 32;
@@ -252,20 +254,6 @@ __global__ __launch_bounds__(256, 3) void conv1x1_bn_kernel(ConvBnParams p) {
         const int col = n0 + sch * 8;
         if (col < p.N) {  // N is a multiple of 8 (checked on the host)
           constexpr int NIT = A_ROWS / RSTEP;
-          // every residual row of this thread in flight at once (the accumulators are dead: registers are free), then
-          // the adds and stores: one memory latency per tile instead of one per row
-          // (the streaming form only: the two-pass variants sit at their register cap and would spill)
-          uint4 rv[PRE ? NIT : 1];
-          if constexpr (PRE) {
-            if (p.res != nullptr) {
-#pragma unroll
-              for (int it = 0; it < NIT; ++it) {
-                const long long row = m0 + srow + it * RSTEP;
-                rv[it] = row < m_hi ? *reinterpret_cast<const uint4*>(p.res + (row * p.ldr + col) * 2)
-                                    : make_uint4(0u, 0u, 0u, 0u);
-              }
-            }
-          }
 #pragma unroll
           for (int it = 0; it < NIT; ++it) {
             const long long row = m0 + srow + it * RSTEP;
@@ -273,11 +261,7 @@ __global__ __launch_bounds__(256, 3) void conv1x1_bn_kernel(ConvBnParams p) {
             uint4 v = *reinterpret_cast<const uint4*>(ct + (srow + it * RSTEP) * CT_PITCH + sch * 16);
             if (p.res != nullptr) {
               unsigned vv[4] = {v.x, v.y, v.z, v.w};
-              uint4 r1;
-              if constexpr (PRE)
-                r1 = rv[it];
-              else
-                r1 = *reinterpret_cast<const uint4*>(p.res + (row * p.ldr + col) * 2);
+              const uint4 r1 = *reinterpret_cast<const uint4*>(p.res + (row * p.ldr + col) * 2);
               const unsigned rw[4] = {r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
