@@ -20,7 +20,7 @@ STUDY = os.environ.get("AVS_STUDY_LIB") == "1"
 LIB_PATH = os.path.join(_PKG_DIR, "lib", "libavsum_hip_study.so" if STUDY else "libavsum_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "avsum_hip.h")
 
-AVS_F32, AVS_BF16, AVS_F32_ACC64 = 0, 1, 2
+AVS_F32, AVS_BF16, AVS_F32_ACC64, AVS_F32_SPLIT = 0, 1, 2, 3
 ACT_NONE, ACT_RELU = 0, 1
 BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
 E_UNSUPPORTED = -6

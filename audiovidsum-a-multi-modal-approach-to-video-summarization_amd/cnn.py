@@ -104,10 +104,13 @@ class ResNet50Runner:
       split   convolution (+ per-tile partial statistics in its epilogue for bf16, folded in tile order) or
               avs_bn_batch_stats -> avs_bn_apply (fp32 parity mode, ragged groups, shapes the other forms decline)."""
 
-    def __init__(self, trunk, dtype=torch.float32, bn_mode="batch"):
+    def __init__(self, trunk, dtype=torch.float32, bn_mode="batch", f32_split=False):
+        """f32_split (fp32 only): activations and weights stay fp32 in HBM, the convolutions' products run on the bf16
+        matrix cores as hi*hi + hi*lo + lo*hi (AVS_F32_SPLIT: ~2^-15 relative per product instead of exact)."""
         if bn_mode not in ("batch", "folded"):
             raise ValueError("bn_mode must be 'batch' (reference-faithful) or 'folded'")
         self.trunk, self.dtype, self.bn_mode = trunk, dtype, bn_mode
+        self.f32_split = bool(f32_split) and dtype == torch.float32
         self.fuse_conv_bn = True
         self.fuse_min_rows, self.fuse_ratio_num, self.fuse_ratio_den = 128, 2, 1
         self.bn_local = True         # the one-launch tile-local form where the library takes the shape
@@ -173,7 +176,7 @@ class ResNet50Runner:
         key = (n, gsz)
         plan = self._plans.get(key)
         if plan is None:
-            dcode = ops.dtype_code(self.dtype)
+            dcode = ops.dtype_code(self.dtype)   # (the tile-local form is bf16 only)
             plan = []
             for geom, xs, wrs in self._layer_geoms(n):
                 ho, wo, cout = geom[10], geom[11], geom[12]
@@ -200,7 +203,7 @@ class ResNet50Runner:
         n, ho, wo, cout = geom[0], geom[10], geom[11], geom[12]
         cin, kh, sh = geom[3], geom[4], geom[6]
         dev, dt = x.device, self.dtype
-        dcode = ops.dtype_code(dt)
+        dcode = ops.dtype_code(dt, self.f32_split)
         gamma, beta, eps, rmean, rvar = bnp
         act = ops.ACT_RELU if relu else ops.ACT_NONE
         y = torch.empty((n, ho, wo, cout), dtype=dt, device=dev)
@@ -454,8 +457,9 @@ INCEPTION_TRANSFORM = (0.229 / 0.5, 0.224 / 0.5, 0.225 / 0.5,
 class InceptionV3Runner:
     """uint8 frames [N,299,299,3] -> fp32 [N,2048]; eval-mode BatchNorm folded into the convolutions."""
 
-    def __init__(self, net, dtype=torch.float32):
+    def __init__(self, net, dtype=torch.float32, f32_split=False):
         self.net, self.dtype = net, dtype
+        self.f32_split = bool(f32_split) and dtype == torch.float32
         self._key = None
         self._w = None
 
@@ -490,7 +494,8 @@ class InceptionV3Runner:
         wo = (ww + 2 * c["pw"] - c["kw"]) // c["s"] + 1
         if out is None:
             out = torch.empty((n, ho, wo, c["cout"]), dtype=self.dtype, device=x.device)
-        return ops.conv2d(x, c["w"], c["kh"], c["kw"], c["s"], (c["ph"], c["pw"]), out, c["b"], ops.ACT_RELU)
+        return ops.conv2d(x, c["w"], c["kh"], c["kw"], c["s"], (c["ph"], c["pw"]), out, c["b"], ops.ACT_RELU,
+                          split=self.f32_split)
 
     def _pool(self, x, mode, k, s, p, out=None):
         n, h, ww, c = x.shape
@@ -574,7 +579,7 @@ class InceptionV3Runner:
         x0 = ops.frames_normalize(frames_u8, dt, 255.0, RESNET_MEAN, RESNET_STD, 299, 300, 0, 0, affine)
         c = w["Conv2d_1a_3x3"]
         x = torch.empty((n, 149, 149, 32), dtype=dt, device=dev)
-        ops.conv2d_raw(ops.dtype_code(dt), n, 299, 149, 16, 3, 1, 2, 1, 0, 0, 149, 149, 32, x0, 299 * 300 * 4, 300 * 4, 8,
+        ops.conv2d_raw(ops.dtype_code(dt, self.f32_split), n, 299, 149, 16, 3, 1, 2, 1, 0, 0, 149, 149, 32, x0, 299 * 300 * 4, 300 * 4, 8,
                        c["w"], c["w"].stride(0), x, 32, c["b"], ops.ACT_RELU, algo_k=27, algo_in_elems=x0.numel())
         del x0
         x = self._conv(w, "Conv2d_2a_3x3", x)

@@ -64,6 +64,7 @@ struct IgemmParams {
   float eps;
   const char* residual;
   long long ldr;
+  int split;         // fp32 operands only: 1 = products on the bf16 matrix cores as hi*hi + hi*lo + lo*hi (AVS_F32_SPLIT)
   int tall;          // 1: the 256-row tile variants (WR = 4)
   int tile_rows;     // EPI_BNLOCAL: rows of the tile that are used (whole groups), also the pitch between tiles
 #ifdef AVS_STUDY
@@ -81,6 +82,26 @@ struct IgemmParams {
 #define AVS_GLDS16(src, dst)                                                                        \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),            \
                                    (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+
+// AVS_F32_SPLIT: fp32 operands, arithmetic on the bf16 matrix cores.  x = hi + lo + r with hi = bf16(x), lo = bf16(x - hi),
+// |r| <= 2^-17 |x|; a*b ~ ah*bh + ah*bl + al*bh (each product exact in the fp32 accumulator), i.e. three
+// v_mfma_f32_32x32x16_bf16 per 16 reduction elements instead of eight v_mfma_f32_32x32x2_f32: 5.3x the matrix rate
+// at a relative error of ~2^-15 per product (bf16 alone: 2^-8).  The split is 3 VALU operations per operand element,
+// amortised over the tile's other dimension.
+__device__ __forceinline__ void avs_split_bf16(const float4& p0, const float4& p1, bf16x8& hi, bf16x8& lo) {
+  const float v[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned short h0 = avs_f32_to_bf16(v[2 * j]), h1 = avs_f32_to_bf16(v[2 * j + 1]);
+    const unsigned short l0 = avs_f32_to_bf16(v[2 * j] - avs_bf16_to_f32(h0));
+    const unsigned short l1 = avs_f32_to_bf16(v[2 * j + 1] - avs_bf16_to_f32(h1));
+    h[j] = (unsigned)h0 | ((unsigned)h1 << 16);
+    l[j] = (unsigned)l0 | ((unsigned)l1 << 16);
+  }
+  hi = __builtin_bit_cast(bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
+  lo = __builtin_bit_cast(bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
+}
 
 // ROWB = bytes of reduction per LDS row and step: 128 (fewer barriers per MAC; 64 KB of LDS, 2 workgroups per
 // CU) for the long reductions, 64 (32 KB, 3 workgroups per CU: more DMA in flight) for the short ones, whose
@@ -108,6 +129,15 @@ constexpr int STATS_MIN_GROUP_ROWS = 64;  // EPI_STATS: a wave's 64 rows then ov
 // ds_read_b128 and the waits are hand-counted (s_waitcnt vmcnt(N) + raw s_barrier), because hipcc orders every
 // LDS read it can see behind ALL outstanding LDS-DMA (vmcnt(0)), which caps a plain-HIP loop at one step of
 // prefetch.  Order per step: wait for this step's DMA -> barrier -> issue step s+2 -> read fragments -> MFMA.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// Passes a fragment THROUGH an empty asm: every later use of it depends on this statement, so it cannot be scheduled
+// ahead of the (volatile) wait that precedes the statement.
+__device__ __forceinline__ void avs_pin(uint4& v) {
+  u32x4 r = __builtin_bit_cast(u32x4, v);
+  asm volatile("" : "+v"(r));
+  v = __builtin_bit_cast(uint4, r);
+}
+
 __device__ __forceinline__ uint4 avs_lds_read_b128(unsigned byte_addr) {
   uint4 v;
   asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(byte_addr));
@@ -122,9 +152,11 @@ __device__ __forceinline__ uint4 avs_lds_read_b128(unsigned byte_addr) {
 // a row's padding test is one bit of a per-row tap mask built once, and a DMA source is base + scalar offset.
 // (Measured on the 3x3 layers: the general staging code issues ~180 vector + scalar instructions per 16 MFMAs and
 // the loop ran at 45 % matrix-core occupancy for that reason alone - with no staging at all it reaches 1.5 PFLOP/s.)
-template <int ES, int BN, bool ACC64, bool SPATIAL, int ROWB, int EPI, bool PIPE, int WR = 2, bool FASTK = false>
+template <int ES, int BN, bool ACC64, bool SPATIAL, int ROWB, int EPI, bool PIPE, int WR = 2, bool FASTK = false,
+          bool SPLIT = false>
 __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? 3 : 2) void igemm_kernel(
     IgemmParams p) {
+  static_assert(!SPLIT || (ES == 4 && !ACC64), "the split-bf16 arithmetic is for fp32 operands");
   static_assert(WR == 2 || (WR == 4 && ES == 2 && !ACC64), "256-row tiles are built for the bf16 variants");
   static_assert(!PIPE || (ROWB == 64 && !ACC64), "the 3-buffer pipeline is built for the 64-byte-row variants");
   static_assert(!ACC64 || (ES == 4 && BN == 64), "fp64 slice accumulation: fp32 operands, narrow tile only");
@@ -419,12 +451,53 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? 3 : 2) voi
       // start as soon as ITS fragments have landed (LDS reads return in order; a scalar load in between can only
       // make the counted wait more conservative)
       if (s + 2 < steps) stage(cur == 0 ? 2 : cur - 1);  // (s+2) % 3 == (cur + 2) % 3
+      // The fragment reads above are asynchronous inline asm: after each hand-counted wait the fragments it covers are
+      // passed THROUGH an empty asm ("+v"), so that no use of them - not even a register copy the compiler may want -
+      // can be scheduled ahead of the wait.  (A copy placed before the wait reads a register whose LDS data has not
+      // landed: seen as size-dependent garbage when a runtime branch made the compiler copy the fragments.)
+      if constexpr (SPLIT) {
+        // fp32 operands on the bf16 matrix cores: the fragments of two sub-steps (8 reduction elements per lane, the
+        // same lane -> k map for A and B) are split into hi / lo and contracted as lo*hi + hi*lo + hi*hi
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) avs_pin(fa[ks][mt]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) avs_pin(fb[ks][nt]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kp = 0; kp < KS; kp += 2) {
+          bf16x8 ah[2], al[2], bh[NT], bl[NT];
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+            avs_split_bf16(__builtin_bit_cast(float4, fa[kp][mt]), __builtin_bit_cast(float4, fa[kp + 1][mt]), ah[mt], al[mt]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            avs_split_bf16(__builtin_bit_cast(float4, fb[kp][nt]), __builtin_bit_cast(float4, fb[kp + 1][nt]), bh[nt], bl[nt]);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+        cur = cur == 2 ? 0 : cur + 1;
+        continue;
+      }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         if (ks + 1 < KS)
           asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((KS - 1) * (2 + NT)) : "memory");
         else
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) avs_pin(fa[ks][mt]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) avs_pin(fb[ks][nt]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -477,6 +550,27 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? 3 : 2) voi
       //    that ended the previous step.  It is in flight during the MFMAs below.
       if (s + 1 < steps) stage(buf ^ 1);
       // 3. matrix cores
+      if constexpr (SPLIT) {
+#pragma unroll
+        for (int kp = 0; kp < KS; kp += 2) {
+          bf16x8 ah[2], al[2], bh[NT], bl[NT];
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+            avs_split_bf16(__builtin_bit_cast(float4, fa[kp][mt]), __builtin_bit_cast(float4, fa[kp + 1][mt]), ah[mt], al[mt]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            avs_split_bf16(__builtin_bit_cast(float4, fb[kp][nt]), __builtin_bit_cast(float4, fb[kp + 1][nt]), bh[nt], bl[nt]);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+      }
+      if constexpr (!SPLIT) {
   #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
   #pragma unroll
@@ -496,6 +590,7 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? 3 : 2) voi
               acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[mt][nt], 0, 0, 0);
             }
           }
+      }
       if constexpr (ACC64) {
   #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -916,6 +1011,19 @@ static void igemm_dispatch_epi4(int epi, dim3 grid, hipStream_t stream, const Ig
       return;
     }
   }
+  if constexpr (ES == 4 && !ACC64 && WR == 2) {
+    if (p.split) {   // AVS_F32_SPLIT: the same tiles, products as three bf16 MFMAs
+      if (epi == EPI_PLAIN)
+        hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_PLAIN, PIPE, WR, FK, true>), grid, dim3(256), 0, stream, p);
+      else if (epi == EPI_STATS)
+        hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE, WR, FK, true>), grid, dim3(256), 0, stream, p);
+      else if (epi == EPI_BRELU)
+        hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BRELU, PIPE, WR, FK, true>), grid, dim3(256), 0, stream, p);
+      else
+        hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_ANY, PIPE, WR, FK, true>), grid, dim3(256), 0, stream, p);
+      return;
+    }
+  }
   if (epi == EPI_PLAIN)
     hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_PLAIN, PIPE, WR, FK>), grid, dim3(256), 0, stream, p);
   else if (epi == EPI_STATS)
@@ -1005,8 +1113,10 @@ static void igemm_dispatch(bool spatial, dim3 grid, hipStream_t stream, const Ig
 static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream, const char* who,
                         bool plan_only = false, long long* tiles_m_out = nullptr) {
   const int es = dtype == AVS_BF16 ? 2 : 4;
+  p.split = dtype == AVS_F32_SPLIT ? 1 : 0;
   const int ce = 16 / es;
-  AVS_REQUIRE(dtype == AVS_F32 || dtype == AVS_BF16 || dtype == AVS_F32_ACC64, AVS_E_ARG, "%s: bad dtype %d", who,
+  AVS_REQUIRE(dtype == AVS_F32 || dtype == AVS_BF16 || dtype == AVS_F32_ACC64 || dtype == AVS_F32_SPLIT, AVS_E_ARG,
+              "%s: bad dtype %d", who,
               dtype);
   AVS_REQUIRE(p.M >= 0 && p.N > 0 && p.K > 0 && batch > 0, AVS_E_SHAPE, "%s: bad sizes M=%d N=%d K=%d batch=%d", who,
               p.M, p.N, p.K, batch);
@@ -1154,7 +1264,8 @@ __global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ 
 
 static int bnstats_plan(const avs_conv_desc* d, int64_t rpg, IgemmParams& p, int64_t* ws_bytes, int* tile_rows,
                         const char* who) {
-  AVS_REQUIRE(d != nullptr && (d->dtype == AVS_BF16 || d->dtype == AVS_F32), AVS_E_ARG, "%s: bf16 / fp32 only", who);
+  AVS_REQUIRE(d != nullptr && (d->dtype == AVS_BF16 || d->dtype == AVS_F32 || d->dtype == AVS_F32_SPLIT), AVS_E_ARG,
+              "%s: bf16 / fp32 only", who);
   AVS_REQUIRE(d->act == AVS_ACT_NONE && d->alpha == 1.0f, AVS_E_ARG, "%s: no activation / scaling", who);
   AVS_REQUIRE(rpg > 0 && rpg < (1ll << 30), AVS_E_ARG, "%s: rows_per_group must be positive", who);
   AVS_REQUIRE(rpg >= STATS_MIN_GROUP_ROWS, AVS_E_UNSUPPORTED,

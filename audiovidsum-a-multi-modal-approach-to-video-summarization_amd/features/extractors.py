@@ -48,7 +48,9 @@ def _as_bgr_u8(frame):
 
 
 class VisualFeatureExtractor(nn.Module):
-    def __init__(self, dtype=torch.float32, bn_mode="batch"):
+    def __init__(self, dtype=torch.float32, bn_mode="batch", f32_split=False):
+        """dtype: torch.float32 (parity mode, fp32 MFMA) or torch.bfloat16 (throughput mode); f32_split (with fp32):
+        fp32 activations / weights, convolution products on the bf16 matrix cores as hi*hi + hi*lo + lo*hi."""
         super().__init__()
         self.resnet = resnet50_trunk()      # nn.Sequential(*resnet50.children()[:-1]), extractors.py:25,29
         self.inception = Inception3()       # fc = Identity, avgpool adaptive, extractors.py:26,32-36
@@ -57,8 +59,8 @@ class VisualFeatureExtractor(nn.Module):
             p.requires_grad = False         # extractors.py:39-40
         self.inception.eval()               # extractors.py:41 (the ResNet trunk stays in train mode: SURVEY Q2)
         self.compute_dtype = dtype
-        self._resnet_runner = ResNet50Runner(self.resnet, dtype, bn_mode)
-        self._inception_runner = InceptionV3Runner(self.inception, dtype)
+        self._resnet_runner = ResNet50Runner(self.resnet, dtype, bn_mode, f32_split)
+        self._inception_runner = InceptionV3Runner(self.inception, dtype, f32_split)
 
     def _to_device_u8(self, frames):
         dev = _device()

@@ -8,7 +8,7 @@ from ctypes import c_float, c_void_p
 import torch
 
 from . import _abi
-from ._abi import ACT_NONE, ACT_RELU, AVS_BF16, AVS_F32, BIAS_COL, BIAS_NONE, BIAS_ROW, check, lib
+from ._abi import ACT_NONE, ACT_RELU, AVS_BF16, AVS_F32, AVS_F32_SPLIT, BIAS_COL, BIAS_NONE, BIAS_ROW, check, lib
 
 __all__ = [
     "ACT_NONE", "ACT_RELU", "linear", "gemm_nt_batched", "conv2d", "conv2d_raw", "conv_bnlocal_tile_rows", "conv1x1_bn", "conv1x1_gram_bn", "bn_gram_affine", "gram_supported", "frames_normalize", "resize_bilinear",
@@ -88,9 +88,11 @@ def _p(t, offset_elems=0):
     return c_void_p(t.data_ptr() + offset_elems * t.element_size())
 
 
-def dtype_code(dtype):
+def dtype_code(dtype, split=False):
+    """C-ABI dtype code of a torch dtype.  split (fp32 only): AVS_F32_SPLIT = fp32 operands contracted on the bf16
+    matrix cores as hi*hi + hi*lo + lo*hi (the contraction entry points only: avs_conv2d_nhwc*, avs_gemm_nt)."""
     if dtype == torch.float32:
-        return AVS_F32
+        return AVS_F32_SPLIT if split else AVS_F32
     if dtype == torch.bfloat16:
         return AVS_BF16
     raise TypeError(f"unsupported compute dtype {dtype}")
@@ -335,7 +337,7 @@ def conv1x1_gram_bn(x2d, wt, rows_per_group, gamma, beta, eps, out2d, residual=N
     return out2d
 
 
-def conv2d(x, wt, kh, kw, stride, pad, out, bias=None, act=ACT_NONE, bnstats=None):
+def conv2d(x, wt, kh, kw, stride, pad, out, bias=None, act=ACT_NONE, bnstats=None, split=False):
     """x: NHWC view [n,h,w,cin] (unit channel stride); wt: [cout, kh*kw*cin]; out: NHWC view [n,ho,wo,cout]
     whose pixels are dense in (n,ho,wo) order (a channel slice of a dense buffer is fine).
     bnstats: see conv2d_raw (returns (scale, shift) then, else `out`)."""
@@ -354,7 +356,7 @@ def conv2d(x, wt, kh, kw, stride, pad, out, bias=None, act=ACT_NONE, bnstats=Non
         raise ValueError(f"weight {tuple(wt.shape)} / dtypes do not match")
     if bias is not None:
         _f32(bias, "bias")
-    r = conv2d_raw(dtype_code(x.dtype), n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x, x.stride(0),
+    r = conv2d_raw(dtype_code(x.dtype, split), n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x, x.stride(0),
                    x.stride(1), x.stride(2), wt, wt.stride(0), out, yps, bias, act, bnstats=bnstats)
     return out if bnstats is None else r
 

@@ -483,6 +483,22 @@ def main():
                                                                         and a32["f1_drift_max"] <= 1e-3)
                 del dev_frames
             del ext32, pipe32
+            # fp32 storage, convolution products on the bf16 matrix cores as hi*hi + hi*lo + lo*hi (AVS_F32_SPLIT)
+            exts = VisualFeatureExtractor(torch.float32, "batch", f32_split=True)
+            exts.load_state_dict(extractor.state_dict())
+            exts = exts.to(dev)
+            pipes = FrameScoringPipeline(exts, scorer, use_inception=False, chunk_frames=4096, frames_per_group=1)
+            run_sub("fp32_split_mode", pipes, frames, offsets, base + "fp32 activations and weights, convolution "
+                    "products on the bf16 matrix cores as hi*hi + hi*lo + lo*hi (~2^-15 relative per product)", steps_=1)
+            if s_frames is not None:
+                dev_frames = torch.from_numpy(np.concatenate(s_frames)).to(dev)
+                asp = accuracy_report(pipes.score(dev_frames, s_off).cpu().numpy(), ref, s_off)
+                subs["fp32_split_mode"]["accuracy"] = {k: (round(v, 8) if isinstance(v, float) else v)
+                                                       for k, v in asp.items()}
+                subs["fp32_split_mode"]["accuracy"]["bars_met"] = bool(asp["score_max_abs_err"] <= 1e-4
+                                                                       and asp["f1_drift_max"] <= 1e-3)
+                del dev_frames
+            del exts, pipes
             frames = None
             torch.cuda.empty_cache()
             subs["config2_audio_visual_fusion"] = config2_leg(extractor, scorer, dev, 1, 50)

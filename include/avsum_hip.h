@@ -46,7 +46,7 @@ enum {
   AVS_E_UNSUPPORTED = -6 /* this entry point does not take the shape; use the documented alternative */
 };
 
-enum { AVS_F32 = 0, AVS_BF16 = 1, AVS_F32_ACC64 = 2 };
+enum { AVS_F32 = 0, AVS_BF16 = 1, AVS_F32_ACC64 = 2, AVS_F32_SPLIT = 3 };
 enum { AVS_ACT_NONE = 0, AVS_ACT_RELU = 1 };
 enum { AVS_BIAS_NONE = 0, AVS_BIAS_COL = 1, AVS_BIAS_ROW = 2 };
 

@@ -83,6 +83,17 @@ def test_bench_pipeline_against_oracle(dev, kind, fpg):
                                   np.flatnonzero(ref[a:b] > ref[a:b].mean()))
     assert r32["selection_agreement"] >= 1.0 - 2.0 / FRAMES and r32["f1_drift_max"] <= 1e-3
 
+    # ---- fp32-split mode: fp32 storage, convolution products on the bf16 matrix cores as hi*hi + hi*lo + lo*hi
+    from avsum_amd.features.extractors import VisualFeatureExtractor
+    exts = VisualFeatureExtractor(torch.float32, "batch", f32_split=True)
+    exts.load_state_dict(ext32.state_dict())
+    ps = FrameScoringPipeline(exts.to(dev), scorer, use_inception=False, chunk_frames=256, frames_per_group=fpg)
+    ss = ps.score(frames, offsets).cpu().numpy()
+    rs = accuracy_report(ss, ref, offsets)
+    print(f"[{kind} fpg={fpg}] fp32-split vs oracle: {rs}")
+    assert rs["score_max_abs_err"] < 1e-4                              # north_star's score bar holds
+    assert rs["selection_agreement"] >= 0.99
+
     # ---- bf16 throughput mode (the bench's): deterministic; measured deviations, asserted as they are
     p16 = FrameScoringPipeline(ext16, scorer, use_inception=False, chunk_frames=12288, frames_per_group=fpg)
     s16 = p16.score(frames, offsets).cpu().numpy()

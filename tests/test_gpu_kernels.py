@@ -116,7 +116,7 @@ def test_abi_rejects_bad_arguments(dev):
 
 
 # ----------------------------------------------------------------------------- conv
-def _conv_case(dev, dtype, n, h, w, cin, cout, kh, kw, stride, pad, tol):
+def _conv_case(dev, dtype, n, h, w, cin, cout, kh, kw, stride, pad, tol, split=False):
     ops = _ops()
     g = torch.Generator().manual_seed(h * 13 + cin)
     x = torch.randn(n, cin, h, w, generator=g)
@@ -129,7 +129,7 @@ def _conv_case(dev, dtype, n, h, w, cin, cout, kh, kw, stride, pad, tol):
     xn = x.permute(0, 2, 3, 1).contiguous().to(dtype).to(dev)
     wk = wt.permute(0, 2, 3, 1).reshape(cout, -1).contiguous().to(dtype).to(dev)
     out = torch.empty((n, ho, wo, cout), dtype=dtype, device=dev)
-    ops.conv2d(xn, wk, kh, kw, stride, pad, out, b.to(dev), 1)
+    ops.conv2d(xn, wk, kh, kw, stride, pad, out, b.to(dev), 1, split=split)
     got = out.float().cpu().permute(0, 3, 1, 2)
     assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
 
@@ -141,6 +141,18 @@ def _conv_case(dev, dtype, n, h, w, cin, cout, kh, kw, stride, pad, tol):
 ])
 def test_conv2d_f32(dev, cfg):
     _conv_case(dev, torch.float32, *cfg, tol=2e-5)
+
+
+@pytest.mark.parametrize("cfg", [
+    (2, 14, 14, 64, 64, 1, 1, 1, 0), (2, 14, 14, 64, 96, 3, 3, 1, 1), (3, 15, 15, 32, 48, 3, 3, 2, 1),
+    (2, 16, 16, 128, 256, 1, 1, 2, 0), (1, 17, 17, 128, 192, 1, 7, 1, (0, 3)), (2, 12, 12, 48, 64, 5, 5, 1, 2),
+    (2, 9, 9, 80, 192, 3, 3, 1, 0), (1, 35, 35, 288, 384, 3, 3, 2, 0), (2, 28, 28, 16, 32, 1, 1, 1, 0),
+])
+def test_conv2d_f32_split(dev, cfg):
+    """AVS_F32_SPLIT: fp32 operands, products on the bf16 matrix cores as hi*hi + hi*lo + lo*hi (both 64- and
+    128-byte-row variants, the pipelined and the plain loop): ~2^-15 relative per product, i.e. ~1e-4 of the exact
+    fp32 result's scale in the worst element, against 2e-5 for the exact fp32 mode and 1.2e-2 for bf16."""
+    _conv_case(dev, torch.float32, *cfg, tol=1e-4, split=True)
 
 
 @pytest.mark.parametrize("cfg", [(2, 14, 14, 64, 64, 3, 3, 1, 1), (2, 16, 16, 128, 256, 1, 1, 2, 0),
