@@ -234,14 +234,18 @@ class ResNet50Runner:
             shift = (beta - rmean * scale).contiguous()
             return finish(scale.view(1, -1), shift.view(1, -1), None, 0)
         grows, gmax, uniform = groups[ho * wo]
-        fast = uniform and dt == torch.bfloat16
-        if fast and local:
+        bf16 = dt == torch.bfloat16
+        # statistics from the convolution's epilogue: the bf16 mode, and the fp32-split mode (whose products already carry
+        # ~2^-15 of error: the E[y^2] - E[y]^2 form on fp32 sums costs nothing next to that); the exact fp32 parity mode
+        # keeps the shifted statistics pass over the stored output
+        fast = uniform and (bf16 or self.f32_split)
+        if fast and bf16 and local:
             conv(act=act, bnlocal=(gmax, gamma, beta, eps, residual))
             if pool is not None:
                 out, k, s, p = pooled(y)
                 return ops.pool2d(y, "max", k, s, p, out)
             return y
-        if in_affine is not None or (fast and self._twopass_ok(cin, cout, kh, sh, gmax)):
+        if in_affine is not None or (fast and bf16 and self._twopass_ok(cin, cout, kh, sh, gmax)):
             # statistics from the input's Gram matrix + ONE streaming pass where the shape allows it (the expanding
             # 1x1 layers of layers 1-2), else the two-pass kernel
             form = ops.conv1x1_gram_bn if (self.gram_stats and ops.gram_supported(cin, cout)) else ops.conv1x1_bn
