@@ -296,9 +296,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=1, choices=[1, 3],
-                    help="BASELINE config of the headline: 1 = SumMe-shape batch per rank; 3 = one rank's share of the "
-                         "400 x 5000-frame sharded inference")
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3],
+                    help="BASELINE config of the headline: 1 = SumMe-shape batch per rank; 2 = the TVSum-shape "
+                         "audio + visual + fusion leg alone (one GPU); 3 = one rank's share of the 400 x 5000-frame "
+                         "sharded inference")
     ap.add_argument("--videos", type=int, default=None)
     ap.add_argument("--mean-frames", type=int, default=None)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
@@ -363,6 +364,19 @@ def main():
     scorer = scorer.to(dev)
     avd.broadcast_module(extractor, 0)  # C1
     avd.broadcast_module(scorer, 0)
+
+    if args.config == 2:
+        # the configs[2] leg on its own (what sub_results.config2_audio_visual_fusion runs), for profiling it alone
+        if world != 1 or args.dtype != "bf16":
+            raise SystemExit("--config 2 is the one-GPU bf16 audio + visual + fusion leg")
+        leg = config2_leg(extractor, scorer, dev, args.steps, args.videos or 50)
+        print(json.dumps({"metric": "frames/sec end-to-end (extract+fuse+score), 224x224 + 16kHz", "value": leg["value"],
+                          "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": 1,
+                          "ms_per_step": leg["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                          "config": {"workload": leg["workload"]}, "roofline": leg["audio_roofline"],
+                          "cpu_baseline": None, "detail": leg}))
+        return
 
     cfg = synthetic.config(args.config, rank, world, args.videos, args.mean_frames)
     lengths, video_ids = cfg["lengths"], cfg["video_ids"]

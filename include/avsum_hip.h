@@ -24,6 +24,11 @@
  *     (avs_gemm_nt / avs_conv2d_nhwc only) = fp32 operands and fp32 MFMA over
  *     each 16-element slice of the reduction, slices summed in fp64: used for
  *     the STFT, where a long fp32 running sum would lose the quiet bins.
+ *     AVS_F32_SPLIT (avs_gemm_nt / avs_conv2d_nhwc[_bnstats] only) = fp32 operands
+ *     in memory, products on the bf16 MFMA: every operand element is split into
+ *     hi = bf16(x), lo = bf16(x - hi) in registers and a*b is taken as
+ *     ah*bh + ah*bl + al*bh (fp32 accumulate): ~2^-15 relative per product instead
+ *     of exact, 5.3x the matrix rate of the f32 MFMA.
  */
 #ifndef AVSUM_HIP_H
 #define AVSUM_HIP_H
