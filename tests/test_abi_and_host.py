@@ -252,3 +252,53 @@ def test_avprocessor_has_the_reference_surface():
     for name, params in (("process_video", ["self", "video_path"]), ("_extract_audio", ["self", "video_path", "audio_path"]),
                          ("_detect_shots", ["self", "video_path"]), ("_extract_frames", ["self", "cap", "start", "end"])):
         assert list(inspect.signature(getattr(AVProcessor, name)).parameters) == params
+
+
+def test_synthetic_config_generators():
+    """the five BASELINE configs as seeded generators (lengths, global video ids, sharding); frames and
+    waveforms have the stated shapes / statistics (generated on the CPU here, in HBM in the bench)."""
+    from avsum_amd import synthetic as sy
+    c1 = sy.config(1)
+    assert len(c1["lengths"]) == 25 and sum(c1["lengths"]) == 45143 and min(c1["lengths"]) >= 900 and max(c1["lengths"]) <= 2700
+    assert c1["video_ids"] == list(range(25)) and c1["num_videos"] == 25
+    assert sy.config(1) == c1                                             # seeded
+    r3 = sy.config(1, rank=3, world=8)
+    assert r3["video_ids"] == list(range(75, 100)) and r3["num_videos"] == 200 and r3["lengths"] != c1["lengths"]
+    c2 = sy.config(2)
+    assert len(c2["lengths"]) == 50 and all(2000 <= n <= 10000 for n in c2["lengths"])
+    seen = []
+    for r in range(8):                                                    # configs[3]: one global list, sharded
+        c3 = sy.config(3, r, 8)
+        assert c3["num_videos"] == 400 and c3["lengths"] == [5000] * 50
+        seen += c3["video_ids"]
+    assert sorted(seen) == list(range(400))
+    assert sy.config(3, 0, 1)["num_videos"] == 50                         # the one-GPU share
+    assert sy.config(0)["lengths"] == [300] and sy.uniform_shots(300) == [(30 * i, 30 * i + 30) for i in range(10)]
+    with pytest.raises(ValueError):
+        sy.config(4)
+    assert sy.offsets_of([3, 5]) == [0, 3, 8]
+    f = sy.make_frames_uniform(5, torch.device("cpu"), 1)
+    assert f.shape == (5, 224, 224, 3) and f.dtype == torch.uint8 and 120 < f.float().mean() < 135
+    assert torch.equal(f, sy.make_frames_uniform(5, torch.device("cpu"), 1))
+    s = sy.make_frames_scenes([70, 50], torch.device("cpu"), 2, scene_frames=60)
+    assert s.shape == (120, 224, 224, 3)
+    within = (s[1].float() - s[2].float()).abs().mean()                   # neighbours of one scene: drift + noise
+    across = (s[1].float() - s[65].float()).abs().mean()                  # different scenes
+    assert within < 15 and across > 2 * within
+    w = sy.make_waveform(16000, 5)
+    assert w.shape == (16000,) and w.dtype == torch.float32 and 0.3 < w.abs().max() < 1.0
+    sine = sy.make_waveform(16000, 0, "sine")
+    assert abs(float(sine.abs().max()) - 0.5) < 1e-3
+
+
+def test_accuracy_report_counts():
+    from avsum_amd.evaluation.accuracy import accuracy_report, synthetic_gt_segments
+    ref = np.linspace(0.0, 1.0, 100, dtype=np.float32)
+    rep = accuracy_report(ref, ref, [0, 60, 100])
+    assert rep["selection_agreement"] == 1.0 and rep["f1_drift_max"] == 0.0 and rep["videos"] == 2 and rep["frames"] == 100
+    flipped = ref.copy()
+    flipped[:60] = flipped[:60][::-1]                                     # first video: selection mirrored
+    rep = accuracy_report(flipped, ref, [0, 60, 100])
+    assert rep["selection_agreement"] == 0.4 and rep["score_max_abs_err"] > 0.5
+    segs = synthetic_gt_segments(300, 900)
+    assert segs == synthetic_gt_segments(300, 900) and all(0 <= a < b <= 300 for a, b in segs)

@@ -203,8 +203,36 @@ def test_bench_contract_line(dev):
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["launches"] > 0 and r["avg_launch_us"] > 0 and r["algorithmic_bytes_per_launch"] > 0
+    assert r["traffic"] is None or "profiles/" in r["traffic_source"]   # replayed from a committed PMC summary, labelled
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "frames/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
+    assert c["runs"] == 5 and c["min"] <= c["value"] <= c["max"]       # median of 5 runs
+    a = d["accuracy"]                                                   # the timed arithmetic mode against the oracle
+    assert a["mode"] == "bf16" and a["deterministic"] is True and a["frames"] == 20 and a["videos"] == 5
+    assert 0.0 <= a["selection_agreement"] <= 1.0 and a["score_max_abs_err"] >= 0 and isinstance(a["bars_met"], bool)
+    assert d["sub_results"] is None                                     # only with the default headline
+
+
+def test_bench_under_the_launcher_one_rank(dev):
+    """The driver's launch line at N = 1: python -m torch.distributed.run --nproc-per-node 1 ... bench.py --gpus 1
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment, rendezvous on 127.0.0.1)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29600 + os.getpid() % 300
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                          "--gpus", "1", "--videos", "2", "--mean-frames", "24", "--chunk", "16", "--steps", "1",
+                          "--warmup", "1", "--cpu-sample", "0"],
+                         capture_output=True, text=True, timeout=600, cwd=root,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, out.stderr[-800:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["cpu_baseline"] is None and d["accuracy"] is None
 
 
 def test_rccl_world1_collectives_on_device(dev):
