@@ -115,6 +115,7 @@ class ResNet50Runner:
         self.fuse_min_rows, self.fuse_ratio_num, self.fuse_ratio_den = 128, 2, 1
         self.bn_local = True         # the one-launch tile-local form where the library takes the shape
         self.gram_stats = True       # conv3 / downsample of layers 1-2: Gram-matrix statistics + one streaming pass
+        self.fused_stem = True       # uint8 frames -> conv1 -> max/min-pooled raw maps + partial sums in one kernel
         self.defer_bn_apply = True   # bn2 + ReLU applied inside conv3's two-pass kernel (avs_conv1x1_bn_in_bf16)
         self._key = None
         self._w = None
@@ -292,11 +293,17 @@ class ResNet50Runner:
         def slot():
             return next(plan) if plan is not None else False
 
-        # stem: (x - mean)/std without /255 (extractors.py:133-139), zero padded by 3 (conv1 pad)
-        x0 = ops.frames_normalize(frames_u8, dt, 1.0, RESNET_MEAN, RESNET_STD, 230, 232, 3, 3)
-        geom, xs, _ = self._stem_geom(n)
-        x = self._conv_bn(geom, xs, x0, w["stem"], w["bn1"], groups, local=slot(), algo_k=147, pool=(3, 2, 1))
-        del x0
+        # stem: (x - mean)/std without /255 (extractors.py:133-139), conv1 7x7/2 pad 3, bn1, ReLU, maxpool 3x3/2
+        stem_local = slot()
+        if self.fused_stem and self.bn_mode == "batch" and uniform and dt == torch.bfloat16:
+            # one fused launch + a tiny finishing pass: the normalised image and the 112x112x64 map never reach HBM
+            gamma, beta, eps = w["bn1"][:3]
+            x = ops.stem_conv_bn_pool(frames_u8, w["stem"], 1.0, RESNET_MEAN, RESNET_STD, gsz, gamma, beta, eps)[0]
+        else:
+            x0 = ops.frames_normalize(frames_u8, dt, 1.0, RESNET_MEAN, RESNET_STD, 230, 232, 3, 3)
+            geom, xs, _ = self._stem_geom(n)
+            x = self._conv_bn(geom, xs, x0, w["stem"], w["bn1"], groups, local=stem_local, algo_k=147, pool=(3, 2, 1))
+            del x0
         hcur = 56
         for blk in w["blocks"]:
             s, planes = blk["stride"], blk["planes"]

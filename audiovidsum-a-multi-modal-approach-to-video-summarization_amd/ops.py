@@ -11,7 +11,7 @@ from . import _abi
 from ._abi import ACT_NONE, ACT_RELU, AVS_BF16, AVS_F32, AVS_F32_SPLIT, BIAS_COL, BIAS_NONE, BIAS_ROW, check, lib
 
 __all__ = [
-    "ACT_NONE", "ACT_RELU", "linear", "gemm_nt_batched", "conv2d", "conv2d_raw", "conv_bnlocal_tile_rows", "conv1x1_bn", "conv1x1_gram_bn", "bn_gram_affine", "gram_supported", "frames_normalize", "resize_bilinear",
+    "ACT_NONE", "ACT_RELU", "linear", "gemm_nt_batched", "conv2d", "conv2d_raw", "conv_bnlocal_tile_rows", "conv1x1_bn", "conv1x1_gram_bn", "bn_gram_affine", "gram_supported", "frames_normalize", "stem_conv_bn_pool", "resize_bilinear",
     "bn_batch_stats", "bn_apply", "bn_maxpool", "pool2d", "global_avgpool", "segment_mean", "hsv_frame_diff", "reflect_pad", "stft_f64", "stft_mel_fused", "power_mel",
     "clamp_topdb", "fill", "quantize", "resample", "lstm", "mha_batchaxis", "score_head", "mhsa_flash", "softmax_rows", "cdist", "dtw_path",
     "gather_scale", "dtype_code",
@@ -376,6 +376,40 @@ def frames_normalize(frames_u8, dtype, denom, mean, std, out_h, out_w, pad_t, pa
     check(lib().avs_frames_normalize_u8(dtype_code(dtype), _p(frames_u8), n, h, w, float(denom), m3, s3, a6, _p(out),
                                         out_h, out_w, pad_t, pad_l, _stream()), "avs_frames_normalize_u8")
     return out
+
+
+_stem_ws = {}
+
+
+def stem_conv_bn_pool(frames_u8, wt, denom, mean, std, frames_per_group, gamma, beta, eps, relu=True):
+    """The fused ResNet-50 stem of the bf16 path (avs_stem_conv_bn_pool_bf16): uint8 [n,224,224,3] -> bf16
+    [n,56,56,64] = maxpool(relu(bn1(conv1((x / denom - mean) / std)))) with batch statistics per group of
+    frames_per_group frames; wt = the stem weight in the 7 x 8 x 4 layout.  Returns (y, scale, shift)."""
+    _dev(frames_u8, wt, gamma, beta)
+    if frames_u8.dtype != torch.uint8 or tuple(frames_u8.shape[1:]) != (224, 224, 3) or not frames_u8.is_contiguous():
+        raise ValueError("frames must be contiguous uint8 [n,224,224,3]")
+    if wt.dtype != torch.bfloat16 or wt.shape[0] != 64 or wt.shape[1] != 224:
+        raise ValueError("stem weight must be bf16 [64, 224] (7 kernel rows x 8 pixels x 4 channels)")
+    n = frames_u8.shape[0]
+    dev = frames_u8.device
+    y = torch.empty((n, 56, 56, 64), dtype=torch.bfloat16, device=dev)
+    groups = n // frames_per_group if frames_per_group else 0
+    scale = torch.empty((groups, 64), dtype=torch.float32, device=dev)
+    shift = torch.empty((groups, 64), dtype=torch.float32, device=dev)
+    need = int(lib().avs_stem_workspace_bytes(n))
+    ws = _stem_ws.get(dev)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+        _stem_ws[dev] = ws
+    m3 = (c_float * 3)(*[float(v) for v in mean])
+    s3 = (c_float * 3)(*[float(v) for v in std])
+    # algorithmic: 2 * 147 MACs per output, uint8 frames in, pooled bf16 map out
+    _timed("stem", AVS_BF16, 2.0 * n * 112 * 112 * 64 * 147, lambda: check(
+        lib().avs_stem_conv_bn_pool_bf16(_p(frames_u8), n, float(denom), m3, s3, _p(wt), wt.stride(0),
+                                         int(frames_per_group), _p(gamma), _p(beta), float(eps), 1 if relu else 0,
+                                         _p(y), _p(scale), _p(shift), _p(ws), ws.numel(), _stream()),
+        "avs_stem_conv_bn_pool_bf16"), float(frames_u8.numel()) + 2.0 * y.numel())
+    return y, scale, shift
 
 
 def resize_bilinear(frames_u8, dh, dw):

@@ -355,6 +355,54 @@ def test_conv1x1_gram_statistics_and_streaming_pass(dev, rpg, k, n, with_res, xf
     assert diff.max().item() < 0.02 * scale and (diff > 0).float().mean().item() < 0.05
 
 
+@pytest.mark.parametrize("n,fpg", [(6, 1), (8, 4), (3, 3)])
+def test_fused_stem_against_the_unfused_sequence_and_torch(dev, n, fpg):
+    """avs_stem_conv_bn_pool_bf16 (uint8 frames -> normalise -> conv1 7x7/2 -> per-tile partial sums + max / min pooled
+    raw maps -> bn1 + ReLU on the max or min by the sign of scale) against (i) torch fp32 on the bf16-rounded operands
+    and (ii) the unfused HIP sequence (normalise, convolution + statistics, BatchNorm + ReLU + maxpool).  gamma has both
+    signs so that the min-pooled map is exercised; image borders exercise the -inf padding of the pooling."""
+    from avsum_amd import ops
+    from avsum_amd.cnn import RESNET_MEAN, RESNET_STD, _stem_weight
+    g = torch.Generator().manual_seed(40 + n)
+    frames = torch.randint(0, 256, (n, 224, 224, 3), dtype=torch.uint8, generator=g)
+    w4 = torch.randn(64, 3, 7, 7, generator=g) * (2.0 / (64 * 49)) ** 0.5
+    gamma = torch.randn(64, generator=g)                      # both signs
+    beta = torch.randn(64, generator=g) * 0.5
+    wk = _stem_weight(w4, 8, torch.bfloat16).to(dev)
+    fd, gd, bd = frames.to(dev), gamma.to(dev), beta.to(dev)
+    y, sc, sh = ops.stem_conv_bn_pool(fd, wk, 1.0, RESNET_MEAN, RESNET_STD, fpg, gd, bd, 1e-5)
+    y2, sc2, sh2 = ops.stem_conv_bn_pool(fd, wk, 1.0, RESNET_MEAN, RESNET_STD, fpg, gd, bd, 1e-5)
+    assert torch.equal(y, y2) and torch.equal(sc, sc2) and torch.equal(sh, sh2)     # deterministic
+    assert y.shape == (n, 56, 56, 64) and sc.shape == (n // fpg, 64)
+    # (i) torch fp32 on the bf16-rounded normalised input and weights
+    mean = torch.tensor(RESNET_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(RESNET_STD).view(1, 3, 1, 1)
+    x = ((frames.permute(0, 3, 1, 2).float() - mean) / std).bfloat16().float()
+    raw = F.conv2d(x, w4.bfloat16().float(), None, 2, 3)                             # [n,64,112,112]
+    rg = raw.view(n // fpg, fpg, 64, 112, 112)
+    m = rg.mean((1, 3, 4), keepdim=True)
+    v = rg.var((1, 3, 4), unbiased=False, keepdim=True)
+    scale_ref = (gamma.view(1, 1, 64, 1, 1) / torch.sqrt(v + 1e-5))
+    shift_ref = beta.view(1, 1, 64, 1, 1) - m * scale_ref
+    assert (sc.cpu() - scale_ref.view(-1, 64)).abs().max().item() < 2e-3 * scale_ref.abs().max().item()
+    act = torch.relu(rg.bfloat16().float() * scale_ref + shift_ref).view(n, 64, 112, 112)
+    ref = F.max_pool2d(act, 3, 2, 1).permute(0, 2, 3, 1)
+    got = y.float().cpu()
+    tol = max(1.0, ref.abs().max().item())
+    assert (got - ref).abs().max().item() < 0.03 * tol and (got - ref).abs().mean().item() < 0.004 * tol
+    # (ii) the unfused HIP sequence: identical convolution values up to the summation order => a bf16 step here and there
+    x0 = ops.frames_normalize(fd, torch.bfloat16, 1.0, RESNET_MEAN, RESNET_STD, 230, 232, 3, 3)
+    rawd = torch.empty((n, 112, 112, 64), dtype=torch.bfloat16, device=dev)
+    geom, xs = (n, 230, 112, 32, 7, 1, 2, 1, 0, 0, 112, 112, 64), (230 * 232 * 4, 232 * 4, 8)
+    scu, shu = ops.conv2d_raw(ops.dtype_code(torch.bfloat16), *geom, x0, *xs, wk, wk.stride(0), rawd, 64,
+                              bnstats=(fpg * 112 * 112, gd, bd, 1e-5))
+    rows = torch.arange(0, n + 1, fpg, dtype=torch.int64, device=dev) * 112 * 112
+    yu = ops.bn_maxpool(rawd, scu, shu, rows, True, 3, 2, 1, torch.empty_like(y))
+    assert (sc - scu).abs().max().item() < 1e-4 * scu.abs().max().item()
+    diff = (y.float() - yu.float()).abs()
+    assert diff.max().item() < 0.03 * tol and (diff > 0).float().mean().item() < 0.02
+
+
 def test_resnet50_bf16_deferred_bn_apply_close(dev):
     """Whole trunk with bn2 applied inside conv3's kernel vs applied by its own pass: the same arithmetic, every
     kernel on the path deterministic => bit-identical features."""
