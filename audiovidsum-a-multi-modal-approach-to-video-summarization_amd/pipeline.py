@@ -114,9 +114,13 @@ class FrameScoringPipeline:
         visual = torch.zeros((n, 4096), dtype=torch.float32, device=dev)
         passes = []   # (group size, frame slice | index array, contiguous)
         for gsz, where in self._uniform_sets(video_offsets):
-            per_pass = max(gsz, self.chunk_frames // gsz * gsz)
             contiguous = isinstance(where, tuple)
             lo, hi = where if contiguous else (0, len(where))
+            # passes of equal size (a short last pass runs the same launches on a fraction of the chip's worth of
+            # work): at most chunk_frames frames each, whole groups
+            cap = max(gsz, self.chunk_frames // gsz * gsz)
+            npass = max(1, -(-(hi - lo) // cap))
+            per_pass = min(cap, max(gsz, -(-(-(-(hi - lo) // npass)) // gsz) * gsz))
             for a in range(lo, hi, per_pass):
                 b = min(a + per_pass, hi)
                 passes.append((gsz, (a, b) if contiguous else where[a:b], contiguous))

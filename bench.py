@@ -304,8 +304,9 @@ def main():
     ap.add_argument("--mean-frames", type=int, default=None)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--extractor", default="resnet50", choices=["resnet50", "resnet50+inception3"])
-    ap.add_argument("--chunk", type=int, default=12288,
-                    help="frames per pass of the trunk (activations of one pass: ~60 GB of the 288 GB at 12288)")
+    ap.add_argument("--chunk", type=int, default=24576,
+                    help="most frames per pass of the trunk (passes are made equal: 45 143 frames = 2 x 22 572; the "
+                         "activations of a 22 572-frame bf16 pass take ~160 GB of the 288 GB)")
     ap.add_argument("--cpu-sample", type=int, default=128, help="frames per CPU-baseline run (0 = skip)")
     ap.add_argument("--cpu-runs", type=int, default=5, help="CPU-baseline runs (the median is reported)")
     ap.add_argument("--frames-per-group", type=int, default=1,
@@ -468,7 +469,7 @@ def main():
                     frames, offsets, base + "bf16, frames normalised in the reference's micro-batches of 4 inside "
                     "each video (extractors.py:48), per-frame scores")
             run_sub("resnet50+inception3", FrameScoringPipeline(extractor, scorer, use_inception=True,
-                                                                chunk_frames=args.chunk, frames_per_group=1),
+                                                                chunk_frames=min(args.chunk, 12288), frames_per_group=1),
                     frames, offsets, base + "bf16, both trunks of VisualFeatureExtractor.forward (Inception-v3: eval "
                     "BatchNorm folded, 299x299 bilinear resize on the GPU)")
             # PCIe-inclusive: the same headline step with the frames in pinned host memory, each pass uploaded by a
