@@ -102,6 +102,14 @@ class FrameScoringPipeline:
                 sets.append((r, np.concatenate(tails)))
         return sets
 
+    @staticmethod
+    def _pass_frames(count, chunk_frames, gsz):
+        """Frames per pass for `count` frames in groups of gsz: the fewest passes of at most chunk_frames frames, made
+        equal in size, whole groups (45 143 frames at 24 576 -> 2 x 22 572, not 24 576 + 20 567)."""
+        cap = max(gsz, chunk_frames // gsz * gsz)
+        npass = max(1, -(-count // cap))
+        return min(cap, max(gsz, -(-(-(-count // npass)) // gsz) * gsz))
+
     def embed(self, frames_u8, video_offsets):
         """uint8 [N,224,224,3] -> fp32 [N,4096] on the device (ResNet-50 | Inception-v3 halves).
         frames_u8 on the device: read in place.  frames_u8 in PINNED host memory: every pass's frames are uploaded
@@ -118,9 +126,7 @@ class FrameScoringPipeline:
             lo, hi = where if contiguous else (0, len(where))
             # passes of equal size (a short last pass runs the same launches on a fraction of the chip's worth of
             # work): at most chunk_frames frames each, whole groups
-            cap = max(gsz, self.chunk_frames // gsz * gsz)
-            npass = max(1, -(-(hi - lo) // cap))
-            per_pass = min(cap, max(gsz, -(-(-(-(hi - lo) // npass)) // gsz) * gsz))
+            per_pass = self._pass_frames(hi - lo, self.chunk_frames, gsz)
             for a in range(lo, hi, per_pass):
                 b = min(a + per_pass, hi)
                 passes.append((gsz, (a, b) if contiguous else where[a:b], contiguous))

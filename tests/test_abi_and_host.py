@@ -302,3 +302,16 @@ def test_accuracy_report_counts():
     assert rep["selection_agreement"] == 0.4 and rep["score_max_abs_err"] > 0.5
     segs = synthetic_gt_segments(300, 900)
     assert segs == synthetic_gt_segments(300, 900) and all(0 <= a < b <= 300 for a, b in segs)
+
+
+def test_pipeline_pass_sizes_cover_every_frame_in_equal_passes():
+    from avsum_amd.pipeline import FrameScoringPipeline
+    f = FrameScoringPipeline._pass_frames
+    assert f(45143, 24576, 1) == 22572 and f(45143, 24576, 4) == 22572 and f(250000, 24576, 1) == 22728
+    assert f(11, 4, 4) == 4 and f(11, 1024, 1) == 11 and f(5, 8, 4) == 8 and f(7, 2, 1) == 2 and f(1, 256, 1) == 1
+    for count, chunk, gsz in ((45143, 24576, 1), (99991, 12288, 4), (13, 5, 3), (24577, 24576, 1), (8, 8, 8), (9, 8, 8)):
+        per = f(count, chunk, gsz)
+        assert per % gsz == 0 and gsz <= per <= max(gsz, chunk // gsz * gsz)
+        passes = -(-count // per)
+        assert passes == max(1, -(-count // max(gsz, chunk // gsz * gsz)))     # never more passes than the cap needs
+        assert (passes - 1) * per < count <= passes * per
