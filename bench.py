@@ -124,15 +124,17 @@ def timed_steps(step, steps, warmup, barrier, profile=None):
     return elapsed, last, prof
 
 
-def roofline_from(prof, dtype, elapsed, traffic):
+def roofline_from(prof, dtype, elapsed, traffic, split=False):
     from avsum_amd import ops
     summ = prof.summary()
-    code = ops.dtype_code(dtype)
+    code = ops.dtype_code(dtype, split)
     conv = summ.get(("conv", code))
     if not conv or conv["ms"] <= 0:
         return None
     achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
-    peak = MFMA_BF16_PEAK_TFLOPS if dtype == torch.bfloat16 else MFMA_F32_PEAK_TFLOPS
+    # f32split runs three bf16 MFMAs per algorithmic product: against the bf16 peak the useful rate is a third of it
+    peak = MFMA_BF16_PEAK_TFLOPS if dtype == torch.bfloat16 else (MFMA_BF16_PEAK_TFLOPS / 3.0 if split
+                                                                   else MFMA_F32_PEAK_TFLOPS)
     seen = prof.seen.get(("conv", code), conv["launches"])
     roofline = {"bound": "mfma", "kernel": "igemm_kernel (avs_conv2d_nhwc[_bnstats|_bnlocal])",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
@@ -302,7 +304,9 @@ def main():
                          "sharded inference")
     ap.add_argument("--videos", type=int, default=None)
     ap.add_argument("--mean-frames", type=int, default=None)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f32split"],
+                    help="arithmetic of the CNN: bf16 (throughput), f32 (exact parity mode), f32split (fp32 storage, "
+                         "products on the bf16 matrix cores as hi*hi + hi*lo + lo*hi)")
     ap.add_argument("--extractor", default="resnet50", choices=["resnet50", "resnet50+inception3"])
     ap.add_argument("--chunk", type=int, default=24576,
                     help="most frames per pass of the trunk (passes are made equal: 45 143 frames = 2 x 22 572; the "
@@ -345,12 +349,13 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    split = args.dtype == "f32split"
     use_inception = args.extractor != "resnet50"
     fpg = args.frames_per_group
 
     # seeded random-init weights of the reference architectures (no pretrained files offline)
     torch.manual_seed(7)
-    extractor = VisualFeatureExtractor(dtype, "batch")
+    extractor = VisualFeatureExtractor(dtype, "batch", f32_split=split)
     scorer = AVBiLSTMModel().eval()
     sd_cpu = None
     if rank == 0 and args.cpu_sample > 0 and world == 1:
@@ -416,7 +421,8 @@ def main():
     frames_all = float(n_all.item())
 
     if rank == 0:
-        roofline = roofline_from(prof, dtype, elapsed, pmc_traffic()) if prof is not None else None
+        roofline = roofline_from(prof, dtype, elapsed, pmc_traffic() if args.dtype == "bf16" else (None, None),
+                                 split) if prof is not None else None
         group_txt = "per-frame shots" if fpg == 1 else f"{fpg}-frame micro-batches"
 
         # ---- CPU baseline + accuracy of the benchmarked mode on the same samples (outside every timed region)
