@@ -115,7 +115,9 @@ class ResNet50Runner:
         self.fuse_min_rows, self.fuse_ratio_num, self.fuse_ratio_den = 128, 2, 1
         self.bn_local = True         # the one-launch tile-local form where the library takes the shape
         self.gram_stats = True       # conv3 / downsample of layers 1-2: Gram-matrix statistics + one streaming pass
-        self.fused_stem = True       # uint8 frames -> conv1 -> max/min-pooled raw maps + partial sums in one kernel
+        self.fused_stem = True       # uint8 frames -> conv1 -> pooled raw map + partial sums in one kernel
+        self.stem_raw = True         # bn1 + ReLU ride in the staging of layer 1's first conv1 / downsample (both take the
+                                     # one-pass form on ONE Gram matrix of the stem output): no finishing pass
         self.defer_bn_apply = True   # bn2 + ReLU applied inside conv3's two-pass kernel (avs_conv1x1_bn_in_bf16)
         self._key = None
         self._w = None
@@ -143,6 +145,12 @@ class ResNet50Runner:
                     d["cd"] = _ohwi(blk.downsample[0].weight, dt)
                     d["bd"] = bn(blk.downsample[1])
                 w["blocks"].append(d)
+        # layer 1's first block: conv1 (64 -> 64) and the downsample (64 -> 256) read the same input, so ONE Gram matrix
+        # gives the batch statistics of both: their weights / BatchNorm parameters stacked for avs_bn_gram_affine_bf16
+        b0 = w["blocks"][0]
+        if "cd" in b0 and b0["c1"].shape[1] == b0["cd"].shape[1] and b0["b1"][2] == b0["bd"][2]:
+            w["cat0"] = (torch.cat([b0["c1"], b0["cd"]]).contiguous(), torch.cat([b0["b1"][0], b0["bd"][0]]).contiguous(),
+                         torch.cat([b0["b1"][1], b0["bd"][1]]).contiguous(), b0["b1"][2], b0["c1"].shape[0])
         self._w, self._key = w, key
         return w
 
@@ -295,10 +303,17 @@ class ResNet50Runner:
 
         # stem: (x - mean)/std without /255 (extractors.py:133-139), conv1 7x7/2 pad 3, bn1, ReLU, maxpool 3x3/2
         stem_local = slot()
+        x_aff = None     # (scale, shift) of bn1 when x is the stem's RAW pooled map (applied by block 0's kernels)
         if self.fused_stem and self.bn_mode == "batch" and uniform and dt == torch.bfloat16:
-            # one fused launch + a tiny finishing pass: the normalised image and the 112x112x64 map never reach HBM
+            # one fused launch: the normalised image and the 112x112x64 map never reach HBM.  bn1 + ReLU: a finishing
+            # pass in place, or (stem_raw) inside the staging of the first block's conv1 / downsample
             gamma, beta, eps = w["bn1"][:3]
-            x = ops.stem_conv_bn_pool(frames_u8, w["stem"], 1.0, RESNET_MEAN, RESNET_STD, gsz, gamma, beta, eps)[0]
+            raw = (self.stem_raw and self.gram_stats and self.fuse_conv_bn and "cat0" in w
+                   and ops.gram_supported(64, w["cat0"][0].shape[0]) and gsz * 56 * 56 >= self.fuse_min_rows)
+            x, sc0, sh0 = ops.stem_conv_bn_pool(frames_u8, w["stem"], 1.0, RESNET_MEAN, RESNET_STD, gsz, gamma, beta, eps,
+                                                apply=not raw)
+            if raw:
+                x_aff = (sc0, sh0)
         else:
             x0 = ops.frames_normalize(frames_u8, dt, 1.0, RESNET_MEAN, RESNET_STD, 230, 232, 3, 3)
             geom, xs, _ = self._stem_geom(n)
@@ -312,8 +327,23 @@ class ResNet50Runner:
             s1, s2 = slot(), slot()
             sd = slot() if "cd" in blk else False
             s3 = slot()
-            geom, xs, _ = self._nhwc_geom(n, hcur, cin, 1, 1, 0, planes)
-            t1 = self._conv_bn(geom, xs, x, blk["c1"], blk["b1"], groups, local=s1)
+            idn = None
+            if x_aff is not None:
+                # first block on the stem's raw map: one Gram matrix -> the folded affines of conv1 and the downsample,
+                # then one streaming pass each (bn1 + ReLU of the stem applied on the way in)
+                wcat, gcat, bcat, eps, c1n = w["cat0"]
+                x2d, gmax = x.view(-1, cin), gsz * hcur * hcur
+                sc, sh = ops.bn_gram_affine(x2d, wcat, gmax, gcat, bcat, eps, x_aff)
+                t1 = torch.empty((n, hcur, hcur, planes), dtype=dt, device=dev)
+                ops.conv1x1_affine(x2d, blk["c1"], gmax, sc[:, :c1n].contiguous(), sh[:, :c1n].contiguous(),
+                                   t1.view(-1, planes), None, True, x_aff)
+                idn = torch.empty((x2d.shape[0], planes * 4), dtype=dt, device=dev)
+                ops.conv1x1_affine(x2d, blk["cd"], gmax, sc[:, c1n:].contiguous(), sh[:, c1n:].contiguous(), idn, None,
+                                   False, x_aff)
+                x_aff = None
+            else:
+                geom, xs, _ = self._nhwc_geom(n, hcur, cin, 1, 1, 0, planes)
+                t1 = self._conv_bn(geom, xs, x, blk["c1"], blk["b1"], groups, local=s1)
             # bn2 + ReLU ride in conv3's input staging when conv3 takes the two-pass kernel: conv2 then only
             # writes its raw output and statistics (no apply pass over it)
             gmax3 = gsz * hout * hout
@@ -326,7 +356,9 @@ class ResNet50Runner:
             if defer2:
                 t2, aff2 = t2
             del t1
-            if "cd" in blk:
+            if idn is not None:
+                pass
+            elif "cd" in blk:
                 geom, xs, _ = self._nhwc_geom(n, hcur, cin, 1, s, 0, planes * 4)
                 idn = self._conv_bn(geom, xs, x, blk["cd"], blk["bd"], groups, relu=False,
                                     local=sd).view(-1, planes * 4)

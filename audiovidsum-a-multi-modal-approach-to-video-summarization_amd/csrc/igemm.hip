@@ -154,7 +154,7 @@ __device__ __forceinline__ uint4 avs_lds_read_b128(unsigned byte_addr) {
 // the loop ran at 45 % matrix-core occupancy for that reason alone - with no staging at all it reaches 1.5 PFLOP/s.)
 template <int ES, int BN, bool ACC64, bool SPATIAL, int ROWB, int EPI, bool PIPE, int WR = 2, bool FASTK = false,
           bool SPLIT = false>
-__global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? 3 : 2) void igemm_kernel(
+__global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64 && ES == 2) ? 4 : 3) : 2) void igemm_kernel(
     IgemmParams p) {
   static_assert(!SPLIT || (ES == 4 && !ACC64), "the split-bf16 arithmetic is for fp32 operands");
   static_assert(WR == 2 || (WR == 4 && ES == 2 && !ACC64), "256-row tiles are built for the bf16 variants");

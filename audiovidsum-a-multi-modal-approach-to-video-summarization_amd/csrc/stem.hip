@@ -8,10 +8,12 @@
 // y' = relu(scale * y + shift), scale = gamma / sigma, the map y -> y' is monotone (non-decreasing for scale >= 0,
 // non-increasing for scale < 0; multiply, add, ReLU and the final rounding are all monotone in floating point), so
 //     maxpool(y') = relu(scale * (scale >= 0 ? MAXpool(y) : MINpool(y)) + shift)        exactly, bit for bit.
-// stem_fused_kernel therefore pools the RAW (bf16-rounded) convolution output on chip, both ways, and writes two
-// 56x56x64 maps (802 KB per frame) plus the tile's partial sums for the statistics; stem_finish_kernel picks max or
-// min per channel once scale is known.  2.2 MB of traffic per frame, and the normalisation of the input rides in the
-// staging (the padded 4-channel image never exists in HBM).
+// And which of the two it is does not wait for the statistics either: sigma > 0, so sign(scale) = sign(gamma), a
+// parameter.  stem_fused_kernel therefore pools the RAW (bf16-rounded) convolution output on chip - max for the channels
+// with gamma >= 0, min for the others - and writes ONE 56x56x64 map (401 KB per frame) plus the tile's partial sums
+// for the statistics; the affine + ReLU is applied afterwards in place (stem_finish_kernel) or by the consumers while
+// they stage it (apply = 0: conv1x1_bn_kernel<XF> / bn_gram_affine_kernel<XF>).  0.55 - 1.35 MB of traffic per frame,
+// and the normalisation of the input rides in the staging (the padded 4-channel image never exists in HBM).
 //
 // One workgroup (5 waves) = one frame x 32 of the 64 output channels, walking the frame's 49 tiles; a tile = 8 x 8 pooled outputs = 17 x 17 convolution
 // outputs (16 x 16 owned + the halo row / column the pooling windows reach into, recomputed: 13 % extra matrix work).
@@ -22,7 +24,7 @@
 //     output pixel is the 16 bytes of two neighbouring patch pixels - one aligned ds_read_b128, no im2col copy;
 //     weights [64][224] resident in LDS for the whole row of tiles; v_mfma_f32_32x32x16_bf16;
 //   * epilogue: column sums of the OWNED outputs (fp32 accumulators) -> per-tile partials (fixed order, no atomics);
-//     bf16 raw tile -> LDS; 3x3/2 max and min over it -> 16-byte stores.
+//     bf16 raw tile -> LDS; 3x3/2 max (min where gamma < 0) over it -> 16-byte stores.
 #include "avs_internal.h"
 #include <stdlib.h>
 
@@ -52,8 +54,8 @@ constexpr int WAVES = 5;
 struct StemParams {
   const uint8_t* frames;
   const char* w;
-  char* omax;
-  char* omin;
+  char* osel;          // [n,56,56,64] bf16: per channel the window's max (gamma >= 0) or min (gamma < 0) of the raw output
+  const float* gamma;
   float* part;
   long long ldw;
   float denom, mean[3], stdv[3];
@@ -109,6 +111,14 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stem_fused_kernel(StemParams p)
     own[mt] = mk;
   }
   const int bbase = lr * W_PITCH + lh * 16;
+  // pooling: a thread's items all have the same 8 channels (320 % 4 == 0).  On the order-preserving keys negation is
+  // the complement, so the channels with gamma < 0 run the same packed MAX on complemented keys (= min of the values).
+  s16x2 flip[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ch = c0 + (t & 3) * 8 + 2 * j;
+    flip[j] = (s16x2){(short)(p.gamma[ch] < 0.f ? -1 : 0), (short)(p.gamma[ch + 1] < 0.f ? -1 : 0)};
+  }
 
   // The patch pixels of a tile are fetched into REGISTERS one tile ahead (15 byte loads per thread, issued before the
   // matrix work of the previous tile and landing during it and its epilogue), then normalised through the LUT and
@@ -222,19 +232,16 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stem_fused_kernel(StemParams p)
         if (m < MROWS) *reinterpret_cast<unsigned short*>(mainb + m * RT_PITCH + lr * 2) = avs_f32_to_bf16(acc[mt][e]);
       }
     __syncthreads();
-    // ---- 3x3 / 2 max and min over the raw tile: item = (pooled pixel of the 8 x 8, 8 of the 32 channels).
+    // ---- 3x3 / 2 max (min) over the raw tile: item = (pooled pixel of the 8 x 8, 8 of the 32 channels).
     // bf16 values compare like their bit patterns after the map key(x) = x ^ ((x >> 15) & 0x7fff) (sign-magnitude ->
-    // two's complement order), which is its own inverse: the window runs on PACKED signed 16-bit max / min (two
-    // channels per instruction), the keys are mapped back at the end.  Exact, no float conversion.
+    // two's complement order), which is its own inverse: the window runs on PACKED signed 16-bit max (two channels
+    // per instruction), the keys are mapped back at the end.  Exact, no float conversion.
     for (int it = t; it < 64 * 4 && !STEM_DBG(p, 1); it += WAVES * 64) {
       const int cg = it & 3, pp = it >> 2;
       const int pyl = pp >> 3, pxl = pp & 7;
-      s16x2 kmax[4], kmin[4];
+      s16x2 kmax[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        kmax[j] = (s16x2){(short)-32768, (short)-32768};
-        kmin[j] = (s16x2){(short)32767, (short)32767};
-      }
+      for (int j = 0; j < 4; ++j) kmax[j] = (s16x2){(short)-32768, (short)-32768};
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy) {
         const int ly = 2 * pyl + dy;
@@ -248,22 +255,20 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stem_fused_kernel(StemParams p)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const s16x2 x = __builtin_bit_cast(s16x2, vv[j]);
-            const s16x2 k = x ^ ((x >> 15) & (s16x2){(short)0x7fff, (short)0x7fff});
+            const s16x2 k = x ^ ((x >> 15) & (s16x2){(short)0x7fff, (short)0x7fff}) ^ flip[j];
             kmax[j] = __builtin_elementwise_max(kmax[j], k);
-            kmin[j] = __builtin_elementwise_min(kmin[j], k);
           }
         }
       }
-      unsigned mx[4], mn[4];
+      unsigned mx[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const s16x2 m7 = (s16x2){(short)0x7fff, (short)0x7fff};
-        mx[j] = __builtin_bit_cast(unsigned, kmax[j] ^ ((kmax[j] >> 15) & m7));
-        mn[j] = __builtin_bit_cast(unsigned, kmin[j] ^ ((kmin[j] >> 15) & m7));
+        const s16x2 k = kmax[j] ^ flip[j];
+        mx[j] = __builtin_bit_cast(unsigned, k ^ ((k >> 15) & m7));
       }
       const long long o = (((img * POOL + 8 * ty + pyl) * POOL + 8 * tx + pxl) * COUT + c0 + cg * 8) * 2;
-      *reinterpret_cast<uint4*>(p.omax + o) = make_uint4(mx[0], mx[1], mx[2], mx[3]);
-      *reinterpret_cast<uint4*>(p.omin + o) = make_uint4(mn[0], mn[1], mn[2], mn[3]);
+      *reinterpret_cast<uint4*>(p.osel + o) = make_uint4(mx[0], mx[1], mx[2], mx[3]);
     }
     __syncthreads();   // the raw tile has been read: the next patch may overwrite it
   }
@@ -291,20 +296,17 @@ __global__ __launch_bounds__(256) void stem_fold_kernel(const float* __restrict_
   shift[i] = beta[ch] - mean * sc;
 }
 
-// y = relu(scale * (scale >= 0 ? max : min) + shift) in avs_bn_apply's arithmetic (multiply, add, ReLU, round): 8
-// channels per thread.
-__global__ __launch_bounds__(256) void stem_finish_kernel(const char* __restrict__ omax, const char* __restrict__ omin,
-                                                          long long items, int fpg, const float* __restrict__ scale,
-                                                          const float* __restrict__ shift, int relu,
-                                                          char* __restrict__ y) {
+// y = relu(scale * y + shift) IN PLACE on the selected-extreme map, in avs_bn_apply's arithmetic (multiply, add, ReLU,
+// round): 8 channels per thread.
+__global__ __launch_bounds__(256) void stem_finish_kernel(long long items, int fpg, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int relu, char* y) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < items;
        i += (long long)gridDim.x * blockDim.x) {
     const int cg = (int)(i & 7);
     const long long px = i >> 3;
     const long long g = (px / (POOL * POOL)) / fpg;
-    const uint4 a = *reinterpret_cast<const uint4*>(omax + i * 16);
-    const uint4 b = *reinterpret_cast<const uint4*>(omin + i * 16);
-    const unsigned av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+    const uint4 a = *reinterpret_cast<const uint4*>(y + i * 16);
+    const unsigned av[4] = {a.x, a.y, a.z, a.w};
     const float4 s0 = *reinterpret_cast<const float4*>(scale + g * COUT + cg * 8);
     const float4 s1 = *reinterpret_cast<const float4*>(scale + g * COUT + cg * 8 + 4);
     const float4 h0 = *reinterpret_cast<const float4*>(shift + g * COUT + cg * 8);
@@ -314,8 +316,8 @@ __global__ __launch_bounds__(256) void stem_finish_kernel(const char* __restrict
     unsigned out[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float x0 = sc[2 * j] >= 0.f ? __uint_as_float(av[j] << 16) : __uint_as_float(bv[j] << 16);
-      const float x1 = sc[2 * j + 1] >= 0.f ? __uint_as_float(av[j] & 0xffff0000u) : __uint_as_float(bv[j] & 0xffff0000u);
+      const float x0 = __uint_as_float(av[j] << 16);
+      const float x1 = __uint_as_float(av[j] & 0xffff0000u);
       float y0 = x0 * sc[2 * j] + sh[2 * j];
       float y1 = x1 * sc[2 * j + 1] + sh[2 * j + 1];
       if (relu) {
@@ -330,14 +332,14 @@ __global__ __launch_bounds__(256) void stem_finish_kernel(const char* __restrict
 
 extern "C" int64_t avs_stem_workspace_bytes(int n) {
   if (n < 0) return AVS_E_SHAPE;
-  // max map + min map (bf16 [n,56,56,64] each) + per-tile partial sums fp32 [n * 49, 2, 64]
-  return (int64_t)n * POOL * POOL * COUT * 2 * 2 + (int64_t)n * TILES * TILES * 2 * COUT * 4;
+  // per-tile partial sums fp32 [n * 49, 2, 64] (the pooled map goes straight to the output)
+  return (int64_t)n * TILES * TILES * 2 * COUT * 4;
 }
 
 extern "C" int avs_stem_conv_bn_pool_bf16(const uint8_t* d_frames, int n, float denom, const float* mean3,
                                           const float* std3, const void* d_w, int64_t ldw, int frames_per_group,
-                                          const float* d_gamma, const float* d_beta, float eps, int relu, void* d_y,
-                                          float* d_scale, float* d_shift, void* d_ws, int64_t ws_bytes,
+                                          const float* d_gamma, const float* d_beta, float eps, int apply, int relu,
+                                          void* d_y, float* d_scale, float* d_shift, void* d_ws, int64_t ws_bytes,
                                           avs_stream_t stream) {
   const char* who = "avs_stem_conv_bn_pool_bf16";
   AVS_REQUIRE(n >= 0 && frames_per_group > 0, AVS_E_SHAPE, "%s: n=%d frames_per_group=%d", who, n, frames_per_group);
@@ -360,10 +362,9 @@ extern "C" int avs_stem_conv_bn_pool_bf16(const uint8_t* d_frames, int n, float 
   p.frames = d_frames;
   p.w = (const char*)d_w;
   p.ldw = ldw;
-  const int64_t map_bytes = (int64_t)n * POOL * POOL * COUT * 2;
-  p.omax = (char*)d_ws;
-  p.omin = p.omax + map_bytes;
-  p.part = reinterpret_cast<float*>(p.omin + map_bytes);
+  p.osel = (char*)d_y;
+  p.gamma = d_gamma;
+  p.part = reinterpret_cast<float*>(d_ws);
   p.denom = denom;
 #ifdef AVS_STUDY
   p.debug = getenv("AVS_STEM_DEBUG") ? atoi(getenv("AVS_STEM_DEBUG")) : 0;
@@ -377,11 +378,13 @@ extern "C" int avs_stem_conv_bn_pool_bf16(const uint8_t* d_frames, int n, float 
   const int groups = n / frames_per_group;
   hipLaunchKernelGGL(stem_fold_kernel, dim3((unsigned)avs_cdiv((int64_t)groups * COUT, 256)), dim3(256), 0, st, p.part,
                      groups, frames_per_group, d_gamma, d_beta, eps, d_scale, d_shift);
-  const long long items = (long long)n * POOL * POOL * (COUT / 8);
-  long long gx = avs_cdiv(items, 256);
-  if (gx > 65536) gx = 65536;
-  hipLaunchKernelGGL(stem_finish_kernel, dim3((unsigned)gx), dim3(256), 0, st, p.omax, p.omin, items, frames_per_group,
-                     d_scale, d_shift, relu, (char*)d_y);
+  if (apply) {
+    const long long items = (long long)n * POOL * POOL * (COUT / 8);
+    long long gx = avs_cdiv(items, 256);
+    if (gx > 65536) gx = 65536;
+    hipLaunchKernelGGL(stem_finish_kernel, dim3((unsigned)gx), dim3(256), 0, st, items, frames_per_group, d_scale,
+                       d_shift, relu, (char*)d_y);
+  }
   AVS_CHECK_LAUNCH(who);
   return AVS_OK;
 }

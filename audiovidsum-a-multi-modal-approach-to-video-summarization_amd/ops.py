@@ -312,21 +312,31 @@ def bn_gram_affine(x2d, wt, rows_per_group, gamma, beta, eps, in_affine=None):
     return scale, shift
 
 
-def conv1x1_gram_bn(x2d, wt, rows_per_group, gamma, beta, eps, out2d, residual=None, relu=True, in_affine=None):
-    """1x1 convolution + batch-statistics BatchNorm (+residual, +ReLU), bf16, same operands as conv1x1_bn, in ONE
-    streaming pass over the output: the statistics come from the Gram matrix of the narrow input (bn_gram_affine),
-    the convolution applies the folded affine in its epilogue (avs_conv1x1_affine_bf16)."""
-    _dev(out2d, residual)
+def conv1x1_affine(x2d, wt, rows_per_group, scale, shift, out2d, residual=None, relu=True, in_affine=None):
+    """out = act((a . wt^T) * scale[g] + shift[g] + residual), bf16, one streaming pass (avs_conv1x1_affine_bf16):
+    scale / shift fp32 [groups, N] contiguous (a BatchNorm already folded, e.g. by bn_gram_affine); a = x2d or
+    bf16(relu(x2d * isc + ish)) with in_affine = (isc, ish) fp32 [groups, K]."""
+    _dev(x2d, wt, out2d, residual, scale, shift)
+    _rowmajor2d(x2d, "x")
+    _rowmajor2d(wt, "w")
     _rowmajor2d(out2d, "out")
     rows, k = x2d.shape
     n = wt.shape[0]
-    if out2d.dtype != torch.bfloat16 or out2d.shape != (rows, n):
-        raise ValueError("conv1x1_gram_bn: out must be bf16 [rows, N]")
+    if x2d.dtype != torch.bfloat16 or wt.dtype != torch.bfloat16 or out2d.dtype != torch.bfloat16:
+        raise TypeError("conv1x1_affine is the bf16 throughput path")
+    if rows % rows_per_group or wt.shape[1] != k or out2d.shape != (rows, n):
+        raise ValueError("conv1x1_affine: shapes do not match")
+    groups = rows // rows_per_group
+    for a in (scale, shift):
+        if a.dtype != torch.float32 or a.shape != (groups, n) or not a.is_contiguous():
+            raise ValueError("scale / shift must be contiguous fp32 [groups, N]")
     if residual is not None:
         _rowmajor2d(residual, "residual")
-    scale, shift = bn_gram_affine(x2d, wt, rows_per_group, gamma, beta, eps, in_affine)
-    groups = rows // rows_per_group
     isc, ish = in_affine if in_affine is not None else (None, None)
+    if in_affine is not None:
+        _dev(isc, ish)
+        if isc.shape != (groups, k) or ish.shape != (groups, k) or not isc.is_contiguous() or not ish.is_contiguous():
+            raise ValueError("in_affine must be contiguous fp32 [groups, K]")
     # algorithmic HBM bytes: read x, write y (+ read the residual)
     nbytes = 2.0 * rows * (k + n * (2 if residual is not None else 1))
     _timed("convbn", AVS_BF16, nbytes, lambda: check(
@@ -335,6 +345,14 @@ def conv1x1_gram_bn(x2d, wt, rows_per_group, gamma, beta, eps, out2d, residual=N
                                       residual.stride(0) if residual is not None else 0, 1 if relu else 0, _p(out2d),
                                       out2d.stride(0), _stream()), "avs_conv1x1_affine_bf16"))
     return out2d
+
+
+def conv1x1_gram_bn(x2d, wt, rows_per_group, gamma, beta, eps, out2d, residual=None, relu=True, in_affine=None):
+    """1x1 convolution + batch-statistics BatchNorm (+residual, +ReLU), bf16, same operands as conv1x1_bn, in ONE
+    streaming pass over the output: the statistics come from the Gram matrix of the narrow input (bn_gram_affine),
+    the convolution applies the folded affine in its epilogue (conv1x1_affine)."""
+    scale, shift = bn_gram_affine(x2d, wt, rows_per_group, gamma, beta, eps, in_affine)
+    return conv1x1_affine(x2d, wt, rows_per_group, scale, shift, out2d, residual, relu, in_affine)
 
 
 def conv2d(x, wt, kh, kw, stride, pad, out, bias=None, act=ACT_NONE, bnstats=None, split=False):
@@ -381,10 +399,12 @@ def frames_normalize(frames_u8, dtype, denom, mean, std, out_h, out_w, pad_t, pa
 _stem_ws = {}
 
 
-def stem_conv_bn_pool(frames_u8, wt, denom, mean, std, frames_per_group, gamma, beta, eps, relu=True):
+def stem_conv_bn_pool(frames_u8, wt, denom, mean, std, frames_per_group, gamma, beta, eps, relu=True, apply=True):
     """The fused ResNet-50 stem of the bf16 path (avs_stem_conv_bn_pool_bf16): uint8 [n,224,224,3] -> bf16
     [n,56,56,64] = maxpool(relu(bn1(conv1((x / denom - mean) / std)))) with batch statistics per group of
-    frames_per_group frames; wt = the stem weight in the 7 x 8 x 4 layout.  Returns (y, scale, shift)."""
+    frames_per_group frames; wt = the stem weight in the 7 x 8 x 4 layout.  Returns (y, scale, shift).
+    apply=False: y is the pooled RAW map and the consumers apply relu(scale * y + shift) while staging it (their
+    in_affine operand) - the finishing pass over the map is saved."""
     _dev(frames_u8, wt, gamma, beta)
     if frames_u8.dtype != torch.uint8 or tuple(frames_u8.shape[1:]) != (224, 224, 3) or not frames_u8.is_contiguous():
         raise ValueError("frames must be contiguous uint8 [n,224,224,3]")
@@ -406,8 +426,9 @@ def stem_conv_bn_pool(frames_u8, wt, denom, mean, std, frames_per_group, gamma, 
     # algorithmic: 2 * 147 MACs per output, uint8 frames in, pooled bf16 map out
     _timed("stem", AVS_BF16, 2.0 * n * 112 * 112 * 64 * 147, lambda: check(
         lib().avs_stem_conv_bn_pool_bf16(_p(frames_u8), n, float(denom), m3, s3, _p(wt), wt.stride(0),
-                                         int(frames_per_group), _p(gamma), _p(beta), float(eps), 1 if relu else 0,
-                                         _p(y), _p(scale), _p(shift), _p(ws), ws.numel(), _stream()),
+                                         int(frames_per_group), _p(gamma), _p(beta), float(eps), 1 if apply else 0,
+                                         1 if relu else 0, _p(y), _p(scale), _p(shift), _p(ws), ws.numel(),
+                                         _stream()),
         "avs_stem_conv_bn_pool_bf16"), float(frames_u8.numel()) + 2.0 * y.numel())
     return y, scale, shift
 

@@ -126,19 +126,24 @@ void avs_tune_bnlocal(int enabled);
 /* The whole ResNet-50 stem of the bf16 throughput path: uint8 frames [n,224,224,3] -> (x / denom - mean) / std ->
  * conv1 7x7/2 (64 channels) -> bn1 in batch-statistics mode over groups of frames_per_group frames -> ReLU ->
  * maxpool 3x3/2 pad 1 -> d_y bf16 [n,56,56,64]  (features/extractors.py:126-140 + children()[0:4] of the trunk, :29,65).
- * Because y -> relu(scale * y + shift) is monotone, the 3x3/2 pooling is done on the RAW convolution output on chip,
- * as a max AND a min map, before the statistics exist; the finishing kernel picks max (scale >= 0) or min per channel:
- * bit-identical to avs_frames_normalize_u8 + avs_conv2d_nhwc_bnstats + avs_bn_maxpool_nhwc on the same convolution
- * values, with 2.2 instead of 4.6 MB of HBM traffic per frame (the normalised image and the 112x112x64 map never
- * reach HBM).  d_w: bf16 [64, ldw >= 224], a row = 7 kernel rows x 8 pixels x 4 channels (zero where kx = 7 or
- * channel = 3).  d_scale / d_shift [n / frames_per_group, 64] receive bn1's folded affine.  Deterministic (per-tile
- * partial sums added in a fixed order).  d_ws: avs_stem_workspace_bytes(n) bytes, uninitialised.
+ * Because y -> relu(scale * y + shift) is monotone, the 3x3/2 pooling is done on the RAW convolution output on chip
+ * before the statistics exist - as a max for the channels with gamma >= 0 and a min for the others (sign(scale) =
+ * sign(gamma)): bit-identical to avs_frames_normalize_u8 + avs_conv2d_nhwc_bnstats + avs_bn_maxpool_nhwc on the
+ * same convolution values, with 1.35 instead of 4.6 MB of HBM traffic per frame (the normalised image and the
+ * 112x112x64 map never reach HBM).
+ * apply = 1: d_y receives the finished activations (relu applied when relu != 0).
+ * apply = 0: d_y receives the pooled RAW map; the consumer applies relu(scale * y + shift) per group and channel
+ *            while staging it (the d_in_scale / d_in_shift operands of avs_conv1x1_affine_bf16 and
+ *            avs_bn_gram_affine_bf16): one pass over the map less.
+ * d_w: bf16 [64, ldw >= 224], a row = 7 kernel rows x 8 pixels x 4 channels (zero where kx = 7 or channel = 3).
+ * d_scale / d_shift [n / frames_per_group, 64] receive bn1's folded affine.  Deterministic (per-tile partial sums
+ * added in a fixed order).  d_ws: avs_stem_workspace_bytes(n) bytes, uninitialised.
  * n must be a multiple of frames_per_group (AVS_E_UNSUPPORTED otherwise: use the unfused sequence).                */
 int64_t avs_stem_workspace_bytes(int n);
 int avs_stem_conv_bn_pool_bf16(const uint8_t* d_frames, int n, float denom, const float* mean3, const float* std3,
                                const void* d_w, int64_t ldw, int frames_per_group, const float* d_gamma,
-                               const float* d_beta, float eps, int relu, void* d_y, float* d_scale, float* d_shift,
-                               void* d_ws, int64_t ws_bytes, avs_stream_t stream);
+                               const float* d_beta, float eps, int apply, int relu, void* d_y, float* d_scale,
+                               float* d_shift, void* d_ws, int64_t ws_bytes, avs_stream_t stream);
 
 /* 1x1 convolution + batch-statistics BatchNorm (+ residual, + ReLU) in one kernel, bf16, for equal-sized
  * groups of rows_per_group consecutive rows (a micro-batch of frames at one resolution):

@@ -357,8 +357,8 @@ def test_conv1x1_gram_statistics_and_streaming_pass(dev, rpg, k, n, with_res, xf
 
 @pytest.mark.parametrize("n,fpg", [(6, 1), (8, 4), (3, 3)])
 def test_fused_stem_against_the_unfused_sequence_and_torch(dev, n, fpg):
-    """avs_stem_conv_bn_pool_bf16 (uint8 frames -> normalise -> conv1 7x7/2 -> per-tile partial sums + max / min pooled
-    raw maps -> bn1 + ReLU on the max or min by the sign of scale) against (i) torch fp32 on the bf16-rounded operands
+    """avs_stem_conv_bn_pool_bf16 (uint8 frames -> normalise -> conv1 7x7/2 -> per-tile partial sums + the pooled raw
+    map, max or min by the sign of gamma -> bn1 + ReLU) against (i) torch fp32 on the bf16-rounded operands
     and (ii) the unfused HIP sequence (normalise, convolution + statistics, BatchNorm + ReLU + maxpool).  gamma has both
     signs so that the min-pooled map is exercised; image borders exercise the -inf padding of the pooling."""
     from avsum_amd import ops
@@ -401,6 +401,18 @@ def test_fused_stem_against_the_unfused_sequence_and_torch(dev, n, fpg):
     assert (sc - scu).abs().max().item() < 1e-4 * scu.abs().max().item()
     diff = (y.float() - yu.float()).abs()
     assert diff.max().item() < 0.03 * tol and (diff > 0).float().mean().item() < 0.02
+    # (iii) apply = 0: the pooled RAW map (max where gamma >= 0, min elsewhere) + bn1's affine; the BatchNorm apply
+    # pass on it gives the finished map bit for bit
+    yr, sc3, sh3 = ops.stem_conv_bn_pool(fd, wk, 1.0, RESNET_MEAN, RESNET_STD, fpg, gd, bd, 1e-5, apply=False)
+    assert torch.equal(sc3, sc) and torch.equal(sh3, sh)
+    rows56 = torch.arange(0, n + 1, fpg, dtype=torch.int64, device=dev) * 56 * 56
+    fin = torch.empty_like(yr).view(-1, 64)
+    ops.bn_apply(yr.view(-1, 64), sc3, sh3, rows56, fpg * 56 * 56, None, ops.ACT_RELU, fin)
+    assert torch.equal(fin.view_as(y), y)
+    pooled = F.max_pool2d(raw.bfloat16().float() * torch.sign(gamma + (gamma == 0)).view(1, 64, 1, 1), 3, 2, 1) \
+        * torch.sign(gamma + (gamma == 0)).view(1, 64, 1, 1)
+    dr = (yr.float().cpu() - pooled.permute(0, 2, 3, 1)).abs()
+    assert dr.max().item() < 0.03 * max(1.0, pooled.abs().max().item()) and (dr > 0).float().mean().item() < 0.02
 
 
 def test_resnet50_bf16_deferred_bn_apply_close(dev):
@@ -415,6 +427,30 @@ def test_resnet50_bf16_deferred_bn_apply_close(dev):
     b.defer_bn_apply = False
     fa, fb = a.forward(frames).cpu(), b.forward(frames).cpu()
     assert torch.equal(fa, fb)
+
+
+@pytest.mark.parametrize("gsize", [1, 4])
+def test_resnet50_bf16_raw_stem_path(dev, gsize):
+    """Whole trunk with bn1 + ReLU of the stem applied inside the first block's conv1 / downsample (one shared Gram
+    matrix) against the stem finished by its own pass: the downsample branch is the same arithmetic (bit-identical
+    operands), conv1 changes form (Gram statistics + one pass instead of convolution + statistics + apply), so the
+    features agree to bf16 noise - and the path is deterministic."""
+    from avsum_amd.cnn import ResNet50Runner, resnet50_trunk
+    torch.manual_seed(31)
+    trunk = resnet50_trunk().to(dev)
+    with torch.no_grad():
+        trunk[1].weight.mul_(torch.where(torch.arange(64, device=dev) % 5 == 0, -1.0, 1.0))   # both signs of gamma
+    frames = torch.from_numpy(_frames(8, 9)).to(dev)
+    groups = list(range(0, 9, gsize))
+    a = ResNet50Runner(trunk, torch.bfloat16)
+    b = ResNet50Runner(trunk, torch.bfloat16)
+    b.stem_raw = False
+    fa, fa2, fb = a.forward(frames, groups).cpu(), a.forward(frames, groups).cpu(), b.forward(frames, groups).cpu()
+    assert torch.equal(fa, fa2)
+    f32 = ResNet50Runner(trunk, torch.float32).forward(frames, groups).cpu()
+    ea, eb = ((fa - f32).norm() / f32.norm()).item(), ((fb - f32).norm() / f32.norm()).item()
+    cos = torch.nn.functional.cosine_similarity(fa, fb, dim=1).min().item()
+    assert cos > 0.98 and ea < 0.2 and ea < 1.25 * eb + 0.01, (cos, ea, eb)
 
 
 @pytest.mark.parametrize("gsize", [1, 3, 4])
