@@ -119,6 +119,7 @@ class ResNet50Runner:
         self.stem_raw = True         # bn1 + ReLU ride in the staging of layer 1's first conv1 / downsample (both take the
                                      # one-pass form on ONE Gram matrix of the stem output): no finishing pass
         self.defer_bn_apply = True   # bn2 + ReLU applied inside conv3's two-pass kernel (avs_conv1x1_bn_in_bf16)
+        self.defer_res_apply = True  # the downsample's BatchNorm applied inside conv3's residual add (layer 2's first block)
         self._key = None
         self._w = None
         self._plans = {}     # (n, group frames) -> per layer: does it take the tile-local form
@@ -203,12 +204,14 @@ class ResNet50Runner:
                 and cout * self.fuse_ratio_den >= cin * self.fuse_ratio_num)
 
     def _conv_bn(self, geom, xs, x, wt, bnp, groups, residual=None, relu=True, local=False, algo_k=None, pool=None,
-                 defer=False, in_affine=None):
+                 defer=False, in_affine=None, res_affine=None):
         """One convolution + BatchNorm (+ residual, + ReLU) -> NHWC activation; picks the form (class docstring).
         pool = (k, s, p): a max pooling follows (the stem) - on the split form it is fused with the BatchNorm apply
         (avs_bn_maxpool_nhwc: the normalised full-resolution map is never written).
         defer: return (raw convolution, (scale, shift)) WITHOUT applying the BatchNorm - the next layer's two-pass
-        kernel applies it while staging its input (in_affine), so this layer needs no apply pass (bf16, equal groups)."""
+        kernel applies it while staging its input (in_affine), so this layer needs no apply pass (bf16, equal groups).
+        res_affine: the residual is a deferred (raw) downsample output; its BatchNorm rides in this layer's residual add
+        (one-pass 1x1 form only)."""
         n, ho, wo, cout = geom[0], geom[10], geom[11], geom[12]
         cin, kh, sh = geom[3], geom[4], geom[6]
         dev, dt = x.device, self.dtype
@@ -257,9 +260,13 @@ class ResNet50Runner:
         if in_affine is not None or (fast and bf16 and self._twopass_ok(cin, cout, kh, sh, gmax)):
             # statistics from the input's Gram matrix + ONE streaming pass where the shape allows it (the expanding
             # 1x1 layers of layers 1-2), else the two-pass kernel
-            form = ops.conv1x1_gram_bn if (self.gram_stats and ops.gram_supported(cin, cout)) else ops.conv1x1_bn
-            form(x.view(-1, cin), wt, gmax, gamma, beta, eps, y2d, residual, relu, in_affine)
+            if self.gram_stats and ops.gram_supported(cin, cout):
+                ops.conv1x1_gram_bn(x.view(-1, cin), wt, gmax, gamma, beta, eps, y2d, residual, relu, in_affine, res_affine)
+            else:
+                assert res_affine is None
+                ops.conv1x1_bn(x.view(-1, cin), wt, gmax, gamma, beta, eps, y2d, residual, relu, in_affine)
             return y
+        assert res_affine is None
         affine = None
         if fast:
             # statistics from the convolution's epilogue: per-tile partial sums of the fp32 accumulators, folded in
@@ -356,17 +363,25 @@ class ResNet50Runner:
             if defer2:
                 t2, aff2 = t2
             del t1
+            affd = None
             if idn is not None:
                 pass
             elif "cd" in blk:
+                # a downsample branch that would take convolution + statistics + apply keeps its output RAW when conv3
+                # is the one-pass form: its BatchNorm is folded into conv3's residual add
+                deferd = (defer2 and self.defer_res_apply and not sd and self.gram_stats
+                          and ops.gram_supported(planes, planes * 4)
+                          and not self._twopass_ok(cin, planes * 4, 1, s, gsz * hout * hout))
                 geom, xs, _ = self._nhwc_geom(n, hcur, cin, 1, s, 0, planes * 4)
-                idn = self._conv_bn(geom, xs, x, blk["cd"], blk["bd"], groups, relu=False,
-                                    local=sd).view(-1, planes * 4)
+                idn = self._conv_bn(geom, xs, x, blk["cd"], blk["bd"], groups, relu=False, local=sd, defer=deferd)
+                if deferd:
+                    idn, affd = idn
+                idn = idn.view(-1, planes * 4)
             else:
                 idn = x.view(-1, cin)
             geom, xs, _ = self._nhwc_geom(n, hout, planes, 1, 1, 0, planes * 4)
             x = self._conv_bn(geom, xs, t2, blk["c3"], blk["b3"], groups, residual=idn, relu=True, local=s3,
-                              in_affine=aff2)
+                              in_affine=aff2, res_affine=affd)
             del t2, idn
             hcur = hout
         return ops.global_avgpool(x, out)

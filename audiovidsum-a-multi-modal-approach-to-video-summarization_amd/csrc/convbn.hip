@@ -41,6 +41,10 @@ struct ConvBnParams {
   // input's Gram matrix), so the statistics pass is skipped: one streaming pass over the group
   const float* pre_scale;
   const float* pre_shift;
+  // RA: the residual is a RAW convolution output too (the downsample branch): its BatchNorm's folded affine
+  // [groups, N] is applied while it is added, y = act(bn(conv) + res * res_scale + res_shift)
+  const float* res_scale;
+  const float* res_shift;
 };
 
 #define AVS_CONVBN_MAX_K 512
@@ -49,7 +53,7 @@ struct ConvBnParams {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),            \
                                    (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
-template <int BN, bool XF, bool PRE = false>
+template <int BN, bool XF, bool PRE = false, bool RA = false>
 // (Four workgroups per CU for the streaming form - 40 KB of LDS each fits - need <= 128 VGPRs: the 128-column
 //  variants then spill 11-16 registers and the kernel ran at 3.1 instead of 4.2 TB/s; three it is.)
 __global__ __launch_bounds__(256, 3) void conv1x1_bn_kernel(ConvBnParams p) {
@@ -254,6 +258,15 @@ __global__ __launch_bounds__(256, 3) void conv1x1_bn_kernel(ConvBnParams p) {
         const int col = n0 + sch * 8;
         if (col < p.N) {  // N is a multiple of 8 (checked on the host)
           constexpr int NIT = A_ROWS / RSTEP;
+          float rs[RA ? 8 : 1], rh[RA ? 8 : 1];   // the residual's affine: this thread's 8 channels, the workgroup's group
+          if constexpr (RA) {
+            const float4 s0 = *reinterpret_cast<const float4*>(p.res_scale + (long long)g * p.N + col);
+            const float4 s1 = *reinterpret_cast<const float4*>(p.res_scale + (long long)g * p.N + col + 4);
+            const float4 h0 = *reinterpret_cast<const float4*>(p.res_shift + (long long)g * p.N + col);
+            const float4 h1 = *reinterpret_cast<const float4*>(p.res_shift + (long long)g * p.N + col + 4);
+            rs[0] = s0.x, rs[1] = s0.y, rs[2] = s0.z, rs[3] = s0.w, rs[4] = s1.x, rs[5] = s1.y, rs[6] = s1.z, rs[7] = s1.w;
+            rh[0] = h0.x, rh[1] = h0.y, rh[2] = h0.z, rh[3] = h0.w, rh[4] = h1.x, rh[5] = h1.y, rh[6] = h1.z, rh[7] = h1.w;
+          }
 #pragma unroll
           for (int it = 0; it < NIT; ++it) {
             const long long row = m0 + srow + it * RSTEP;
@@ -265,8 +278,13 @@ __global__ __launch_bounds__(256, 3) void conv1x1_bn_kernel(ConvBnParams p) {
               const unsigned rw[4] = {r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
-                float a0 = __uint_as_float(vv[j] << 16) + __uint_as_float(rw[j] << 16);
-                float a1 = __uint_as_float(vv[j] & 0xffff0000u) + __uint_as_float(rw[j] & 0xffff0000u);
+                float r0 = __uint_as_float(rw[j] << 16), r1 = __uint_as_float(rw[j] & 0xffff0000u);
+                if constexpr (RA) {
+                  r0 = r0 * rs[2 * j] + rh[2 * j];
+                  r1 = r1 * rs[2 * j + 1] + rh[2 * j + 1];
+                }
+                float a0 = __uint_as_float(vv[j] << 16) + r0;
+                float a1 = __uint_as_float(vv[j] & 0xffff0000u) + r1;
                 if (p.relu) {
                   a0 = fmaxf(a0, 0.f);
                   a1 = fmaxf(a1, 0.f);
@@ -320,7 +338,8 @@ static int conv1x1_bn_launch(const char* who, const void* d_x, int64_t lin_strid
                              int n, int64_t rows_per_group, int groups, const float* d_gamma, const float* d_beta,
                              float eps, const void* d_residual, int64_t ldr, int relu, void* d_y, int64_t ldc,
                              const float* d_in_scale, const float* d_in_shift, const float* d_pre_scale,
-                             const float* d_pre_shift, avs_stream_t stream) {
+                             const float* d_pre_shift, const float* d_res_scale, const float* d_res_shift,
+                             avs_stream_t stream) {
   AVS_REQUIRE(k > 0 && n > 0 && groups >= 0 && rows_per_group > 0 && rows_per_group < (1ll << 30), AVS_E_SHAPE,
               "%s: k=%d n=%d groups=%d rows_per_group=%lld", who, k, n, groups, (long long)rows_per_group);
   if (groups == 0) return AVS_OK;
@@ -332,6 +351,13 @@ static int conv1x1_bn_launch(const char* who, const void* d_x, int64_t lin_strid
               AVS_E_SHAPE, "%s: k, n and every stride must be multiples of 8 elements (16 bytes)", who);
   AVS_REQUIRE(avs_aligned16(d_x) && avs_aligned16(d_w) && avs_aligned16(d_y) && avs_aligned16(d_residual),
               AVS_E_ALIGN, "%s: operands must be 16-byte aligned", who);
+  const bool ra = d_res_scale != nullptr;
+  if (ra) {
+    AVS_REQUIRE(pre && d_residual && d_res_shift, AVS_E_ARG,
+                "%s: a residual affine needs the residual, its shift and the one-pass form", who);
+    AVS_REQUIRE(avs_aligned16(d_res_scale) && avs_aligned16(d_res_shift), AVS_E_ALIGN,
+                "%s: residual scale / shift must be 16-byte aligned", who);
+  }
   const bool xf = d_in_scale != nullptr;
   if (xf) {
     AVS_REQUIRE(d_in_shift, AVS_E_ARG, "%s: null input shift", who);
@@ -360,6 +386,8 @@ static int conv1x1_bn_launch(const char* who, const void* d_x, int64_t lin_strid
   p.in_shift = d_in_shift;
   p.pre_scale = d_pre_scale;
   p.pre_shift = d_pre_shift;
+  p.res_scale = d_res_scale;
+  p.res_shift = d_res_shift;
   const bool narrow = n <= 64 || g_convbn_narrow;
   const int bn = narrow ? 64 : 128;
   p.tiles_n = (n + bn - 1) / bn;
@@ -368,7 +396,14 @@ static int conv1x1_bn_launch(const char* who, const void* d_x, int64_t lin_strid
   const dim3 grid((unsigned)total), block(256);
   hipStream_t st = (hipStream_t)stream;
 #define AVS_CONVBN_LAUNCH(BN_, XF_, PRE_) hipLaunchKernelGGL((conv1x1_bn_kernel<BN_, XF_, PRE_>), grid, block, 0, st, p)
-  if (pre) {
+  if (ra) {
+#define AVS_CONVBN_LAUNCH_RA(BN_, XF_) hipLaunchKernelGGL((conv1x1_bn_kernel<BN_, XF_, true, true>), grid, block, 0, st, p)
+    if (narrow && xf) AVS_CONVBN_LAUNCH_RA(64, true);
+    else if (narrow) AVS_CONVBN_LAUNCH_RA(64, false);
+    else if (xf) AVS_CONVBN_LAUNCH_RA(128, true);
+    else AVS_CONVBN_LAUNCH_RA(128, false);
+#undef AVS_CONVBN_LAUNCH_RA
+  } else if (pre) {
     if (narrow && xf) AVS_CONVBN_LAUNCH(64, true, true);
     else if (narrow) AVS_CONVBN_LAUNCH(64, false, true);
     else if (xf) AVS_CONVBN_LAUNCH(128, true, true);
@@ -389,7 +424,8 @@ extern "C" int avs_conv1x1_bn_bf16(const void* d_x, int64_t lin_stride, int k, c
                                    float eps, const void* d_residual, int64_t ldr, int relu, void* d_y, int64_t ldc,
                                    avs_stream_t stream) {
   return conv1x1_bn_launch("avs_conv1x1_bn_bf16", d_x, lin_stride, k, d_w, ldb, n, rows_per_group, groups, d_gamma,
-                           d_beta, eps, d_residual, ldr, relu, d_y, ldc, nullptr, nullptr, nullptr, nullptr, stream);
+                           d_beta, eps, d_residual, ldr, relu, d_y, ldc, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           nullptr, stream);
 }
 
 extern "C" int avs_conv1x1_bn_in_bf16(const void* d_x, int64_t lin_stride, int k, const float* d_in_scale,
@@ -400,18 +436,21 @@ extern "C" int avs_conv1x1_bn_in_bf16(const void* d_x, int64_t lin_stride, int k
   AVS_REQUIRE(d_in_scale && d_in_shift, AVS_E_ARG, "avs_conv1x1_bn_in_bf16: null input scale / shift");
   return conv1x1_bn_launch("avs_conv1x1_bn_in_bf16", d_x, lin_stride, k, d_w, ldb, n, rows_per_group, groups, d_gamma,
                            d_beta, eps, d_residual, ldr, relu, d_y, ldc, d_in_scale, d_in_shift, nullptr, nullptr,
-                           stream);
+                           nullptr, nullptr, stream);
 }
 
 extern "C" int avs_conv1x1_affine_bf16(const void* d_x, int64_t lin_stride, int k, const float* d_in_scale,
                                        const float* d_in_shift, const void* d_w, int64_t ldb, int n,
                                        int64_t rows_per_group, int groups, const float* d_scale, const float* d_shift,
-                                       const void* d_residual, int64_t ldr, int relu, void* d_y, int64_t ldc,
+                                       const void* d_residual, int64_t ldr, const float* d_res_scale,
+                                       const float* d_res_shift, int relu, void* d_y, int64_t ldc,
                                        avs_stream_t stream) {
   AVS_REQUIRE(d_scale && d_shift, AVS_E_ARG, "avs_conv1x1_affine_bf16: null output scale / shift");
+  AVS_REQUIRE((d_res_scale == nullptr) == (d_res_shift == nullptr), AVS_E_ARG,
+              "avs_conv1x1_affine_bf16: residual scale and shift go together");
   return conv1x1_bn_launch("avs_conv1x1_affine_bf16", d_x, lin_stride, k, d_w, ldb, n, rows_per_group, groups, nullptr,
                            nullptr, 0.f, d_residual, ldr, relu, d_y, ldc, d_in_scale, d_in_shift, d_scale, d_shift,
-                           stream);
+                           d_res_scale, d_res_shift, stream);
 }
 
 // ============================================================================================================

@@ -312,10 +312,12 @@ def bn_gram_affine(x2d, wt, rows_per_group, gamma, beta, eps, in_affine=None):
     return scale, shift
 
 
-def conv1x1_affine(x2d, wt, rows_per_group, scale, shift, out2d, residual=None, relu=True, in_affine=None):
+def conv1x1_affine(x2d, wt, rows_per_group, scale, shift, out2d, residual=None, relu=True, in_affine=None,
+                   res_affine=None):
     """out = act((a . wt^T) * scale[g] + shift[g] + residual), bf16, one streaming pass (avs_conv1x1_affine_bf16):
     scale / shift fp32 [groups, N] contiguous (a BatchNorm already folded, e.g. by bn_gram_affine); a = x2d or
-    bf16(relu(x2d * isc + ish)) with in_affine = (isc, ish) fp32 [groups, K]."""
+    bf16(relu(x2d * isc + ish)) with in_affine = (isc, ish) fp32 [groups, K]; res_affine = (rsc, rsh) fp32
+    [groups, N]: the residual is a raw convolution output, added as residual * rsc + rsh."""
     _dev(x2d, wt, out2d, residual, scale, shift)
     _rowmajor2d(x2d, "x")
     _rowmajor2d(wt, "w")
@@ -337,22 +339,32 @@ def conv1x1_affine(x2d, wt, rows_per_group, scale, shift, out2d, residual=None, 
         _dev(isc, ish)
         if isc.shape != (groups, k) or ish.shape != (groups, k) or not isc.is_contiguous() or not ish.is_contiguous():
             raise ValueError("in_affine must be contiguous fp32 [groups, K]")
+    rsc, rsh = res_affine if res_affine is not None else (None, None)
+    if res_affine is not None:
+        _dev(rsc, rsh)
+        if residual is None:
+            raise ValueError("res_affine without a residual")
+        for a in (rsc, rsh):
+            if a.dtype != torch.float32 or a.shape != (groups, n) or not a.is_contiguous():
+                raise ValueError("res_affine must be contiguous fp32 [groups, N]")
     # algorithmic HBM bytes: read x, write y (+ read the residual)
     nbytes = 2.0 * rows * (k + n * (2 if residual is not None else 1))
     _timed("convbn", AVS_BF16, nbytes, lambda: check(
         lib().avs_conv1x1_affine_bf16(_p(x2d), x2d.stride(0), k, _p(isc), _p(ish), _p(wt), wt.stride(0), n,
                                       rows_per_group, groups, _p(scale), _p(shift), _p(residual),
-                                      residual.stride(0) if residual is not None else 0, 1 if relu else 0, _p(out2d),
-                                      out2d.stride(0), _stream()), "avs_conv1x1_affine_bf16"))
+                                      residual.stride(0) if residual is not None else 0, _p(rsc), _p(rsh),
+                                      1 if relu else 0, _p(out2d), out2d.stride(0), _stream()),
+        "avs_conv1x1_affine_bf16"))
     return out2d
 
 
-def conv1x1_gram_bn(x2d, wt, rows_per_group, gamma, beta, eps, out2d, residual=None, relu=True, in_affine=None):
+def conv1x1_gram_bn(x2d, wt, rows_per_group, gamma, beta, eps, out2d, residual=None, relu=True, in_affine=None,
+                    res_affine=None):
     """1x1 convolution + batch-statistics BatchNorm (+residual, +ReLU), bf16, same operands as conv1x1_bn, in ONE
     streaming pass over the output: the statistics come from the Gram matrix of the narrow input (bn_gram_affine),
     the convolution applies the folded affine in its epilogue (conv1x1_affine)."""
     scale, shift = bn_gram_affine(x2d, wt, rows_per_group, gamma, beta, eps, in_affine)
-    return conv1x1_affine(x2d, wt, rows_per_group, scale, shift, out2d, residual, relu, in_affine)
+    return conv1x1_affine(x2d, wt, rows_per_group, scale, shift, out2d, residual, relu, in_affine, res_affine)
 
 
 def conv2d(x, wt, kh, kw, stride, pad, out, bias=None, act=ACT_NONE, bnstats=None, split=False):

@@ -178,7 +178,11 @@ int avs_conv1x1_bn_in_bf16(const void* d_x, int64_t lin_stride, int k, const flo
  * avs_conv1x1_bn_in_bf16 (d_in_scale / d_in_shift = NULL: a is x itself; else a = bf16(relu(x * in_scale + in_shift)),
  * the previous layer's BatchNorm applied on the way in).  Replaces avs_conv1x1_bn[_in]_bf16 for k in {64, 128},
  * n % 32 == 0 (features/extractors.py:29,65: conv3 / downsample of the train-mode ResNet bottlenecks); other
- * shapes: AVS_E_UNSUPPORTED.  Statistics agree with the two-pass kernel's to fp32 rounding, not bit for bit.     */
+ * shapes: AVS_E_UNSUPPORTED.  Statistics agree with the two-pass kernel's to fp32 rounding, not bit for bit.
+ * d_res_scale / d_res_shift (both or neither; fp32 [groups, n]): the residual is itself a RAW convolution output
+ * (the downsample branch of a bottleneck, :29) whose BatchNorm is folded into the add,
+ *   y = act( conv(a) * scale + shift + residual * res_scale + res_shift ),
+ * so the downsample branch needs no apply pass of its own.                                                      */
 int avs_bn_gram_affine_bf16(const void* d_x, int64_t lin_stride, int k, const float* d_in_scale,
                             const float* d_in_shift, const void* d_w, int64_t ldb, int n, int64_t rows_per_group,
                             int groups, const float* d_gamma, const float* d_beta, float eps, float* d_scale,
@@ -186,7 +190,8 @@ int avs_bn_gram_affine_bf16(const void* d_x, int64_t lin_stride, int k, const fl
 int avs_conv1x1_affine_bf16(const void* d_x, int64_t lin_stride, int k, const float* d_in_scale,
                             const float* d_in_shift, const void* d_w, int64_t ldb, int n, int64_t rows_per_group,
                             int groups, const float* d_scale, const float* d_shift, const void* d_residual,
-                            int64_t ldr, int relu, void* d_y, int64_t ldc, avs_stream_t stream);
+                            int64_t ldr, const float* d_res_scale, const float* d_res_shift, int relu, void* d_y,
+                            int64_t ldc, avs_stream_t stream);
 
 /* Tuning knob: 1 = 64-channel slabs (4 workgroups per CU) in avs_conv1x1_bn_bf16 whatever n is.          */
 void avs_tune_convbn_narrow(int enabled);

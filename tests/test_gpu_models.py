@@ -348,6 +348,22 @@ def test_conv1x1_gram_statistics_and_streaming_pass(dev, rpg, k, n, with_res, xf
     got = out.float().cpu()
     scale = max(1.0, ref.abs().max().item())
     assert (got - ref).abs().max().item() < 0.03 * scale and (got - ref).abs().mean().item() < 0.004 * scale
+    if with_res:
+        # residual affine: the residual as a RAW convolution output whose BatchNorm is folded into the add, against
+        # the same kernel on the residual finished first by avs_bn_apply (one bf16 rounding more)
+        rsc, rsh = (torch.rand(groups, n, generator=g) + 0.5).to(dev), torch.randn(groups, n, generator=g).to(dev)
+        grows = torch.arange(0, rows + 1, rpg, dtype=torch.int64, device=dev)
+        rfin = ops.bn_apply(rd, rsc, rsh, grows, rpg, None, ops.ACT_NONE)
+        want = ops.conv1x1_gram_bn(xd, wd, rpg, gd, bd, 1e-5, torch.empty_like(out), rfin, True, in_aff).float()
+        gota = ops.conv1x1_gram_bn(xd, wd, rpg, gd, bd, 1e-5, torch.empty_like(out), rd, True, in_aff,
+                                   res_affine=(rsc, rsh)).float()
+        da = (gota - want).abs()
+        sa = max(1.0, want.abs().max().item())
+        assert da.max().item() < 0.02 * sa and (da > 0).float().mean().item() < 0.2
+        ref_a = torch.relu((yg * sc_ref[:, None, :] + sh_ref[:, None, :]).view(rows, n).float()
+                           + (res.float().view(groups, rpg, n) * rsc.cpu()[:, None, :] + rsh.cpu()[:, None, :]).view(rows, n))
+        assert (gota.cpu() - ref_a).abs().max().item() < 0.03 * sa
+        assert (gota.cpu() - ref_a).abs().mean().item() <= (want.cpu() - ref_a).abs().mean().item() * 1.05 + 1e-6
     two = torch.empty_like(out)
     ops.conv1x1_bn(xd, wd, rpg, gd, bd, 1e-5, two, rd, True, in_aff)
     # same products, affines equal to fp32 rounding: outputs differ by at most one bf16 step here and there
@@ -424,6 +440,7 @@ def test_resnet50_bf16_deferred_bn_apply_close(dev):
     frames = torch.from_numpy(_frames(8, 6)).to(dev)
     a = ResNet50Runner(trunk, torch.bfloat16)
     b = ResNet50Runner(trunk, torch.bfloat16)
+    a.defer_res_apply = False     # (folds the downsample's BatchNorm into conv3's add: one bf16 rounding less, not identical)
     b.defer_bn_apply = False
     fa, fb = a.forward(frames).cpu(), b.forward(frames).cpu()
     assert torch.equal(fa, fb)
@@ -434,7 +451,8 @@ def test_resnet50_bf16_raw_stem_path(dev, gsize):
     """Whole trunk with bn1 + ReLU of the stem applied inside the first block's conv1 / downsample (one shared Gram
     matrix) against the stem finished by its own pass: the downsample branch is the same arithmetic (bit-identical
     operands), conv1 changes form (Gram statistics + one pass instead of convolution + statistics + apply), so the
-    features agree to bf16 noise - and the path is deterministic."""
+    features agree to bf16 noise - and the path is deterministic.  The same for layer 2's downsample branch kept raw
+    with its BatchNorm folded into conv3's residual add (defer_res_apply)."""
     from avsum_amd.cnn import ResNet50Runner, resnet50_trunk
     torch.manual_seed(31)
     trunk = resnet50_trunk().to(dev)
@@ -444,7 +462,7 @@ def test_resnet50_bf16_raw_stem_path(dev, gsize):
     groups = list(range(0, 9, gsize))
     a = ResNet50Runner(trunk, torch.bfloat16)
     b = ResNet50Runner(trunk, torch.bfloat16)
-    b.stem_raw = False
+    b.stem_raw = b.defer_res_apply = False
     fa, fa2, fb = a.forward(frames, groups).cpu(), a.forward(frames, groups).cpu(), b.forward(frames, groups).cpu()
     assert torch.equal(fa, fa2)
     f32 = ResNet50Runner(trunk, torch.float32).forward(frames, groups).cpu()
