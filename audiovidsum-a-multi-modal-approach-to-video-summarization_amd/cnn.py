@@ -120,6 +120,8 @@ class ResNet50Runner:
                                      # one-pass form on ONE Gram matrix of the stem output): no finishing pass
         self.defer_bn_apply = True   # bn2 + ReLU applied inside conv3's two-pass kernel (avs_conv1x1_bn_in_bf16)
         self.defer_res_apply = True  # the downsample's BatchNorm applied inside conv3's residual add (layer 2's first block)
+        self.gram_finish_min_k = 128  # >= this many input channels: the Gram kernel stores the finished input in place, so
+                                      # the convolution pass (N / 128 column slabs) does not transform it per slab
         self._key = None
         self._w = None
         self._plans = {}     # (n, group frames) -> per layer: does it take the tile-local form
@@ -261,7 +263,8 @@ class ResNet50Runner:
             # statistics from the input's Gram matrix + ONE streaming pass where the shape allows it (the expanding
             # 1x1 layers of layers 1-2), else the two-pass kernel
             if self.gram_stats and ops.gram_supported(cin, cout):
-                ops.conv1x1_gram_bn(x.view(-1, cin), wt, gmax, gamma, beta, eps, y2d, residual, relu, in_affine, res_affine)
+                ops.conv1x1_gram_bn(x.view(-1, cin), wt, gmax, gamma, beta, eps, y2d, residual, relu, in_affine, res_affine,
+                                    finish_input=cin >= self.gram_finish_min_k)
             else:
                 assert res_affine is None
                 ops.conv1x1_bn(x.view(-1, cin), wt, gmax, gamma, beta, eps, y2d, residual, relu, in_affine)

@@ -479,7 +479,8 @@ struct GramParams {
   const float* beta;
   float* scale;
   float* shift;
-  long long lin_stride, ldb;
+  char* a_out;   // XF only, may be x itself: the transformed input a = bf16(relu(x * in_scale + in_shift)) is stored here
+  long long lin_stride, ldb, lda;
   int N, rows_per_group;
   float eps;
 };
@@ -552,6 +553,11 @@ __global__ __launch_bounds__(256, 2) void bn_gram_affine_kernel(GramParams p) {
           cs[2 * j + 1] += hi;
         }
         v = make_uint4(vv[0], vv[1], vv[2], vv[3]);
+        if constexpr (XF) {
+          // every chunk is read by exactly one thread before it is written: in place (a_out == x) is safe
+          if (p.a_out != nullptr)
+            *reinterpret_cast<uint4*>(p.a_out + ((g * R + row) * p.lda) * 2 + c * 16) = v;
+        }
       }
       *reinterpret_cast<uint4*>(lds + buf * TILE_BYTES + (r0t + RPT * q) * PITCH + c * 16) = v;
     }
@@ -705,7 +711,8 @@ __global__ __launch_bounds__(256, 2) void bn_gram_affine_kernel(GramParams p) {
 extern "C" int avs_bn_gram_affine_bf16(const void* d_x, int64_t lin_stride, int k, const float* d_in_scale,
                                        const float* d_in_shift, const void* d_w, int64_t ldb, int n,
                                        int64_t rows_per_group, int groups, const float* d_gamma, const float* d_beta,
-                                       float eps, float* d_scale, float* d_shift, avs_stream_t stream) {
+                                       float eps, float* d_scale, float* d_shift, void* d_a_out, int64_t lda,
+                                       avs_stream_t stream) {
   const char* who = "avs_bn_gram_affine_bf16";
   AVS_REQUIRE(k == 64 || k == 128, AVS_E_UNSUPPORTED, "%s: k = %d (built for 64 and 128 input channels)", who, k);
   AVS_REQUIRE(n > 0 && n % 32 == 0, AVS_E_UNSUPPORTED, "%s: n = %d must be a multiple of 32", who, n);
@@ -717,6 +724,12 @@ extern "C" int avs_bn_gram_affine_bf16(const void* d_x, int64_t lin_stride, int 
   AVS_REQUIRE(lin_stride % 8 == 0 && lin_stride >= k && ldb % 8 == 0 && ldb >= k, AVS_E_SHAPE,
               "%s: strides must be multiples of 8 elements (16 bytes) and at least k", who);
   AVS_REQUIRE(avs_aligned16(d_x) && avs_aligned16(d_w), AVS_E_ALIGN, "%s: x / w must be 16-byte aligned", who);
+  if (d_a_out != nullptr) {
+    AVS_REQUIRE(d_in_scale != nullptr, AVS_E_ARG, "%s: the transformed input is only stored with an input affine", who);
+    AVS_REQUIRE(lda % 8 == 0 && lda >= k && avs_aligned16(d_a_out), AVS_E_ALIGN,
+                "%s: a_out must be 16-byte aligned with a row stride that is a multiple of 8 elements and at least k", who);
+    AVS_REQUIRE(d_a_out != d_x || lda == lin_stride, AVS_E_ARG, "%s: in place needs lda == lin_stride", who);
+  }
   GramParams p{};
   p.x = (const char*)d_x;
   p.w = (const char*)d_w;
@@ -728,6 +741,8 @@ extern "C" int avs_bn_gram_affine_bf16(const void* d_x, int64_t lin_stride, int 
   p.shift = d_shift;
   p.lin_stride = lin_stride;
   p.ldb = ldb;
+  p.a_out = (char*)d_a_out;
+  p.lda = lda;
   p.N = n;
   p.rows_per_group = (int)rows_per_group;
   p.eps = eps;

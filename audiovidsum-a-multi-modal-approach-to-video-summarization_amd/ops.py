@@ -282,10 +282,11 @@ def gram_supported(k, n):
     return k in (64, 128) and n % 32 == 0
 
 
-def bn_gram_affine(x2d, wt, rows_per_group, gamma, beta, eps, in_affine=None):
+def bn_gram_affine(x2d, wt, rows_per_group, gamma, beta, eps, in_affine=None, store_input=False):
     """Folded BatchNorm affine (scale, shift) fp32 [groups, N] of y = a . wt^T per group of rows, computed from the
     Gram matrix of a WITHOUT forming y (avs_bn_gram_affine_bf16).  a = x2d, or bf16(relu(x2d * isc + ish)) with
-    in_affine = (isc, ish) fp32 [groups, K].  K in {64, 128}, N a multiple of 32."""
+    in_affine = (isc, ish) fp32 [groups, K].  K in {64, 128}, N a multiple of 32.
+    store_input (with in_affine): x2d is overwritten IN PLACE with a."""
     _dev(x2d, wt, gamma, beta)
     _rowmajor2d(x2d, "x")
     _rowmajor2d(wt, "w")
@@ -305,10 +306,13 @@ def bn_gram_affine(x2d, wt, rows_per_group, gamma, beta, eps, in_affine=None):
     scale = torch.empty((groups, n), dtype=torch.float32, device=x2d.device)
     shift = torch.empty((groups, n), dtype=torch.float32, device=x2d.device)
     # algorithmic HBM bytes: x read once
-    _timed("gram", AVS_BF16, 2.0 * rows * k, lambda: check(
+    if store_input and in_affine is None:
+        raise ValueError("store_input needs in_affine")
+    _timed("gram", AVS_BF16, 2.0 * rows * k * (2 if store_input else 1), lambda: check(
         lib().avs_bn_gram_affine_bf16(_p(x2d), x2d.stride(0), k, _p(isc), _p(ish), _p(wt), wt.stride(0), n,
                                       rows_per_group, groups, _p(gamma), _p(beta), float(eps), _p(scale), _p(shift),
-                                      _stream()), "avs_bn_gram_affine_bf16"))
+                                      _p(x2d) if store_input else None, x2d.stride(0), _stream()),
+        "avs_bn_gram_affine_bf16"))
     return scale, shift
 
 
@@ -359,11 +363,17 @@ def conv1x1_affine(x2d, wt, rows_per_group, scale, shift, out2d, residual=None, 
 
 
 def conv1x1_gram_bn(x2d, wt, rows_per_group, gamma, beta, eps, out2d, residual=None, relu=True, in_affine=None,
-                    res_affine=None):
+                    res_affine=None, finish_input=False):
     """1x1 convolution + batch-statistics BatchNorm (+residual, +ReLU), bf16, same operands as conv1x1_bn, in ONE
     streaming pass over the output: the statistics come from the Gram matrix of the narrow input (bn_gram_affine),
-    the convolution applies the folded affine in its epilogue (conv1x1_affine)."""
-    scale, shift = bn_gram_affine(x2d, wt, rows_per_group, gamma, beta, eps, in_affine)
+    the convolution applies the folded affine in its epilogue (conv1x1_affine).
+    finish_input (with in_affine): the statistics kernel overwrites x2d with the transformed input, and the convolution
+    pass reads it finished instead of transforming it once per column slab."""
+    if finish_input and in_affine is not None:
+        scale, shift = bn_gram_affine(x2d, wt, rows_per_group, gamma, beta, eps, in_affine, store_input=True)
+        in_affine = None
+    else:
+        scale, shift = bn_gram_affine(x2d, wt, rows_per_group, gamma, beta, eps, in_affine)
     return conv1x1_affine(x2d, wt, rows_per_group, scale, shift, out2d, residual, relu, in_affine, res_affine)
 
 

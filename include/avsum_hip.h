@@ -182,11 +182,14 @@ int avs_conv1x1_bn_in_bf16(const void* d_x, int64_t lin_stride, int k, const flo
  * d_res_scale / d_res_shift (both or neither; fp32 [groups, n]): the residual is itself a RAW convolution output
  * (the downsample branch of a bottleneck, :29) whose BatchNorm is folded into the add,
  *   y = act( conv(a) * scale + shift + residual * res_scale + res_shift ),
- * so the downsample branch needs no apply pass of its own.                                                      */
+ * so the downsample branch needs no apply pass of its own.
+ * d_a_out (avs_bn_gram_affine_bf16; NULL = off; needs d_in_scale): the transformed input a is also stored, bf16
+ * [rows, lda >= k] - d_a_out == d_x (lda == lin_stride) overwrites the raw input in place - so that the convolution
+ * pass can read a finished input (d_in_scale = NULL) instead of transforming it once per 128-column slab.         */
 int avs_bn_gram_affine_bf16(const void* d_x, int64_t lin_stride, int k, const float* d_in_scale,
                             const float* d_in_shift, const void* d_w, int64_t ldb, int n, int64_t rows_per_group,
                             int groups, const float* d_gamma, const float* d_beta, float eps, float* d_scale,
-                            float* d_shift, avs_stream_t stream);
+                            float* d_shift, void* d_a_out, int64_t lda, avs_stream_t stream);
 int avs_conv1x1_affine_bf16(const void* d_x, int64_t lin_stride, int k, const float* d_in_scale,
                             const float* d_in_shift, const void* d_w, int64_t ldb, int n, int64_t rows_per_group,
                             int groups, const float* d_scale, const float* d_shift, const void* d_residual,

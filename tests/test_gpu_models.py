@@ -348,6 +348,13 @@ def test_conv1x1_gram_statistics_and_streaming_pass(dev, rpg, k, n, with_res, xf
     got = out.float().cpu()
     scale = max(1.0, ref.abs().max().item())
     assert (got - ref).abs().max().item() < 0.03 * scale and (got - ref).abs().mean().item() < 0.004 * scale
+    if xf:
+        # finish_input: the statistics kernel overwrites the raw input with a = bf16(relu(x * isc + ish)) and the pass
+        # reads it finished - the same arithmetic, bit-identical output
+        xc = xd.clone()
+        out_f = ops.conv1x1_gram_bn(xc, wd, rpg, gd, bd, 1e-5, torch.empty_like(out), rd, True, in_aff, finish_input=True)
+        assert torch.equal(out_f, out)
+        assert torch.equal(xc.float().cpu(), a.bfloat16().float())
     if with_res:
         # residual affine: the residual as a RAW convolution output whose BatchNorm is folded into the add, against
         # the same kernel on the residual finished first by avs_bn_apply (one bf16 rounding more)

@@ -19,6 +19,7 @@ ap.add_argument("--n", type=int, default=8192)
 ap.add_argument("--gf", type=int, default=1)
 ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32split", "f32"])
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--set", action="append", default=[], help="runner attribute override, e.g. --set gram_finish_min_k=64")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -28,6 +29,9 @@ ext = VisualFeatureExtractor(dt, "batch", f32_split=args.dtype == "f32split").to
 runner = ext._resnet_runner if hasattr(ext, "_resnet_runner") else None
 if runner is None:
     runner = next(v for v in vars(ext).values() if isinstance(v, cnn.ResNet50Runner))
+for kv in args.set:
+    k, v = kv.split("=")
+    setattr(runner, k, type(getattr(runner, k))(int(v)))
 frames = torch.randint(0, 256, (args.n, 224, 224, 3), dtype=torch.uint8, device=dev)
 gf = torch.arange(0, args.n + 1, args.gf, dtype=torch.int64)
 
