@@ -70,6 +70,7 @@ _SIGNATURES = {
     "avs_tune_fast_staging": (None, [c_int]),
     "avs_tune_tall_tiles": (None, [c_int, c_int64, c_int64]),
     "avs_tune_convbn_narrow": (None, [c_int]),
+    "avs_tune_lstm_resident": (None, [c_int]),
     "avs_gemm_nt": (c_int, [c_int, c_int, c_int, c_int, P, c_int64, c_int64, P, c_int64, c_int64, P, c_int64,
                             c_int64, P, c_int, c_int64, c_float, c_int, c_int, P]),
     "avs_frames_normalize_u8": (c_int, [c_int, P, c_int, c_int, c_int, c_float, POINTER(c_float), POINTER(c_float),

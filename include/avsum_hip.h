@@ -376,6 +376,10 @@ int avs_resample_f32(const float* d_x, int64_t t, int channels, const float* d_t
 int avs_lstm_f32(const float* d_xproj, const float* d_whh_t, int hidden, int ndir,
                  unsigned reverse_mask, const int64_t* d_seq_rows, int nseq,
                  float* d_out, int64_t ldo, int out_col0, avs_stream_t stream);
+/* Tuning knob: hidden = 256 keeps part of W_hh^T on chip for the whole sequence (1: 20 of a thread's 64 row-vectors in
+ * registers + 8 in LDS, default; 2: 16 + 8) instead of streaming all of it from L2 every step (0).  Same arithmetic in
+ * the same order: bit-identical outputs.                                                                          */
+void avs_tune_lstm_resident(int mode);
 
 /* Attention core of nn.MultiheadAttention fed [B,T,E] WITHOUT batch_first
  * (models/av_model.py:26,44): for every time-step t and head h,

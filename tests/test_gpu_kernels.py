@@ -427,6 +427,18 @@ def test_lstm_vs_oracle(dev):
         ops.lstm(xproj, whh_t, hid, 2, 0b10, seq, out, 4)
         assert (out[:, 4:].cpu() - ref).abs().max().item() < 2e-5
         assert out[:, :4].abs().max().item() == 0
+        if hid == 256:
+            # the scorer's size keeps part of W_hh^T in registers / LDS (default); the generic streaming kernel and the
+            # other resident split run the same fmaf chain in the same order: bit-identical
+            from avsum_amd import _abi
+            try:
+                for mode in (0, 2):
+                    _abi.lib().avs_tune_lstm_resident(mode)
+                    alt = torch.zeros_like(out)
+                    ops.lstm(xproj, whh_t, hid, 2, 0b10, seq, alt, 4)
+                    assert torch.equal(alt, out)
+            finally:
+                _abi.lib().avs_tune_lstm_resident(1)
 
 
 def test_softmax_score_head_mha(dev):
