@@ -42,6 +42,19 @@ __device__ __forceinline__ unsigned short avs_f32_to_bf16(float f) {
   return __builtin_bit_cast(unsigned short, b);
 }
 
+// two values -> packed bf16 (lo in bits 0..15): one v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned avs_pack_bf16x2(float lo, float hi) {
+  return (unsigned)avs_f32_to_bf16(lo) | ((unsigned)avs_f32_to_bf16(hi) << 16);
+}
+// ReLU on a packed bf16 pair: as signed 16-bit integers the negative values (and -0) are exactly the negative
+// integers, so max(x, 0) per half is relu, bit for bit what fmaxf(v, 0) before the rounding gives (the rounding is
+// monotone and keeps the sign): one v_pk_max_i16 for two values
+__device__ __forceinline__ unsigned avs_relu_bf16x2(unsigned v) {
+  typedef short avs_s16x2 __attribute__((ext_vector_type(2)));
+  const avs_s16x2 z = {0, 0};
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(avs_s16x2, v), z));
+}
+
 template <typename T> struct avs_elem;
 template <> struct avs_elem<float> {
   static __device__ __forceinline__ float load(const float* p) { return *p; }

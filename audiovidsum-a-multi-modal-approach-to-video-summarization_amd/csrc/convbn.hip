@@ -242,16 +242,19 @@ __global__ __launch_bounds__(256, 3) void conv1x1_bn_kernel(ConvBnParams p) {
         char* ct = reinterpret_cast<char*>(lds);
         char* cbase = ct + (wr * 64 + 4 * lh) * CT_PITCH + (wc * (BN / 2) + lr) * 2;
         const bool relu_now = p.relu && p.res == nullptr;
+        // two accumulator registers (rows r, r + 1 of one column) per conversion; ReLU on the packed pair
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
+            for (int e = 0; e < 16; e += 2) {
               const int roff = mt * 32 + (e & 3) + 8 * (e >> 2);
-              float v = fmaf(acc[mt][nt][e], scale[nt], shift[nt]);
-              if (relu_now) v = fmaxf(v, 0.f);
-              *reinterpret_cast<unsigned short*>(cbase + roff * CT_PITCH + nt * 64) = avs_f32_to_bf16(v);
+              unsigned pk = avs_pack_bf16x2(fmaf(acc[mt][nt][e], scale[nt], shift[nt]),
+                                            fmaf(acc[mt][nt][e + 1], scale[nt], shift[nt]));
+              if (relu_now) pk = avs_relu_bf16x2(pk);
+              *reinterpret_cast<unsigned short*>(cbase + roff * CT_PITCH + nt * 64) = (unsigned short)pk;
+              *reinterpret_cast<unsigned short*>(cbase + (roff + 1) * CT_PITCH + nt * 64) = (unsigned short)(pk >> 16);
             }
         __syncthreads();
         const int srow = t / CPRW, sch = t - srow * CPRW;
@@ -283,13 +286,10 @@ __global__ __launch_bounds__(256, 3) void conv1x1_bn_kernel(ConvBnParams p) {
                   r0 = r0 * rs[2 * j] + rh[2 * j];
                   r1 = r1 * rs[2 * j + 1] + rh[2 * j + 1];
                 }
-                float a0 = __uint_as_float(vv[j] << 16) + r0;
-                float a1 = __uint_as_float(vv[j] & 0xffff0000u) + r1;
-                if (p.relu) {
-                  a0 = fmaxf(a0, 0.f);
-                  a1 = fmaxf(a1, 0.f);
-                }
-                vv[j] = (unsigned)avs_f32_to_bf16(a0) | ((unsigned)avs_f32_to_bf16(a1) << 16);
+                const float a0 = __uint_as_float(vv[j] << 16) + r0;
+                const float a1 = __uint_as_float(vv[j] & 0xffff0000u) + r1;
+                vv[j] = avs_pack_bf16x2(a0, a1);
+                if (p.relu) vv[j] = avs_relu_bf16x2(vv[j]);
               }
               v = make_uint4(vv[0], vv[1], vv[2], vv[3]);
             }

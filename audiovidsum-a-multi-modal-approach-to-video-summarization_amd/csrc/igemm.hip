@@ -802,11 +802,12 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
+            for (int e = 0; e < 16; e += 2) {   // rows r, r + 1 of one column: one conversion, ReLU on the packed pair
               const int roff = mt * 32 + (e & 3) + 8 * (e >> 2);
-              float v = fmaf(acc[mt][nt][e], sc, sf);
-              if (relu_now) v = fmaxf(v, 0.f);
-              *reinterpret_cast<unsigned short*>(cbase + roff * CT_PITCH + nt * 64) = avs_f32_to_bf16(v);
+              unsigned pk = avs_pack_bf16x2(fmaf(acc[mt][nt][e], sc, sf), fmaf(acc[mt][nt][e + 1], sc, sf));
+              if (relu_now) pk = avs_relu_bf16x2(pk);
+              *reinterpret_cast<unsigned short*>(cbase + roff * CT_PITCH + nt * 64) = (unsigned short)pk;
+              *reinterpret_cast<unsigned short*>(cbase + (roff + 1) * CT_PITCH + nt * 64) = (unsigned short)(pk >> 16);
             }
         }
       } else {
@@ -822,14 +823,21 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
+            for (int e = 0; e < 16; e += 2) {
+              float v2[2];
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                const int roff = mt * 32 + ((e + h) & 3) + 8 * ((e + h) >> 2);
+                const bool g1 = roff >= b1, g2 = roff >= b2;
+                const float sc = g2 ? sc2 : (g1 ? sc1 : sc0);
+                const float sf = g2 ? sf2 : (g1 ? sf1 : sf0);
+                v2[h] = fmaf(acc[mt][nt][e + h], sc, sf);
+              }
               const int roff = mt * 32 + (e & 3) + 8 * (e >> 2);
-              const bool g1 = roff >= b1, g2 = roff >= b2;
-              const float sc = g2 ? sc2 : (g1 ? sc1 : sc0);
-              const float sf = g2 ? sf2 : (g1 ? sf1 : sf0);
-              float v = fmaf(acc[mt][nt][e], sc, sf);
-              if (relu_now) v = fmaxf(v, 0.f);
-              *reinterpret_cast<unsigned short*>(cbase + roff * CT_PITCH + nt * 64) = avs_f32_to_bf16(v);
+              unsigned pk = avs_pack_bf16x2(v2[0], v2[1]);
+              if (relu_now) pk = avs_relu_bf16x2(pk);
+              *reinterpret_cast<unsigned short*>(cbase + roff * CT_PITCH + nt * 64) = (unsigned short)pk;
+              *reinterpret_cast<unsigned short*>(cbase + (roff + 1) * CT_PITCH + nt * 64) = (unsigned short)(pk >> 16);
             }
         }
       }
@@ -863,13 +871,10 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
             const unsigned rv[4] = {r4[it].x, r4[it].y, r4[it].z, r4[it].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              float lo = __uint_as_float(vv[j] << 16) + __uint_as_float(rv[j] << 16);
-              float hi = __uint_as_float(vv[j] & 0xffff0000u) + __uint_as_float(rv[j] & 0xffff0000u);
-              if (relu_res) {
-                lo = fmaxf(lo, 0.f);
-                hi = fmaxf(hi, 0.f);
-              }
-              vv[j] = (unsigned)avs_f32_to_bf16(lo) | ((unsigned)avs_f32_to_bf16(hi) << 16);
+              const float lo = __uint_as_float(vv[j] << 16) + __uint_as_float(rv[j] << 16);
+              const float hi = __uint_as_float(vv[j] & 0xffff0000u) + __uint_as_float(rv[j] & 0xffff0000u);
+              vv[j] = avs_pack_bf16x2(lo, hi);
+              if (relu_res) vv[j] = avs_relu_bf16x2(vv[j]);
             }
             v = make_uint4(vv[0], vv[1], vv[2], vv[3]);
           }
@@ -902,19 +907,29 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
             bcol = col < p.N ? bias[col] : 0.f;
           }
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
+          for (int e = 0; e < 16; e += 2) {   // rows r, r + 1 of one column: one conversion, ReLU on the packed pair
             const int roff = mt * 32 + (e & 3) + 8 * (e >> 2);
-            float v = acc[mt][nt][e];
-            if constexpr (EPI == EPI_ANY) {
-              v = fmaf(v, p.alpha, bcol);
-              if (p.bias_mode == AVS_BIAS_ROW) {
-                const int row = m0 + wr * 64 + 4 * lh + roff;
-                if (row < p.M) v += bias[row];
+            float v2[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              float v = acc[mt][nt][e + h];
+              if constexpr (EPI == EPI_ANY) {
+                v = fmaf(v, p.alpha, bcol);
+                if (p.bias_mode == AVS_BIAS_ROW) {
+                  const int row = m0 + wr * 64 + 4 * lh + roff + h;
+                  if (row < p.M) v += bias[row];
+                }
               }
-              if (p.act == AVS_ACT_RELU) v = fmaxf(v, 0.f);
+              if constexpr (EPI == EPI_BRELU) v = v + bcol;
+              v2[h] = v;
             }
-            if constexpr (EPI == EPI_BRELU) v = fmaxf(v + bcol, 0.f);
-            *reinterpret_cast<unsigned short*>(cbase + roff * CT_PITCH + nt * 64) = avs_f32_to_bf16(v);
+            unsigned pk = avs_pack_bf16x2(v2[0], v2[1]);
+            if constexpr (EPI == EPI_ANY) {
+              if (p.act == AVS_ACT_RELU) pk = avs_relu_bf16x2(pk);
+            }
+            if constexpr (EPI == EPI_BRELU) pk = avs_relu_bf16x2(pk);
+            *reinterpret_cast<unsigned short*>(cbase + roff * CT_PITCH + nt * 64) = (unsigned short)pk;
+            *reinterpret_cast<unsigned short*>(cbase + (roff + 1) * CT_PITCH + nt * 64) = (unsigned short)(pk >> 16);
           }
         }
     }
