@@ -22,6 +22,8 @@ shapes = [  # name, hw, cin, cout, k, stride
     ("l2.b0.conv2 3x3/2 128->128", 56, 128, 128, 3, 2),
     ("l2.down 1x1/2 256->512", 56, 256, 512, 1, 2),
     ("l3.conv2 3x3 256->256", 14, 256, 256, 3, 1),
+    ("l3.conv1 1x1 1024->256", 14, 1024, 256, 1, 1),
+    ("l3.conv3 1x1 256->1024", 14, 256, 1024, 1, 1),
 ]
 n = args.n
 for name, hw, cin, cout, k, s in shapes:
