@@ -63,6 +63,9 @@ class FrameScoringPipeline:
         self.use_inception = use_inception
         self.chunk_frames = int(chunk_frames)
         self.frames_per_group = int(frames_per_group)
+        # frames in pinned host memory: the first pass's upload has no computation to hide behind, so the first pass is
+        # a short one (its upload is the only exposed copy of the step)
+        self.host_lead_frames = 4096
 
     def _group_offsets(self, video_offsets):
         """BatchNorm groups never straddle a video: per video, groups of frames_per_group (+ remainder)."""
@@ -126,6 +129,14 @@ class FrameScoringPipeline:
             lo, hi = where if contiguous else (0, len(where))
             # passes of equal size (a short last pass runs the same launches on a fraction of the chip's worth of
             # work): at most chunk_frames frames each, whole groups
+            lead = 0
+            if host and not passes and self.host_lead_frames > 0:
+                lead = max(gsz, self.host_lead_frames // gsz * gsz)
+                if lead * 2 >= hi - lo:
+                    lead = 0                       # too few frames for a lead pass to be worth a launch sequence
+            if lead:
+                passes.append((gsz, (lo, lo + lead) if contiguous else where[lo:lo + lead], contiguous))
+                lo += lead
             per_pass = self._pass_frames(hi - lo, self.chunk_frames, gsz)
             for a in range(lo, hi, per_pass):
                 b = min(a + per_pass, hi)

@@ -161,6 +161,28 @@ def test_ragged_micro_batches_fp32(dev):
     assert torch.equal(got, want)
 
 
+def test_pinned_host_frames_are_uploaded_pass_by_pass(dev):
+    """Frames in pinned host memory (the PCIe-inclusive path): a short lead pass, then equal passes uploaded by the copy
+    stream while the previous one computes; fp32 features are bit-identical to the HBM-resident path for every pass
+    structure (every BatchNorm group is one frame here), host tensors that are not pinned are refused."""
+    from avsum_amd.features.extractors import VisualFeatureExtractor
+    from avsum_amd.pipeline import FrameScoringPipeline
+    torch.manual_seed(63)
+    ext = VisualFeatureExtractor(torch.float32, "batch").to(dev)
+    rng = np.random.default_rng(7)
+    host = torch.from_numpy(rng.integers(0, 256, (23, 224, 224, 3), dtype=np.uint8))
+    offsets = [0, 9, 23]
+    want = FrameScoringPipeline(ext, None, use_inception=False, chunk_frames=64).embed(host.to(dev), offsets)
+    pipe = FrameScoringPipeline(ext, None, use_inception=False, chunk_frames=8)
+    pipe.host_lead_frames = 3                       # passes of 3 | 7 | 7 | 6 frames
+    got = pipe.embed(host.pin_memory(), offsets)
+    assert got.is_cuda and torch.equal(got, want)
+    pipe.host_lead_frames = 0                       # no lead pass: 8 | 8 | 7
+    assert torch.equal(pipe.embed(host.pin_memory(), offsets), want)
+    with pytest.raises(ValueError, match="pinned"):
+        pipe.embed(host, offsets)
+
+
 def test_bf16_batch_invariance(dev):
     """Same property in the bf16 throughput mode.  Every BatchNorm form is deterministic and per-group, but the
     chunking decides which FORM a layer takes (a 3-frame pass and a 9-frame pass tile differently), so two chunkings
