@@ -189,6 +189,10 @@ __global__ __launch_bounds__(256, 3) void conv1x1_bn_kernel(ConvBnParams p) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+      // a group's last tile is usually short (784 rows = 6 tiles + 16 rows): 32-row blocks of this wave that lie past the
+      // group's end (wave-uniform) skip their fragment reads, matrix work and conversion - their rows were staged as
+      // zeros, are never stored and add nothing to the statistics
+      const int live = PRE ? (int)(m_hi - m0) - wr * 64 : 64;   // rows of this wave's 64 that exist (one-pass form only)
       stage(0);
       transform(0, 0);
       __syncthreads();
@@ -197,30 +201,36 @@ __global__ __launch_bounds__(256, 3) void conv1x1_bn_kernel(ConvBnParams p) {
         const uint4* abuf = lds + buf * BUF;
         const uint4* bbuf = abuf + A_ROWS * CPRR;
         uint4 fa[KS][2], fb[KS][NT];
+        if (live > 0) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const int chunk = 2 * ks + lh;
+          for (int ks = 0; ks < KS; ++ks) {
+            const int chunk = 2 * ks + lh;
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt) {
-            const int row = wr * 64 + mt * 32 + lr;
-            fa[ks][mt] = abuf[row * CPRR + (chunk ^ ((row >> SH) & (CPRR - 1)))];
-          }
+            for (int mt = 0; mt < 2; ++mt) {
+              const int row = wr * 64 + mt * 32 + lr;
+              if (mt == 0 || live > 32) fa[ks][mt] = abuf[row * CPRR + (chunk ^ ((row >> SH) & (CPRR - 1)))];
+            }
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            const int row = wc * (BN / 2) + nt * 32 + lr;
-            fb[ks][nt] = bbuf[row * CPRR + (chunk ^ ((row >> SH) & (CPRR - 1)))];
+            for (int nt = 0; nt < NT; ++nt) {
+              const int row = wc * (BN / 2) + nt * 32 + lr;
+              fb[ks][nt] = bbuf[row * CPRR + (chunk ^ ((row >> SH) & (CPRR - 1)))];
+            }
           }
         }
         if (s + 1 < steps) stage(buf ^ 1);
+        if (live > 0) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
+          for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < 2; ++mt)
+              if (mt == 0 || live > 32) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[ks][mt]),
-                                                                    __builtin_bit_cast(bf16x8, fb[ks][nt]),
-                                                                    acc[mt][nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt)
+                  acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[ks][mt]),
+                                                                        __builtin_bit_cast(bf16x8, fb[ks][nt]),
+                                                                        acc[mt][nt], 0, 0, 0);
+              }
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (s + 1 < steps) transform(buf ^ 1, (s + 1) * BKE);
         __syncthreads();
@@ -244,7 +254,8 @@ __global__ __launch_bounds__(256, 3) void conv1x1_bn_kernel(ConvBnParams p) {
         const bool relu_now = p.relu && p.res == nullptr;
         // two accumulator registers (rows r, r + 1 of one column) per conversion; ReLU on the packed pair
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt) {
+          if (live <= mt * 32) continue;   // no row of this 32-row block exists: nothing to convert (never stored)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -256,6 +267,7 @@ __global__ __launch_bounds__(256, 3) void conv1x1_bn_kernel(ConvBnParams p) {
               *reinterpret_cast<unsigned short*>(cbase + roff * CT_PITCH + nt * 64) = (unsigned short)pk;
               *reinterpret_cast<unsigned short*>(cbase + (roff + 1) * CT_PITCH + nt * 64) = (unsigned short)(pk >> 16);
             }
+        }
         __syncthreads();
         const int srow = t / CPRW, sch = t - srow * CPRW;
         const int col = n0 + sch * 8;
