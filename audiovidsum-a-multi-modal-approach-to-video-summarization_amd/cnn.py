@@ -113,6 +113,8 @@ class ResNet50Runner:
         self.f32_split = bool(f32_split) and dtype == torch.float32
         self.fuse_conv_bn = True
         self.fuse_min_rows, self.fuse_ratio_num, self.fuse_ratio_den = 128, 2, 1
+        self.twopass_max_cin = 128   # wider inputs (256 -> 1024 at 4-frame groups): the second matrix pass costs more than
+                                     # the split form's extra traffic (measured: 4.5 vs 3.4 ms per 8192 frames)
         self.bn_local = True         # the one-launch tile-local form where the library takes the shape
         self.gram_stats = True       # conv3 / downsample of layers 1-2: Gram-matrix statistics + one streaming pass
         self.fused_stem = True       # uint8 frames -> conv1 -> pooled raw map + partial sums in one kernel
@@ -203,7 +205,7 @@ class ResNet50Runner:
         # measured on MI355X: the two-pass kernel wins over the split form where the layer is write-heavy
         # (cout >= 2*cin: the conv3 / downsample layers) and a group is several row tiles long
         return (kh == 1 and sh == 1 and self.fuse_conv_bn and gmax >= self.fuse_min_rows
-                and cout * self.fuse_ratio_den >= cin * self.fuse_ratio_num)
+                and cout * self.fuse_ratio_den >= cin * self.fuse_ratio_num and cin <= self.twopass_max_cin)
 
     def _conv_bn(self, geom, xs, x, wt, bnp, groups, residual=None, relu=True, local=False, algo_k=None, pool=None,
                  defer=False, in_affine=None, res_affine=None):

@@ -225,13 +225,10 @@ extern "C" int avs_lstm_f32(const float* d_xproj, const float* d_whh_t, int hidd
 #define AVS_LSTM_RESIDENT(RK_, LK_, D_)                                                                              \
     {                                                                                                                \
       const size_t shm = ((size_t)256 + 4 * 1024) * sizeof(float) + (size_t)(LK_) * 1024 * sizeof(float4);           \
-      static bool attr_set = false;                                                                                  \
-      if (!attr_set) {                                                                                               \
-        AVS_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_h256_kernel<RK_, LK_, D_>),               \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess,         \
-                    AVS_E_HIP, "avs_lstm_f32: cannot reserve %zu bytes of LDS", shm);                                \
-        attr_set = true;                                                                                             \
-      }                                                                                                              \
+      /* per launch: the attribute belongs to the current device's copy of the kernel */                             \
+      AVS_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_h256_kernel<RK_, LK_, D_>),                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess,           \
+                  AVS_E_HIP, "avs_lstm_f32: cannot reserve %zu bytes of LDS", shm);                                  \
       hipLaunchKernelGGL((lstm_h256_kernel<RK_, LK_, D_>), dim3(nseq, ndir), dim3(1024), shm, (hipStream_t)stream,   \
                          d_xproj, d_whh_t, ndir, reverse_mask, d_seq_rows, d_out, (long long)ldo, out_col0);         \
     }
