@@ -79,8 +79,8 @@ _SIGNATURES = {
     "avs_bn_batch_stats": (c_int, [c_int, P, c_int64, c_int, c_int64, P, c_int, P, P, c_float, P, P, P]),
     "avs_bn_apply": (c_int, [c_int, P, c_int64, c_int, c_int64, P, c_int, c_int64, P, P, P, c_int64, c_int, P,
                              c_int64, P]),
-    "avs_pool2d_nhwc": (c_int, [c_int, c_int, P, c_int, c_int, c_int, c_int, c_int64, c_int, c_int, c_int, P, c_int,
-                                c_int, c_int64, P]),
+    "avs_pool2d_nhwc": (c_int, [c_int, c_int, P, c_int, c_int, c_int, c_int, c_int64, c_int, c_int, c_int, P, c_int, P,
+                                c_int, c_int, c_int64, P]),
     "avs_bn_maxpool_nhwc": (c_int, [c_int, P, c_int, c_int, c_int, c_int, c_int64, P, c_int, P, P, c_int, c_int, c_int,
                                     c_int, P, c_int, c_int, c_int64, P]),
     "avs_global_avgpool_nhwc": (c_int, [c_int, P, c_int, c_int, c_int, P, c_int64, P]),

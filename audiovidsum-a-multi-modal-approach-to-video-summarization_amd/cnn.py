@@ -523,6 +523,7 @@ class InceptionV3Runner:
     def __init__(self, net, dtype=torch.float32, f32_split=False):
         self.net, self.dtype = net, dtype
         self.f32_split = bool(f32_split) and dtype == torch.float32
+        self.pool_after_conv = True   # branch_pool: 1x1 convolution first, average pooling on its (narrow) output
         self._key = None
         self._w = None
 
@@ -560,6 +561,18 @@ class InceptionV3Runner:
         return ops.conv2d(x, c["w"], c["kh"], c["kw"], c["s"], (c["ph"], c["pw"]), out, c["b"], ops.ACT_RELU,
                           split=self.f32_split)
 
+    def _pool_branch(self, w, name, x, out):
+        """branch_pool = avg_pool2d(3, 1, 1) -> 1x1 conv -> folded BN -> ReLU, run as 1x1 conv (no bias) -> average ->
+        + bias -> ReLU: the two linear maps commute (count_include_pad's zero padding included), and the pooling pass
+        then moves cout (32-192) instead of cin (192-2048) channels."""
+        if not self.pool_after_conv:
+            return self._conv(w, name, self._pool(x, "avg", 3, 1, 1), out)
+        c = w[name]
+        n, h, ww, _ = x.shape
+        z = torch.empty((n, h, ww, c["cout"]), dtype=self.dtype, device=x.device)
+        ops.conv2d(x, c["w"], 1, 1, 1, (0, 0), z, None, ops.ACT_NONE, split=self.f32_split)
+        return ops.pool2d(z, "avg", 3, 1, 1, out, c["b"], ops.ACT_RELU)
+
     def _pool(self, x, mode, k, s, p, out=None):
         n, h, ww, c = x.shape
         ho, wo = (h + 2 * p - k) // s + 1, (ww + 2 * p - k) // s + 1
@@ -583,7 +596,7 @@ class InceptionV3Runner:
         self._conv(w, p + ".branch5x5_2", self._conv(w, p + ".branch5x5_1", x), o5)
         t = self._conv(w, p + ".branch3x3dbl_2", self._conv(w, p + ".branch3x3dbl_1", x))
         self._conv(w, p + ".branch3x3dbl_3", t, o3)
-        self._conv(w, p + ".branch_pool", self._pool(x, "avg", 3, 1, 1), op)
+        self._pool_branch(w, p + ".branch_pool", x, op)
         return buf
 
     def _block_b(self, w, p, x):
@@ -603,7 +616,7 @@ class InceptionV3Runner:
         for i in (2, 3, 4):
             t = self._conv(w, f"{p}.branch7x7dbl_{i}", t)
         self._conv(w, p + ".branch7x7dbl_5", t, od)
-        self._conv(w, p + ".branch_pool", self._pool(x, "avg", 3, 1, 1), op)
+        self._pool_branch(w, p + ".branch_pool", x, op)
         return buf
 
     def _block_d(self, w, p, x):
@@ -625,7 +638,7 @@ class InceptionV3Runner:
         t = self._conv(w, p + ".branch3x3dbl_2", self._conv(w, p + ".branch3x3dbl_1", x))
         self._conv(w, p + ".branch3x3dbl_3a", t, oda)
         self._conv(w, p + ".branch3x3dbl_3b", t, odb)
-        self._conv(w, p + ".branch_pool", self._pool(x, "avg", 3, 1, 1), op)
+        self._pool_branch(w, p + ".branch_pool", x, op)
         return buf
 
     def forward(self, frames_u8, out=None):

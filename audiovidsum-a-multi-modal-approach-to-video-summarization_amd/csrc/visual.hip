@@ -372,8 +372,8 @@ extern "C" int avs_bn_apply(int dtype, const void* d_x, int64_t rows, int c, int
 // ---------------------------------------------------------------------------
 template <typename T, int V>
 __global__ __launch_bounds__(256) void pool2d_kernel(int mode, const T* __restrict__ x, int n, int h, int w, int c,
-                                                     long long xps, int k, int s, int p, T* __restrict__ y, int ho,
-                                                     int wo, long long yps) {
+                                                     long long xps, int k, int s, int p, const float* __restrict__ bias,
+                                                     int relu, T* __restrict__ y, int ho, int wo, long long yps) {
   const int cv = c / V;
   const long long total = (long long)n * ho * wo * cv;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -404,14 +404,24 @@ __global__ __launch_bounds__(256) void pool2d_kernel(int mode, const T* __restri
 #pragma unroll
       for (int j = 0; j < V; ++j) a[j] = a[j] / d;
     }
+    if (bias != nullptr) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) a[j] += bias[ch + j];
+    }
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) a[j] = fmaxf(a[j], 0.f);
+    }
     storev<T, V>(y + ((img * ho + oy) * (long long)wo + ox) * yps + ch, a);
   }
 }
 
 extern "C" int avs_pool2d_nhwc(int dtype, int mode, const void* d_x, int n, int h, int w, int c, int64_t x_px_stride,
-                               int k, int s, int p, void* d_y, int ho, int wo, int64_t y_px_stride,
-                               avs_stream_t stream) {
+                               int k, int s, int p, const float* d_bias, int act, void* d_y, int ho, int wo,
+                               int64_t y_px_stride, avs_stream_t stream) {
   AVS_REQUIRE(dtype == AVS_F32 || dtype == AVS_BF16, AVS_E_ARG, "avs_pool2d_nhwc: bad dtype");
+  AVS_REQUIRE(act == AVS_ACT_NONE || act == AVS_ACT_RELU, AVS_E_ARG, "avs_pool2d_nhwc: bad activation %d", act);
+  const int relu = act == AVS_ACT_RELU;
   AVS_REQUIRE(mode == 0 || mode == 1, AVS_E_ARG, "avs_pool2d_nhwc: bad mode");
   AVS_REQUIRE(n >= 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0 && k > 0 && s > 0 && p >= 0 && p < k && ho > 0 &&
                   wo > 0 && x_px_stride >= c && x_px_stride % 4 == 0 && y_px_stride >= c && y_px_stride % 4 == 0,
@@ -426,16 +436,16 @@ extern "C" int avs_pool2d_nhwc(int dtype, int mode, const void* d_x, int n, int 
   if (gx > 65536) gx = 65536;
   if (dtype == AVS_F32)
     hipLaunchKernelGGL((pool2d_kernel<float, 4>), dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, mode,
-                       (const float*)d_x, n, h, w, c, (long long)x_px_stride, k, s, p, (float*)d_y, ho, wo,
-                       (long long)y_px_stride);
+                       (const float*)d_x, n, h, w, c, (long long)x_px_stride, k, s, p, d_bias, relu, (float*)d_y, ho,
+                       wo, (long long)y_px_stride);
   else if (wide)
     hipLaunchKernelGGL((pool2d_kernel<avs_bf16_tag, 8>), dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, mode,
-                       (const avs_bf16_tag*)d_x, n, h, w, c, (long long)x_px_stride, k, s, p, (avs_bf16_tag*)d_y, ho,
-                       wo, (long long)y_px_stride);
+                       (const avs_bf16_tag*)d_x, n, h, w, c, (long long)x_px_stride, k, s, p, d_bias, relu,
+                       (avs_bf16_tag*)d_y, ho, wo, (long long)y_px_stride);
   else
     hipLaunchKernelGGL((pool2d_kernel<avs_bf16_tag, 4>), dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, mode,
-                       (const avs_bf16_tag*)d_x, n, h, w, c, (long long)x_px_stride, k, s, p, (avs_bf16_tag*)d_y, ho,
-                       wo, (long long)y_px_stride);
+                       (const avs_bf16_tag*)d_x, n, h, w, c, (long long)x_px_stride, k, s, p, d_bias, relu,
+                       (avs_bf16_tag*)d_y, ho, wo, (long long)y_px_stride);
   AVS_CHECK_LAUNCH("avs_pool2d_nhwc");
   return AVS_OK;
 }

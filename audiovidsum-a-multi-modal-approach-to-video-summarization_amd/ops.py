@@ -496,12 +496,17 @@ def bn_apply(x2d, scale, shift, group_rows=None, max_group_rows=0, residual=None
     return out
 
 
-def pool2d(x, mode, k, s, p, out):
-    """x, out: NHWC views (unit channel stride, dense pixels).  mode 'max' | 'avg'."""
+def pool2d(x, mode, k, s, p, out, bias=None, act=ACT_NONE):
+    """x, out: NHWC views (unit channel stride, dense pixels).  mode 'max' | 'avg'.  out = act(pool(x) + bias) with an
+    optional fp32 per-channel bias."""
     n, h, w, c = x.shape
     _, ho, wo, _ = out.shape
+    if bias is not None:
+        _f32(bias, "bias")
+        if bias.numel() != c or not bias.is_contiguous():
+            raise ValueError("pool2d: bias must be contiguous fp32 [c]")
     check(lib().avs_pool2d_nhwc(dtype_code(x.dtype), 0 if mode == "max" else 1, _p(x), n, h, w, c, x.stride(2), k, s,
-                                p, _p(out), ho, wo, out.stride(2), _stream()), "avs_pool2d_nhwc")
+                                p, _p(bias), int(act), _p(out), ho, wo, out.stride(2), _stream()), "avs_pool2d_nhwc")
     return out
 
 

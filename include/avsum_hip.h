@@ -270,10 +270,15 @@ int avs_bn_apply(int dtype, const void* d_x, int64_t rows, int c, int64_t ldx,
 
 /* 2-D pooling on NHWC.  mode 0 = max (padding = -inf), 1 = average with
  * count_include_pad (torch defaults).  ResNet maxpool 3x3/2 p1, Inception
- * max 3x3/2 p0 and avg 3x3/1 p1.  y may be a channel slice (y_px_stride).   */
+ * max 3x3/2 p0 and avg 3x3/1 p1.  y may be a channel slice (y_px_stride).
+ * d_bias (fp32 [c], may be NULL) and act (AVS_ACT_NONE / AVS_ACT_RELU) are applied after the pooling:
+ * y = act(pool(x) + bias).  Inception's branch_pool (avg_pool2d 3x3/1 -> 1x1 conv -> folded BN -> ReLU,
+ * torchvision inception.py as loaded at features/extractors.py:26) runs as 1x1 conv WITHOUT bias -> this call:
+ * averaging and a 1x1 convolution commute (both linear; the zero padding of count_include_pad commutes too), and the
+ * pooling then moves cout instead of cin channels (4-10x fewer).                                                   */
 int avs_pool2d_nhwc(int dtype, int mode, const void* d_x, int n, int h, int w, int c,
-                    int64_t x_px_stride, int k, int s, int p, void* d_y, int ho, int wo,
-                    int64_t y_px_stride, avs_stream_t stream);
+                    int64_t x_px_stride, int k, int s, int p, const float* d_bias, int act, void* d_y,
+                    int ho, int wo, int64_t y_px_stride, avs_stream_t stream);
 
 /* BatchNorm apply + ReLU + max pooling in one pass: y = maxpool_{k,s,p}( act( x*scale[g] + shift[g] ) ), g = the
  * group (d_group_rows ranges over INPUT rows, as in avs_bn_apply; groups == 0 / NULL: one affine) of the image.

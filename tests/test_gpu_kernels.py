@@ -295,6 +295,13 @@ def test_pools_and_segment_mean(dev):
         out = torch.empty((2, ref.shape[2], ref.shape[3], 16), device=dev)
         ops.pool2d(xn, mode, k, s, p, out)
         assert (out.cpu().permute(0, 3, 1, 2) - ref).abs().max().item() < 1e-6
+    # act(pool(x) + bias) into a channel slice of a wider buffer (Inception's branch_pool after its 1x1 convolution)
+    bias = torch.randn(16, generator=g)
+    wide = torch.zeros((2, 15, 15, 40), device=dev)
+    ops.pool2d(xn, "avg", 3, 1, 1, wide[..., 8:24], bias.to(dev), ops.ACT_RELU)
+    ref = torch.relu(F.avg_pool2d(x, 3, 1, 1) + bias.view(1, -1, 1, 1))
+    assert (wide[..., 8:24].cpu().permute(0, 3, 1, 2) - ref).abs().max().item() < 1e-6
+    assert wide[..., :8].abs().max().item() == 0 and wide[..., 24:].abs().max().item() == 0
     gap = ops.global_avgpool(xn).cpu()
     assert (gap - x.mean((2, 3))).abs().max().item() < 1e-6
     feats = torch.randn(9, 32, generator=g)

@@ -691,9 +691,16 @@ def test_inception_v3_fp32(dev):
         ref = ocnn.inception_v3_forward(sd, torch.cat([ocnn.preprocess_inception(f) for f in frames]))
     from avsum_amd import ops
     big = ops.resize_bilinear(torch.from_numpy(frames).to(dev), 299, 299)
-    got = InceptionV3Runner(net.to(dev), torch.float32).forward(big).cpu()
+    runner = InceptionV3Runner(net.to(dev), torch.float32)
+    got = runner.forward(big).cpu()
     err = (got - ref).abs().max().item()
     assert err < 1e-4 * max(1.0, ref.abs().max().item()), err
+    # branch_pool in the reference's order (average, then 1x1 convolution) instead of convolution first: the same
+    # linear map, equal to fp32 reassociation
+    runner.pool_after_conv = False
+    lit = runner.forward(big).cpu()
+    assert (lit - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+    assert (lit - got).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
 def test_visual_extractor_api(dev):
