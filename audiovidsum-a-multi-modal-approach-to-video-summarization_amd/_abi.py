@@ -21,6 +21,7 @@ LIB_PATH = os.path.join(_PKG_DIR, "lib", "libavsum_hip_study.so" if STUDY else "
 HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "avsum_hip.h")
 
 AVS_F32, AVS_BF16, AVS_F32_ACC64, AVS_F32_SPLIT = 0, 1, 2, 3
+AVS_W_ROWS, AVS_W_KSTEP32 = 0, 1
 ACT_NONE, ACT_RELU = 0, 1
 BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
 E_UNSUPPORTED = -6
@@ -39,7 +40,7 @@ class ConvDesc(ctypes.Structure):
         ("ho", c_int), ("wo", c_int), ("cout", c_int),
         ("x_img_stride", c_int64), ("x_row_stride", c_int64), ("x_px_stride", c_int64),
         ("w_row_stride", c_int64), ("y_px_stride", c_int64),
-        ("act", c_int), ("alpha", c_float),
+        ("act", c_int), ("alpha", c_float), ("w_layout", c_int),
     ]
 
 

@@ -90,6 +90,21 @@ def _stem_weight(weight, px, dtype):
     return w.reshape(o, kh * px * 4).to(dtype).contiguous()
 
 
+class _W:
+    """A convolution weight in kernel layout: `rows` = [cout, kh*kw*cin] (what the 1x1 BatchNorm kernels and the stem
+    read) and, for bf16 with a reduction that is a multiple of 32, `kstep` = the same matrix reduction-step major
+    (ops.weights_kstep32: whole cache lines per weight DMA instruction of the contraction kernel)."""
+    __slots__ = ("rows", "kstep")
+
+    def __init__(self, rows):
+        self.rows = rows
+        self.kstep = ops.weights_kstep32(rows) if rows.dtype == torch.bfloat16 and rows.shape[1] % 32 == 0 else None
+
+    def conv_operand(self):
+        """(tensor, w_layout) for avs_conv2d_nhwc*."""
+        return (self.kstep, 1) if self.kstep is not None else (self.rows, 0)
+
+
 class ResNet50Runner:
     """Runs the container's parameters on uint8 frames [N,224,224,3] -> fp32 [N,2048].
 
@@ -134,7 +149,7 @@ class ResNet50Runner:
         if self._w is not None and key == self._key:
             return self._w
         t, dt = self.trunk, self.dtype
-        w = {"stem": _stem_weight(t[0].weight, 8, dt), "blocks": []}
+        w = {"stem": _W(_stem_weight(t[0].weight, 8, dt)), "blocks": []}
 
         def bn(m):
             return (m.weight.detach().float().contiguous(), m.bias.detach().float().contiguous(), float(m.eps),
@@ -143,19 +158,20 @@ class ResNet50Runner:
         w["bn1"] = bn(t[1])
         for li in range(4, 8):
             for blk in t[li]:
-                d = {"c1": _ohwi(blk.conv1.weight, dt), "b1": bn(blk.bn1), "c2": _ohwi(blk.conv2.weight, dt),
-                     "b2": bn(blk.bn2), "c3": _ohwi(blk.conv3.weight, dt), "b3": bn(blk.bn3),
+                d = {"c1": _W(_ohwi(blk.conv1.weight, dt)), "b1": bn(blk.bn1), "c2": _W(_ohwi(blk.conv2.weight, dt)),
+                     "b2": bn(blk.bn2), "c3": _W(_ohwi(blk.conv3.weight, dt)), "b3": bn(blk.bn3),
                      "stride": blk.stride, "planes": blk.conv1.out_channels}
                 if blk.downsample is not None:
-                    d["cd"] = _ohwi(blk.downsample[0].weight, dt)
+                    d["cd"] = _W(_ohwi(blk.downsample[0].weight, dt))
                     d["bd"] = bn(blk.downsample[1])
                 w["blocks"].append(d)
         # layer 1's first block: conv1 (64 -> 64) and the downsample (64 -> 256) read the same input, so ONE Gram matrix
         # gives the batch statistics of both: their weights / BatchNorm parameters stacked for avs_bn_gram_affine_bf16
         b0 = w["blocks"][0]
-        if "cd" in b0 and b0["c1"].shape[1] == b0["cd"].shape[1] and b0["b1"][2] == b0["bd"][2]:
-            w["cat0"] = (torch.cat([b0["c1"], b0["cd"]]).contiguous(), torch.cat([b0["b1"][0], b0["bd"][0]]).contiguous(),
-                         torch.cat([b0["b1"][1], b0["bd"][1]]).contiguous(), b0["b1"][2], b0["c1"].shape[0])
+        if "cd" in b0 and b0["c1"].rows.shape[1] == b0["cd"].rows.shape[1] and b0["b1"][2] == b0["bd"][2]:
+            w["cat0"] = (torch.cat([b0["c1"].rows, b0["cd"].rows]).contiguous(),
+                         torch.cat([b0["b1"][0], b0["bd"][0]]).contiguous(),
+                         torch.cat([b0["b1"][1], b0["bd"][1]]).contiguous(), b0["b1"][2], b0["c1"].rows.shape[0])
         self._w, self._key = w, key
         return w
 
@@ -226,8 +242,9 @@ class ResNet50Runner:
         y2d = y.view(-1, cout)
 
         def conv(**kw):
-            return ops.conv2d_raw(dcode, *geom, x, *xs, wt, wt.stride(0), y, cout, algo_k=algo_k,
-                                  algo_in_elems=x.numel() if algo_k is not None else None, **kw)
+            wsel, layout = wt.conv_operand()
+            return ops.conv2d_raw(dcode, *geom, x, *xs, wsel, wsel.stride(0), y, cout, algo_k=algo_k,
+                                  algo_in_elems=x.numel() if algo_k is not None else None, w_layout=layout, **kw)
 
         def pooled(t):
             k, s, p = pool
@@ -265,11 +282,11 @@ class ResNet50Runner:
             # statistics from the input's Gram matrix + ONE streaming pass where the shape allows it (the expanding
             # 1x1 layers of layers 1-2), else the two-pass kernel
             if self.gram_stats and ops.gram_supported(cin, cout):
-                ops.conv1x1_gram_bn(x.view(-1, cin), wt, gmax, gamma, beta, eps, y2d, residual, relu, in_affine, res_affine,
+                ops.conv1x1_gram_bn(x.view(-1, cin), wt.rows, gmax, gamma, beta, eps, y2d, residual, relu, in_affine, res_affine,
                                     finish_input=cin >= self.gram_finish_min_k)
             else:
                 assert res_affine is None
-                ops.conv1x1_bn(x.view(-1, cin), wt, gmax, gamma, beta, eps, y2d, residual, relu, in_affine)
+                ops.conv1x1_bn(x.view(-1, cin), wt.rows, gmax, gamma, beta, eps, y2d, residual, relu, in_affine)
             return y
         assert res_affine is None
         affine = None
@@ -322,7 +339,7 @@ class ResNet50Runner:
             gamma, beta, eps = w["bn1"][:3]
             raw = (self.stem_raw and self.gram_stats and self.fuse_conv_bn and "cat0" in w
                    and ops.gram_supported(64, w["cat0"][0].shape[0]) and gsz * 56 * 56 >= self.fuse_min_rows)
-            x, sc0, sh0 = ops.stem_conv_bn_pool(frames_u8, w["stem"], 1.0, RESNET_MEAN, RESNET_STD, gsz, gamma, beta, eps,
+            x, sc0, sh0 = ops.stem_conv_bn_pool(frames_u8, w["stem"].rows, 1.0, RESNET_MEAN, RESNET_STD, gsz, gamma, beta, eps,
                                                 apply=not raw)
             if raw:
                 x_aff = (sc0, sh0)
@@ -347,10 +364,10 @@ class ResNet50Runner:
                 x2d, gmax = x.view(-1, cin), gsz * hcur * hcur
                 sc, sh = ops.bn_gram_affine(x2d, wcat, gmax, gcat, bcat, eps, x_aff)
                 t1 = torch.empty((n, hcur, hcur, planes), dtype=dt, device=dev)
-                ops.conv1x1_affine(x2d, blk["c1"], gmax, sc[:, :c1n].contiguous(), sh[:, :c1n].contiguous(),
+                ops.conv1x1_affine(x2d, blk["c1"].rows, gmax, sc[:, :c1n].contiguous(), sh[:, :c1n].contiguous(),
                                    t1.view(-1, planes), None, True, x_aff)
                 idn = torch.empty((x2d.shape[0], planes * 4), dtype=dt, device=dev)
-                ops.conv1x1_affine(x2d, blk["cd"], gmax, sc[:, c1n:].contiguous(), sh[:, c1n:].contiguous(), idn, None,
+                ops.conv1x1_affine(x2d, blk["cd"].rows, gmax, sc[:, c1n:].contiguous(), sh[:, c1n:].contiguous(), idn, None,
                                    False, x_aff)
                 x_aff = None
             else:
@@ -533,7 +550,7 @@ class InceptionV3Runner:
             s = bn.weight.float() / torch.sqrt(bn.running_var.float() + bn.eps)
             wt = conv.weight.float() * s.view(-1, 1, 1, 1)
             bias = (bn.bias.float() - bn.running_mean.float() * s).contiguous()
-            w = _stem_weight(wt, stem_px, self.dtype) if stem_px else _ohwi(wt, self.dtype)
+            w = _W(_stem_weight(wt, stem_px, self.dtype) if stem_px else _ohwi(wt, self.dtype))
         kh, kw = conv.kernel_size
         return {"w": w, "b": bias, "kh": kh, "kw": kw, "s": conv.stride[0], "ph": conv.padding[0],
                 "pw": conv.padding[1], "cout": conv.out_channels}
@@ -558,8 +575,9 @@ class InceptionV3Runner:
         wo = (ww + 2 * c["pw"] - c["kw"]) // c["s"] + 1
         if out is None:
             out = torch.empty((n, ho, wo, c["cout"]), dtype=self.dtype, device=x.device)
-        return ops.conv2d(x, c["w"], c["kh"], c["kw"], c["s"], (c["ph"], c["pw"]), out, c["b"], ops.ACT_RELU,
-                          split=self.f32_split)
+        wsel, layout = c["w"].conv_operand()
+        return ops.conv2d(x, wsel, c["kh"], c["kw"], c["s"], (c["ph"], c["pw"]), out, c["b"], ops.ACT_RELU,
+                          split=self.f32_split, w_layout=layout)
 
     def _pool_branch(self, w, name, x, out):
         """branch_pool = avg_pool2d(3, 1, 1) -> 1x1 conv -> folded BN -> ReLU, run as 1x1 conv (no bias) -> average ->
@@ -570,7 +588,8 @@ class InceptionV3Runner:
         c = w[name]
         n, h, ww, _ = x.shape
         z = torch.empty((n, h, ww, c["cout"]), dtype=self.dtype, device=x.device)
-        ops.conv2d(x, c["w"], 1, 1, 1, (0, 0), z, None, ops.ACT_NONE, split=self.f32_split)
+        wsel, layout = c["w"].conv_operand()
+        ops.conv2d(x, wsel, 1, 1, 1, (0, 0), z, None, ops.ACT_NONE, split=self.f32_split, w_layout=layout)
         return ops.pool2d(z, "avg", 3, 1, 1, out, c["b"], ops.ACT_RELU)
 
     def _pool(self, x, mode, k, s, p, out=None):
@@ -655,8 +674,10 @@ class InceptionV3Runner:
         x0 = ops.frames_normalize(frames_u8, dt, 255.0, RESNET_MEAN, RESNET_STD, 299, 300, 0, 0, affine)
         c = w["Conv2d_1a_3x3"]
         x = torch.empty((n, 149, 149, 32), dtype=dt, device=dev)
+        wsel, layout = c["w"].conv_operand()
         ops.conv2d_raw(ops.dtype_code(dt, self.f32_split), n, 299, 149, 16, 3, 1, 2, 1, 0, 0, 149, 149, 32, x0, 299 * 300 * 4, 300 * 4, 8,
-                       c["w"], c["w"].stride(0), x, 32, c["b"], ops.ACT_RELU, algo_k=27, algo_in_elems=x0.numel())
+                       wsel, wsel.stride(0), x, 32, c["b"], ops.ACT_RELU, algo_k=27, algo_in_elems=x0.numel(),
+                       w_layout=layout)
         del x0
         x = self._conv(w, "Conv2d_2a_3x3", x)
         x = self._conv(w, "Conv2d_2b_3x3", x)

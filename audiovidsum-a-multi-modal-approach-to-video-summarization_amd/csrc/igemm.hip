@@ -66,6 +66,8 @@ struct IgemmParams {
   long long ldr;
   int split;         // fp32 operands only: 1 = products on the bf16 matrix cores as hi*hi + hi*lo + lo*hi (AVS_F32_SPLIT)
   int tall;          // 1: the 256-row tile variants (WR = 4)
+  int w_kstep;       // 1: w is stored reduction-step major (AVS_W_KSTEP32), bf16 [K / 32][N][32]: the 64 bytes a B row needs
+                     //    in one step sit next to the neighbouring rows' (whole cache lines per DMA instruction)
   int tile_rows;     // EPI_BNLOCAL: rows of the tile that are used (whole groups), also the pitch between tiles
 #ifdef AVS_STUDY
   int debug;  // ablation switches of the kernel-study build (tools/): 1 = skip output stores, 2 = skip A/B loads, ...
@@ -283,8 +285,8 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
       a_origin = (long long)n_first * p.x_img_stride - (long long)p.ph * p.x_row_stride - (long long)p.pw * p.x_px_stride;
     }
     a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(x) + a_origin * ES, 0, (int)BUF_OOB, 0x00020000);
-    b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(w) + (long long)n0 * p.ldb * ES, 0, (int)BUF_OOB,
-                                               0x00020000);
+    b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(w) + (p.w_kstep ? (long long)n0 * 64 : (long long)n0 * p.ldb * ES), 0, (int)BUF_OOB, 0x00020000);
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       unsigned mk = 0, off = BUF_OOB;
@@ -315,7 +317,9 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i)
-      boff[i] = b_base[i] != nullptr ? (unsigned)((long long)(rb + RPP * i) * p.ldb * ES) + cq * 16 : BUF_OOB;
+      boff[i] = b_base[i] == nullptr ? BUF_OOB
+                : p.w_kstep        ? (unsigned)((rb + RPP * i) * 64) + (unsigned)(cq >> 2) * (unsigned)p.N * 64u + (cq & 3) * 16
+                                   : (unsigned)((long long)(rb + RPP * i) * p.ldb * ES) + cq * 16;
   }
 
   auto stage = [&](int buf) {
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
           __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (__attribute__((address_space(3))) void*)(bbuf + 256 * i), 16,
                                                    (int)boff[i], f_kb, 0, 0);
       }
-      f_kb += BKE * ES;
+      f_kb += p.w_kstep ? p.N * ROWB : BKE * ES;   // (ROWB / 64 pieces of N x 64 bytes per step)
       // next step (scalar): the same tap's next channel block, or the next tap
       f_ci0 += BKE;
       f_koff += BKE * ES;
@@ -370,9 +374,11 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const unsigned long long bm = (kval && b_base[i] != nullptr) ? ~0ull : 0ull;
-      const char* src = reinterpret_cast<const char*>(
-          (reinterpret_cast<unsigned long long>(b_base[i] + (long long)kc * ES) & bm) |
-          (reinterpret_cast<unsigned long long>(zsrc) & ~bm));
+      // AVS_W_KSTEP32 (bf16): element (n, k) lives at ((k / 32) * N + n) * 32 + k % 32
+      const char* bsrc = p.w_kstep ? w + (((long long)(kc >> 5) * p.N + (n0 + rb + RPP * i)) * 32 + (kc & 31)) * ES
+                                   : b_base[i] + (long long)kc * ES;
+      const char* src = reinterpret_cast<const char*>((reinterpret_cast<unsigned long long>(bsrc) & bm) |
+                                                      (reinterpret_cast<unsigned long long>(zsrc) & ~bm));
       AVS_GLDS16(src, bbuf + 256 * i);
     }
     kc += BKE;
@@ -1233,6 +1239,12 @@ static int conv_fill_params(const avs_conv_desc* d, const void* d_x, const void*
   p.x_row_stride = d->x_row_stride;
   p.x_px_stride = d->x_px_stride;
   p.ldb = d->w_row_stride;
+  AVS_REQUIRE(d->w_layout == AVS_W_ROWS || d->w_layout == AVS_W_KSTEP32, AVS_E_ARG, "%s: bad w_layout %d", who,
+              d->w_layout);
+  p.w_kstep = d->w_layout == AVS_W_KSTEP32 ? 1 : 0;
+  AVS_REQUIRE(!p.w_kstep || (d->dtype == AVS_BF16 && p.K % 32 == 0), AVS_E_UNSUPPORTED,
+              "%s: the reduction-step-major weight layout is for bf16 and reductions that are multiples of 32 (K = %d)",
+              who, p.K);
   p.ldc = d->y_px_stride;
   p.alpha = d->alpha;
   p.act = d->act;

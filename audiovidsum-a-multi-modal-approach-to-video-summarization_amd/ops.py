@@ -180,17 +180,18 @@ def _stats_workspace(device, nbytes):
 
 def conv2d_raw(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x, x_img_stride, x_row_stride, x_px_stride,
                wt, w_row_stride, y, y_px_stride, bias=None, act=ACT_NONE, alpha=1.0, x_off=0, y_off=0, algo_k=None,
-               bnstats=None, bnlocal=None, algo_in_elems=None):
+               bnstats=None, bnlocal=None, algo_in_elems=None, w_layout=0):
     """algo_k: the algorithmic reduction length when it differs from kh*kw*cin (zero-padded stem rows);
     algo_in_elems: input elements the launch reads when the geometry does not say (the re-viewed stem image).
     bnstats = (rows_per_group, gamma, beta, eps): the BatchNorm batch statistics of equal-sized row groups from the
     kernel's epilogue (no bias / activation; deterministic per-tile partial sums); returns the folded
     (scale, shift) [G, cout], or None when the library declines the shape (groups of < 64 rows).
     bnlocal = (rows_per_group, gamma, beta, eps, residual2d | None): the whole BatchNorm (+ residual, then `act`) in
-    the convolution's launch (avs_conv2d_nhwc_bnlocal; shapes for which conv_bnlocal_tile_rows is not None)."""
+    the convolution's launch (avs_conv2d_nhwc_bnlocal; shapes for which conv_bnlocal_tile_rows is not None).
+    w_layout: _abi.AVS_W_ROWS (wt[cout, K]) or AVS_W_KSTEP32 (the image weights_kstep32() makes)."""
     _dev(x, wt, y, bias)
     d = _abi.ConvDesc(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x_img_stride, x_row_stride,
-                      x_px_stride, w_row_stride, y_px_stride, act, float(alpha))
+                      x_px_stride, w_row_stride, y_px_stride, act, float(alpha), int(w_layout))
     flops = 2.0 * n * ho * wo * cout * (algo_k if algo_k is not None else kh * kw * cin)
     # algorithmic HBM bytes: the input map read once (the pixels a strided 1x1 skips are not needed), the output
     # written once (+ the residual read once); weights are negligible and L2-resident
@@ -377,7 +378,18 @@ def conv1x1_gram_bn(x2d, wt, rows_per_group, gamma, beta, eps, out2d, residual=N
     return conv1x1_affine(x2d, wt, rows_per_group, scale, shift, out2d, residual, relu, in_affine, res_affine)
 
 
-def conv2d(x, wt, kh, kw, stride, pad, out, bias=None, act=ACT_NONE, bnstats=None, split=False):
+def weights_kstep32(wt):
+    """bf16 [cout, K] (K a multiple of 32) -> the same matrix stored reduction-step major, [K / 32][cout][32]
+    (AVS_W_KSTEP32), returned with the ROW shape [cout, K] so that shape checks read the same: the 64 bytes of a
+    filter that one reduction step reads then sit next to the neighbouring filters' (whole cache lines per DMA
+    instruction of the contraction kernel)."""
+    cout, k = wt.shape
+    if wt.dtype != torch.bfloat16 or k % 32:
+        raise ValueError("weights_kstep32: bf16 [cout, K] with K a multiple of 32")
+    return wt.reshape(cout, k // 32, 32).permute(1, 0, 2).contiguous().view(cout, k)
+
+
+def conv2d(x, wt, kh, kw, stride, pad, out, bias=None, act=ACT_NONE, bnstats=None, split=False, w_layout=0):
     """x: NHWC view [n,h,w,cin] (unit channel stride); wt: [cout, kh*kw*cin]; out: NHWC view [n,ho,wo,cout]
     whose pixels are dense in (n,ho,wo) order (a channel slice of a dense buffer is fine).
     bnstats: see conv2d_raw (returns (scale, shift) then, else `out`)."""
@@ -397,7 +409,7 @@ def conv2d(x, wt, kh, kw, stride, pad, out, bias=None, act=ACT_NONE, bnstats=Non
     if bias is not None:
         _f32(bias, "bias")
     r = conv2d_raw(dtype_code(x.dtype, split), n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x, x.stride(0),
-                   x.stride(1), x.stride(2), wt, wt.stride(0), out, yps, bias, act, bnstats=bnstats)
+                   x.stride(1), x.stride(2), wt, wt.stride(0), out, yps, bias, act, bnstats=bnstats, w_layout=w_layout)
     return out if bnstats is None else r
 
 

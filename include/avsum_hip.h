@@ -86,7 +86,14 @@ typedef struct {
   int64_t y_px_stride;      /* elements between output pixels (>= cout)       */
   int act;                  /* AVS_ACT_*                                      */
   float alpha;
+  int w_layout;             /* AVS_W_ROWS: w[cout][w_row_stride], a row = (kh, kw, cin);
+                             * AVS_W_KSTEP32 (bf16, kh*kw*cin a multiple of 32): the same matrix stored
+                             * reduction-step major, w[k / 32][cout][32] - the 64 bytes of a filter that one
+                             * reduction step reads sit next to the neighbouring filters', so the weight tile of
+                             * a step is contiguous whole cache lines (+2..6 % on the ResNet layers);
+                             * w_row_stride is ignored.  Weights are re-laid out once, offline.              */
 } avs_conv_desc;
+enum { AVS_W_ROWS = 0, AVS_W_KSTEP32 = 1 };
 
 int avs_conv2d_nhwc(const avs_conv_desc* desc, const void* d_x, const void* d_w,
                     const float* d_bias, void* d_y, avs_stream_t stream);

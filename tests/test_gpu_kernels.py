@@ -13,6 +13,11 @@ def _ops():
     return ops
 
 
+def _lib():
+    from avsum_amd import _abi
+    return _abi.lib()
+
+
 def rel_err(a, b):
     a, b = a.double(), b.double()
     return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
@@ -191,6 +196,37 @@ def test_conv2d_bf16_tall_tiles(dev, cfg):
         assert (sh_t - sh_b).abs().max().item() < 2e-3 * max(1.0, sh_b.abs().max().item())
     finally:
         L.avs_tune_tall_tiles(0, 0, -1)
+
+
+@pytest.mark.parametrize("cfg", [(3, 14, 14, 64, 96, 3, 1, 1), (2, 9, 11, 32, 40, 1, 1, 0), (2, 12, 12, 128, 64, 3, 2, 1),
+                                 (70, 14, 14, 256, 256, 3, 1, 1), (2, 8, 8, 1024, 136, 1, 1, 0), (1, 7, 7, 96, 24, 5, 1, 2)])
+def test_conv2d_bf16_kstep_weight_layout(dev, cfg):
+    """AVS_W_KSTEP32: the same weight matrix stored reduction-step major gives bit-identical outputs (every staging
+    form: scalar tap walk / general gather, 64- and 128-byte steps, 128- and 256-row tiles); fp32 and reductions
+    that are not multiples of 32 are refused."""
+    ops = _ops()
+    n, h, w_, cin, cout, k, s, p = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    x = torch.randn(n, h, w_, cin, generator=g).bfloat16().to(dev)
+    wt = (torch.randn(cout, k * k * cin, generator=g) / (k * k * cin) ** 0.5).bfloat16().to(dev)
+    ho, wo = (h + 2 * p - k) // s + 1, (w_ + 2 * p - k) // s + 1
+    bias = torch.randn(cout, generator=g).to(dev)
+    ref = ops.conv2d(x, wt, k, k, s, p, torch.empty((n, ho, wo, cout), dtype=torch.bfloat16, device=dev), bias, ops.ACT_RELU)
+    wk = ops.weights_kstep32(wt)
+    assert wk.shape == wt.shape and (k * k * cin == 32 or not torch.equal(wk, wt))   # one step: the layouts coincide
+    for tall in (1, 2):
+        try:
+            _lib().avs_tune_tall_tiles(tall, 0, -1)
+            got = ops.conv2d(x, wk, k, k, s, p, torch.empty_like(ref), bias, ops.ACT_RELU, w_layout=1)
+            want = ops.conv2d(x, wt, k, k, s, p, torch.empty_like(ref), bias, ops.ACT_RELU)
+        finally:
+            _lib().avs_tune_tall_tiles(0, 0, -1)
+        assert torch.equal(got, want)
+    assert torch.equal(want, ref) or (want.float() - ref.float()).abs().max().item() < 0.05
+    with pytest.raises(RuntimeError):
+        ops.conv2d(x.float(), wt.float(), k, k, s, p, torch.empty_like(ref).float(), w_layout=1)
+    with pytest.raises(ValueError):
+        ops.weights_kstep32(wt[:, :24])
 
 
 def test_conv2d_seeded_shape_sweep(dev):

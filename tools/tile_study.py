@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Kernel study: the convolution + per-tile statistics launch (the split form's first kernel) per ResNet-50 layer shape
-with the 128-row and the 256-row tiles (avs_tune_tall_tiles: 1 = never, 2 = whenever the variant exists).
+with the 128-row and the 256-row tiles (avs_tune_tall_tiles: 1 = never, 2 = whenever the variant exists), the latter
+also with the weights stored reduction-step major (AVS_W_KSTEP32).
 Usage: python tools/tile_study.py [--n 4096]"""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -36,11 +37,15 @@ for name, hw, cin, cout, k, s in shapes:
     gamma, beta = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev)
     flops = 2.0 * n * ho * ho * cout * wrs
     line = f"{name:28s}"
-    for tag, tall in (("128-row", 1), ("256-row", 2)):
+    wk = ops.weights_kstep32(w)   # reduction-step major image (AVS_W_KSTEP32)
+    ref_y = None
+    for tag, tall, kstep in (("128-row", 1, 0), ("256-row", 2, 0), ("256-row w-kstep", 2, 1)):
         L.avs_tune_tall_tiles(tall, 0, -1)
+        wsel = wk if kstep else w
 
         def run():
-            return ops.conv2d_raw(code, *geom, x, *xs, w, wrs, y, cout, bnstats=(ho * ho, gamma, beta, 1e-5))
+            return ops.conv2d_raw(code, *geom, x, *xs, wsel, wrs, y, cout, bnstats=(ho * ho, gamma, beta, 1e-5),
+                                  w_layout=kstep)
         for _ in range(2):
             run()
         torch.cuda.synchronize()
@@ -51,6 +56,9 @@ for name, hw, cin, cout, k, s in shapes:
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / 5
-        line += f" | {tag} {us:8.1f} us {flops / us / 1e6:6.0f} TFLOP/s"
+        if tag == "256-row":
+            ref_y = y.clone()
+        same = "" if not kstep else (" same" if torch.equal(y, ref_y) else " DIFFERENT")
+        line += f" | {tag} {us:8.1f} us {flops / us / 1e6:6.0f} TFLOP/s{same}"
     print(line, flush=True)
 L.avs_tune_tall_tiles(0, 0, -1)
