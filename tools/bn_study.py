@@ -71,8 +71,11 @@ for name, hw, cin, cout, k, s, with_res in shapes:
         ops.conv2d_raw(code, *geom, x, *xs, w, wrs, y, cout)
 
     def split():
-        sc, sh = ops.conv2d_raw(code, *geom, x, *xs, w, wrs, y, cout, bnstats=(rpg, gamma, beta, 1e-5))
-        ops.bn_apply(y2, sc, sh, grows, rpg, res, ops.ACT_RELU, y2)
+        aff = ops.conv2d_raw(code, *geom, x, *xs, w, wrs, y, cout, bnstats=(rpg, gamma, beta, 1e-5))
+        if aff is None:   # groups of fewer than 64 rows: the fused statistics decline, the runner's sequence is this
+            ops.conv2d_raw(code, *geom, x, *xs, w, wrs, y, cout)
+            aff = ops.bn_batch_stats(y2, grows, gamma, beta, 1e-5)
+        ops.bn_apply(y2, aff[0], aff[1], grows, rpg, res, ops.ACT_RELU, y2)
 
     def twopass():
         ops.conv1x1_bn(x.view(-1, cin), w, rpg, gamma, beta, 1e-5, y2, res, True)
