@@ -235,6 +235,29 @@ def test_bench_contract_line(dev):
     assert d["sub_results"] is None                                     # only with the default headline
 
 
+@pytest.mark.parametrize("dtype,config", [("f32split", "1"), ("f32", "1"), ("bf16", "3")])
+def test_bench_other_headlines(dev, dtype, config):
+    """The non-default headlines of bench.py stay runnable: the fp32 parity / fp32-split arithmetic modes (whose
+    roofline is priced against the fp32 peak / a third of the bf16 peak) and one rank's share of configs[3]."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", config, "--dtype", dtype, "--videos", "2",
+                          "--mean-frames", "24", "--chunk", "16", "--steps", "1", "--warmup", "1", "--cpu-sample", "0",
+                          "--sub", "none"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-800:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and d["dtype"] == dtype
+    r = d["roofline"]
+    assert r is not None and r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    if dtype == "f32split":
+        assert abs(r["peak"] - 2500.0 / 3.0) < 1.0
+
+
 def test_bench_under_the_launcher_one_rank(dev):
     """The driver's launch line at N = 1: python -m torch.distributed.run --nproc-per-node 1 ... bench.py --gpus 1
     (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment, rendezvous on 127.0.0.1)."""
