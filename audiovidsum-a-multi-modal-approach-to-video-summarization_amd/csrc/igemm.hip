@@ -279,7 +279,9 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
     long long a_origin;
     int n_first = 0;
     if (p.lin_stride >= 0) {
-      a_origin = (long long)m0 * p.lin_stride;
+      // study build, bit 6 (1x1 layers, 64-byte steps): the INPUT is read reduction-step major too, x[k / 32][M][32] - what
+      // a channel-blocked activation layout would give the A operand (whole cache lines per DMA instruction)
+      a_origin = AVS_DEBUG_BIT(p, 64) ? (long long)m0 * BKE : (long long)m0 * p.lin_stride;
     } else {
       n_first = m0 / p.HoWo;
       a_origin = (long long)n_first * p.x_img_stride - (long long)p.ph * p.x_row_stride - (long long)p.pw * p.x_px_stride;
@@ -297,7 +299,8 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
       if (a_base[i] != nullptr && m < p.M) {
         if (p.lin_stride >= 0) {
           mk = ~0u;
-          off = (unsigned)((long long)(m - m0) * p.lin_stride * ES) + cq * 16;
+          off = AVS_DEBUG_BIT(p, 64) ? (unsigned)((m - m0) * ROWB) + cq * 16
+                                     : (unsigned)((long long)(m - m0) * p.lin_stride * ES) + cq * 16;
         } else {
           const int n = m / p.HoWo;
           if constexpr (SPATIAL) {
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
       f_kb += p.w_kstep ? p.N * ROWB : BKE * ES;   // (ROWB / 64 pieces of N x 64 bytes per step)
       // next step (scalar): the same tap's next channel block, or the next tap
       f_ci0 += BKE;
-      f_koff += BKE * ES;
+      f_koff += AVS_DEBUG_BIT(p, 64) ? p.M * ROWB : BKE * ES;
       if (f_ci0 == p.cin) {
         f_ci0 = 0;
         ++f_tap;
