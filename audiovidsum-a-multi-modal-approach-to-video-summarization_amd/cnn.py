@@ -92,13 +92,14 @@ def _stem_weight(weight, px, dtype):
 
 class _W:
     """A convolution weight in kernel layout: `rows` = [cout, kh*kw*cin] (what the 1x1 BatchNorm kernels and the stem
-    read) and, for bf16 with a reduction that is a multiple of 32, `kstep` = the same matrix reduction-step major
+    read) and, when the reduction is a multiple of a 64-byte step, `kstep` = the same matrix reduction-step major
     (ops.weights_kstep32: whole cache lines per weight DMA instruction of the contraction kernel)."""
     __slots__ = ("rows", "kstep")
 
     def __init__(self, rows):
         self.rows = rows
-        self.kstep = ops.weights_kstep32(rows) if rows.dtype == torch.bfloat16 and rows.shape[1] % 32 == 0 else None
+        step = 32 if rows.dtype == torch.bfloat16 else 16   # elements of a 64-byte reduction step
+        self.kstep = ops.weights_kstep32(rows) if rows.shape[1] % step == 0 else None
 
     def conv_operand(self):
         """(tensor, w_layout) for avs_conv2d_nhwc*."""

@@ -66,7 +66,7 @@ struct IgemmParams {
   long long ldr;
   int split;         // fp32 operands only: 1 = products on the bf16 matrix cores as hi*hi + hi*lo + lo*hi (AVS_F32_SPLIT)
   int tall;          // 1: the 256-row tile variants (WR = 4)
-  int w_kstep;       // 1: w is stored reduction-step major (AVS_W_KSTEP32), bf16 [K / 32][N][32]: the 64 bytes a B row needs
+  int w_kstep;       // 1: w is stored reduction-step major (AVS_W_KSTEP32), [K / S][N][S], S = 32 bf16 / 16 fp32: the 64 bytes a B row needs
                      //    in one step sit next to the neighbouring rows' (whole cache lines per DMA instruction)
   int tile_rows;     // EPI_BNLOCAL: rows of the tile that are used (whole groups), also the pitch between tiles
 #ifdef AVS_STUDY
@@ -159,7 +159,8 @@ template <int ES, int BN, bool ACC64, bool SPATIAL, int ROWB, int EPI, bool PIPE
 __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64 && ES == 2) ? 4 : 3) : 2) void igemm_kernel(
     IgemmParams p) {
   static_assert(!SPLIT || (ES == 4 && !ACC64), "the split-bf16 arithmetic is for fp32 operands");
-  static_assert(WR == 2 || (WR == 4 && ES == 2 && !ACC64), "256-row tiles are built for the bf16 variants");
+  static_assert(WR == 2 || (WR == 4 && !ACC64 && (ES == 2 || SPLIT)),
+                "256-row tiles are built for the bf16 variants and the fp32-split arithmetic");
   static_assert(!PIPE || (ROWB == 64 && !ACC64), "the 3-buffer pipeline is built for the 64-byte-row variants");
   static_assert(!ACC64 || (ES == 4 && BN == 64), "fp64 slice accumulation: fp32 operands, narrow tile only");
   static_assert(ROWB == 64 || ROWB == 128, "row bytes");
@@ -377,8 +378,9 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const unsigned long long bm = (kval && b_base[i] != nullptr) ? ~0ull : 0ull;
-      // AVS_W_KSTEP32 (bf16): element (n, k) lives at ((k / 32) * N + n) * 32 + k % 32
-      const char* bsrc = p.w_kstep ? w + (((long long)(kc >> 5) * p.N + (n0 + rb + RPP * i)) * 32 + (kc & 31)) * ES
+      // AVS_W_KSTEP32: element (n, k) lives at ((k / S) * N + n) * S + k % S, S = the elements of a 64-byte step
+      constexpr int KSE = 64 / ES;
+      const char* bsrc = p.w_kstep ? w + (((long long)(kc / KSE) * p.N + (n0 + rb + RPP * i)) * KSE + (kc % KSE)) * ES
                                    : b_base[i] + (long long)kc * ES;
       const char* src = reinterpret_cast<const char*>((reinterpret_cast<unsigned long long>(bsrc) & bm) |
                                                       (reinterpret_cast<unsigned long long>(zsrc) & ~bm));
@@ -1035,27 +1037,29 @@ static void igemm_dispatch_epi4(int epi, dim3 grid, hipStream_t stream, const Ig
       return;
     }
   }
-  if constexpr (ES == 4 && !ACC64 && WR == 2) {
-    if (p.split) {   // AVS_F32_SPLIT: the same tiles, products as three bf16 MFMAs
+  if constexpr (ES == 4 && !ACC64) {
+    if (p.split || WR == 4) {   // AVS_F32_SPLIT: the same tiles, products as three bf16 MFMAs (WR = 4 exists for it only)
       if (epi == EPI_PLAIN)
         hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_PLAIN, PIPE, WR, FK, true>), grid, dim3(256), 0, stream, p);
       else if (epi == EPI_STATS)
         hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE, WR, FK, true>), grid, dim3(256), 0, stream, p);
       else if (epi == EPI_BRELU)
         hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BRELU, PIPE, WR, FK, true>), grid, dim3(256), 0, stream, p);
-      else
+      else if constexpr (WR == 2)
         hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_ANY, PIPE, WR, FK, true>), grid, dim3(256), 0, stream, p);
       return;
     }
   }
-  if (epi == EPI_PLAIN)
-    hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_PLAIN, PIPE, WR, FK>), grid, dim3(256), 0, stream, p);
-  else if (epi == EPI_STATS)
-    hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE, WR, FK>), grid, dim3(256), 0, stream, p);
-  else if (epi == EPI_BRELU)
-    hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BRELU, PIPE, WR, FK>), grid, dim3(256), 0, stream, p);
-  else if constexpr (WR == 2)
-    hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_ANY, PIPE, WR, FK>), grid, dim3(256), 0, stream, p);
+  if constexpr (!(ES == 4 && WR == 4)) {   // (fp32 on 256-row tiles exists as fp32-split only: handled above)
+    if (epi == EPI_PLAIN)
+      hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_PLAIN, PIPE, WR, FK>), grid, dim3(256), 0, stream, p);
+    else if (epi == EPI_STATS)
+      hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE, WR, FK>), grid, dim3(256), 0, stream, p);
+    else if (epi == EPI_BRELU)
+      hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BRELU, PIPE, WR, FK>), grid, dim3(256), 0, stream, p);
+    else if constexpr (WR == 2)
+      hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_ANY, PIPE, WR, FK>), grid, dim3(256), 0, stream, p);
+  }
 }
 
 
@@ -1083,8 +1087,8 @@ static void igemm_dispatch_epi2(int epi, dim3 grid, hipStream_t stream, const Ig
   if constexpr (ACC64) {
     hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_ANY, false>), grid, dim3(256), 0, stream, p);
   } else {
-    if constexpr (ES == 2 && ROWB == 64 && PIPE) {
-      if (p.tall) {  // igemm_launch only sets it for the epilogue forms compiled at WR = 4
+    if constexpr (ROWB == 64 && PIPE) {
+      if (p.tall) {  // igemm_launch only sets it for the epilogue forms compiled at WR = 4 (bf16; fp32 only as fp32-split)
         igemm_dispatch_epi3<ES, BN, ACC64, SP, ROWB, PIPE, 4>(epi, grid, stream, p);
         return;
       }
@@ -1167,7 +1171,8 @@ static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream
     const bool fixed_epi = p.alpha == 1.0f &&
                            ((p.bias_mode == AVS_BIAS_NONE && p.act == AVS_ACT_NONE) ||
                             (p.bias_mode == AVS_BIAS_COL && p.act == AVS_ACT_RELU && !p.stat_part));
-    const bool can = dtype == AVS_BF16 && fixed_epi && g_pipe3 && (long long)p.K * es > 128 && batch == 1;
+    const bool can = (dtype == AVS_BF16 || dtype == AVS_F32_SPLIT) && fixed_epi && g_pipe3 && (long long)p.K * es > 128 &&
+                     batch == 1;
     const long long tall_tiles = ((long long)p.M + 255) / 256 * p.tiles_n;
     if (can && (g_tall_mode == 2 || (g_tall_mode == 0 && tall_tiles >= g_tall_min_tiles &&
                                      (narrow || (long long)p.K * es >= g_tall_min_k_bytes))))
@@ -1245,8 +1250,8 @@ static int conv_fill_params(const avs_conv_desc* d, const void* d_x, const void*
   AVS_REQUIRE(d->w_layout == AVS_W_ROWS || d->w_layout == AVS_W_KSTEP32, AVS_E_ARG, "%s: bad w_layout %d", who,
               d->w_layout);
   p.w_kstep = d->w_layout == AVS_W_KSTEP32 ? 1 : 0;
-  AVS_REQUIRE(!p.w_kstep || (d->dtype == AVS_BF16 && p.K % 32 == 0), AVS_E_UNSUPPORTED,
-              "%s: the reduction-step-major weight layout is for bf16 and reductions that are multiples of 32 (K = %d)",
+  AVS_REQUIRE(!p.w_kstep || (d->dtype != AVS_F32_ACC64 && p.K % (d->dtype == AVS_BF16 ? 32 : 16) == 0), AVS_E_UNSUPPORTED,
+              "%s: the reduction-step-major weight layout needs a reduction that is a multiple of a 64-byte step (K = %d)",
               who, p.K);
   p.ldc = d->y_px_stride;
   p.alpha = d->alpha;

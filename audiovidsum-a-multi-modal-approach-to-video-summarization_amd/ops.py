@@ -379,14 +379,17 @@ def conv1x1_gram_bn(x2d, wt, rows_per_group, gamma, beta, eps, out2d, residual=N
 
 
 def weights_kstep32(wt):
-    """bf16 [cout, K] (K a multiple of 32) -> the same matrix stored reduction-step major, [K / 32][cout][32]
-    (AVS_W_KSTEP32), returned with the ROW shape [cout, K] so that shape checks read the same: the 64 bytes of a
-    filter that one reduction step reads then sit next to the neighbouring filters' (whole cache lines per DMA
-    instruction of the contraction kernel)."""
+    """[cout, K] bf16 / fp32 (K a multiple of S = 32 / 16 elements = one 64-byte step) -> the same matrix stored
+    reduction-step major, [K / S][cout][S] (AVS_W_KSTEP32), returned with the ROW shape [cout, K] so that shape checks
+    read the same: the 64 bytes of a filter that one reduction step reads then sit next to the neighbouring filters'
+    (whole cache lines per DMA instruction of the contraction kernel)."""
     cout, k = wt.shape
-    if wt.dtype != torch.bfloat16 or k % 32:
-        raise ValueError("weights_kstep32: bf16 [cout, K] with K a multiple of 32")
-    return wt.reshape(cout, k // 32, 32).permute(1, 0, 2).contiguous().view(cout, k)
+    if wt.dtype not in (torch.bfloat16, torch.float32):
+        raise ValueError("weights_kstep32: bf16 or fp32 weights")
+    step = 32 if wt.dtype == torch.bfloat16 else 16
+    if k % step:
+        raise ValueError(f"weights_kstep32: K = {k} is not a multiple of {step}")
+    return wt.reshape(cout, k // step, step).permute(1, 0, 2).contiguous().view(cout, k)
 
 
 def conv2d(x, wt, kh, kw, stride, pad, out, bias=None, act=ACT_NONE, bnstats=None, split=False, w_layout=0):

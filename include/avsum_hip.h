@@ -87,8 +87,9 @@ typedef struct {
   int act;                  /* AVS_ACT_*                                      */
   float alpha;
   int w_layout;             /* AVS_W_ROWS: w[cout][w_row_stride], a row = (kh, kw, cin);
-                             * AVS_W_KSTEP32 (bf16, kh*kw*cin a multiple of 32): the same matrix stored
-                             * reduction-step major, w[k / 32][cout][32] - the 64 bytes of a filter that one
+                             * AVS_W_KSTEP32 (kh*kw*cin a multiple of S = 32 bf16 / 16 fp32 elements, i.e. of a
+                             * 64-byte step; not AVS_F32_ACC64): the same matrix stored
+                             * reduction-step major, w[k / S][cout][S] - the 64 bytes of a filter that one
                              * reduction step reads sit next to the neighbouring filters', so the weight tile of
                              * a step is contiguous whole cache lines (+2..6 % on the ResNet layers);
                              * w_row_stride is ignored.  Weights are re-laid out once, offline.              */

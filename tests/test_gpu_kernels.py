@@ -158,6 +158,32 @@ def test_conv2d_f32_split(dev, cfg):
     128-byte-row variants, the pipelined and the plain loop): ~2^-15 relative per product, i.e. ~1e-4 of the exact
     fp32 result's scale in the worst element, against 2e-5 for the exact fp32 mode and 1.2e-2 for bf16."""
     _conv_case(dev, torch.float32, *cfg, tol=1e-4, split=True)
+    # the 256-row tiles (4 x 1 waves) forced on: same products in the same k order per output element => the same
+    # values as the 128-row tiles, also with the fused BatchNorm statistics
+    from avsum_amd import _abi
+    ops = _ops()
+    L = _abi.lib()
+    n, h, w, cin, cout, kh, kw, stride, pad = cfg
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(n, h, w, cin, generator=g).to(dev)
+    wk = (torch.randn(cout, kh * kw * cin, generator=g) / (kh * kw * cin) ** 0.5).to(dev)
+    ph, pw = pad if isinstance(pad, tuple) else (pad, pad)
+    ho, wo = (h + 2 * ph - kh) // stride + 1, (w + 2 * pw - kw) // stride + 1
+    gamma, beta = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
+    rpg = max(64, ho * wo)
+    try:
+        L.avs_tune_tall_tiles(2, 0, -1)
+        _conv_case(dev, torch.float32, *cfg, tol=1e-4, split=True)
+        tall = torch.empty((n, ho, wo, cout), device=dev)
+        sc_t, sh_t = ops.conv2d(x, wk, kh, kw, stride, pad, tall, bnstats=(rpg, gamma, beta, 1e-5), split=True)
+        L.avs_tune_tall_tiles(1, 0, -1)
+        base = torch.empty_like(tall)
+        sc_b, sh_b = ops.conv2d(x, wk, kh, kw, stride, pad, base, bnstats=(rpg, gamma, beta, 1e-5), split=True)
+        assert torch.equal(tall, base)
+        assert (sc_t - sc_b).abs().max().item() < 1e-4 * sc_b.abs().max().item()
+        assert (sh_t - sh_b).abs().max().item() < 1e-4 * max(1.0, sh_b.abs().max().item())
+    finally:
+        L.avs_tune_tall_tiles(0, 0, -1)
 
 
 @pytest.mark.parametrize("cfg", [(2, 14, 14, 64, 64, 3, 3, 1, 1), (2, 16, 16, 128, 256, 1, 1, 2, 0),
@@ -223,10 +249,17 @@ def test_conv2d_bf16_kstep_weight_layout(dev, cfg):
             _lib().avs_tune_tall_tiles(0, 0, -1)
         assert torch.equal(got, want)
     assert torch.equal(want, ref) or (want.float() - ref.float()).abs().max().item() < 0.05
-    with pytest.raises(RuntimeError):
-        ops.conv2d(x.float(), wt.float(), k, k, s, p, torch.empty_like(ref).float(), w_layout=1)
+    # fp32 (16-element steps), exact and split arithmetic
+    x32, w32 = x.float(), wt.float()
+    for split in (False, True):
+        a = ops.conv2d(x32, w32, k, k, s, p, torch.empty_like(ref).float(), bias, ops.ACT_RELU, split=split)
+        b = ops.conv2d(x32, ops.weights_kstep32(w32), k, k, s, p, torch.empty_like(ref).float(), bias, ops.ACT_RELU,
+                       split=split, w_layout=1)
+        assert torch.equal(a, b)
     with pytest.raises(ValueError):
         ops.weights_kstep32(wt[:, :24])
+    with pytest.raises(RuntimeError):     # the layout flag on a reduction that is not whole steps
+        ops.conv2d(x[..., :24].contiguous(), wt[:, :24 * k * k].contiguous(), k, k, s, p, torch.empty_like(ref), w_layout=1)
 
 
 def test_conv2d_seeded_shape_sweep(dev):
