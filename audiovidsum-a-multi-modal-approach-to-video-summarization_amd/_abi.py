@@ -20,7 +20,7 @@ STUDY = os.environ.get("AVS_STUDY_LIB") == "1"
 LIB_PATH = os.path.join(_PKG_DIR, "lib", "libavsum_hip_study.so" if STUDY else "libavsum_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "avsum_hip.h")
 
-AVS_F32, AVS_BF16, AVS_F32_ACC64, AVS_F32_SPLIT = 0, 1, 2, 3
+AVS_F32, AVS_BF16, AVS_F32_ACC64, AVS_F32_SPLIT, AVS_F16X2 = 0, 1, 2, 3, 4
 AVS_W_ROWS, AVS_W_KSTEP32 = 0, 1
 ACT_NONE, ACT_RELU = 0, 1
 BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
@@ -49,6 +49,8 @@ _SIGNATURES = {
     "avs_abi_version": (c_int, []),
     "avs_last_error": (c_char_p, []),
     "avs_device_info": (c_int, [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int64), c_char_p, c_int]),
+    "avs_f16x2_pack_f32": (c_int, [P, P, c_int64, P]),
+    "avs_f16x2_unpack_f32": (c_int, [P, P, c_int64, P]),
     "avs_conv2d_nhwc": (c_int, [POINTER(ConvDesc), P, P, P, P, P]),
     "avs_conv2d_bnstats_workspace_bytes": (c_int64, [POINTER(ConvDesc), c_int64]),
     "avs_conv2d_nhwc_bnstats": (c_int, [POINTER(ConvDesc), P, P, P, c_int64, P, P, c_float, P, P, P, c_int64, P]),

@@ -121,12 +121,17 @@ class ResNet50Runner:
               avs_bn_batch_stats -> avs_bn_apply (fp32 parity mode, ragged groups, shapes the other forms decline)."""
 
     def __init__(self, trunk, dtype=torch.float32, bn_mode="batch", f32_split=False):
-        """f32_split (fp32 only): activations and weights stay fp32 in HBM, the convolutions' products run on the bf16
-        matrix cores as hi*hi + hi*lo + lo*hi (AVS_F32_SPLIT: ~2^-15 relative per product instead of exact)."""
+        """f32_split (fp32 only): True = activations and weights stay fp32 in HBM, the convolutions' products run on the
+        bf16 matrix cores as hi*hi + hi*lo + lo*hi (AVS_F32_SPLIT: ~2^-15 relative per product instead of exact);
+        "f16x2" = AVS_F16X2: activations and weights are STORED as fp16 hi | lo runs (22 significant bits, the byte
+        size of fp32), products are three fp16 MFMAs with no arithmetic on the operands, every output is split once
+        where it is produced, BatchNorm statistics are centred two-round sums: the fast parity-grade mode."""
         if bn_mode not in ("batch", "folded"):
             raise ValueError("bn_mode must be 'batch' (reference-faithful) or 'folded'")
         self.trunk, self.dtype, self.bn_mode = trunk, dtype, bn_mode
-        self.f32_split = bool(f32_split) and dtype == torch.float32
+        self.h2 = f32_split == "f16x2" and dtype == torch.float32
+        self.f32_split = bool(f32_split) and not self.h2 and dtype == torch.float32
+        self.code = ops.dtype_code(dtype, "f16x2" if self.h2 else self.f32_split)
         self.fuse_conv_bn = True
         self.fuse_min_rows, self.fuse_ratio_num, self.fuse_ratio_den = 128, 2, 1
         self.twopass_max_cin = 128   # wider inputs (256 -> 1024 at 4-frame groups): the second matrix pass costs more than
@@ -150,7 +155,12 @@ class ResNet50Runner:
         if self._w is not None and key == self._key:
             return self._w
         t, dt = self.trunk, self.dtype
-        w = {"stem": _W(_stem_weight(t[0].weight, 8, dt)), "blocks": []}
+        pack = ops.f16x2_pack if self.h2 else (lambda r: r)   # AVS_F16X2: every weight row as fp16 hi | lo runs, once
+
+        def mkw(rows):
+            return _W(pack(rows))
+
+        w = {"stem": mkw(_stem_weight(t[0].weight, 8, dt)), "blocks": []}
 
         def bn(m):
             return (m.weight.detach().float().contiguous(), m.bias.detach().float().contiguous(), float(m.eps),
@@ -159,11 +169,11 @@ class ResNet50Runner:
         w["bn1"] = bn(t[1])
         for li in range(4, 8):
             for blk in t[li]:
-                d = {"c1": _W(_ohwi(blk.conv1.weight, dt)), "b1": bn(blk.bn1), "c2": _W(_ohwi(blk.conv2.weight, dt)),
-                     "b2": bn(blk.bn2), "c3": _W(_ohwi(blk.conv3.weight, dt)), "b3": bn(blk.bn3),
+                d = {"c1": mkw(_ohwi(blk.conv1.weight, dt)), "b1": bn(blk.bn1), "c2": mkw(_ohwi(blk.conv2.weight, dt)),
+                     "b2": bn(blk.bn2), "c3": mkw(_ohwi(blk.conv3.weight, dt)), "b3": bn(blk.bn3),
                      "stride": blk.stride, "planes": blk.conv1.out_channels}
                 if blk.downsample is not None:
-                    d["cd"] = _W(_ohwi(blk.downsample[0].weight, dt))
+                    d["cd"] = mkw(_ohwi(blk.downsample[0].weight, dt))
                     d["bd"] = bn(blk.downsample[1])
                 w["blocks"].append(d)
         # layer 1's first block: conv1 (64 -> 64) and the downsample (64 -> 256) read the same input, so ONE Gram matrix
@@ -207,7 +217,7 @@ class ResNet50Runner:
         key = (n, gsz)
         plan = self._plans.get(key)
         if plan is None:
-            dcode = ops.dtype_code(self.dtype)   # (the tile-local form is bf16 only)
+            dcode = self.code   # (the tile-local form exists for bf16 and f16x2)
             plan = []
             for geom, xs, wrs in self._layer_geoms(n):
                 ho, wo, cout = geom[10], geom[11], geom[12]
@@ -236,7 +246,7 @@ class ResNet50Runner:
         n, ho, wo, cout = geom[0], geom[10], geom[11], geom[12]
         cin, kh, sh = geom[3], geom[4], geom[6]
         dev, dt = x.device, self.dtype
-        dcode = ops.dtype_code(dt, self.f32_split)
+        dcode = self.code
         gamma, beta, eps, rmean, rvar = bnp
         act = ops.ACT_RELU if relu else ops.ACT_NONE
         y = torch.empty((n, ho, wo, cout), dtype=dt, device=dev)
@@ -255,11 +265,11 @@ class ResNet50Runner:
         def finish(scale, shift, grows, gmax):
             if pool is not None and residual is None:
                 out, k, s, p = pooled(y)
-                return ops.bn_maxpool(y, scale, shift, grows, relu, k, s, p, out)
-            ops.bn_apply(y2d, scale, shift, grows, gmax, residual, act, y2d)
+                return ops.bn_maxpool(y, scale, shift, grows, relu, k, s, p, out, code=dcode)
+            ops.bn_apply(y2d, scale, shift, grows, gmax, residual, act, y2d, code=dcode)
             if pool is not None:
                 out, k, s, p = pooled(y)
-                return ops.pool2d(y, "max", k, s, p, out)
+                return ops.pool2d(y, "max", k, s, p, out, code=dcode)
             return y
 
         if self.bn_mode != "batch":
@@ -272,12 +282,12 @@ class ResNet50Runner:
         # statistics from the convolution's epilogue: the bf16 mode, and the fp32-split mode (whose products already carry
         # ~2^-15 of error: the E[y^2] - E[y]^2 form on fp32 sums costs nothing next to that); the exact fp32 parity mode
         # keeps the shifted statistics pass over the stored output
-        fast = uniform and (bf16 or self.f32_split)
-        if fast and bf16 and local:
+        fast = uniform and (bf16 or self.f32_split or self.h2)
+        if fast and (bf16 or self.h2) and local:
             conv(act=act, bnlocal=(gmax, gamma, beta, eps, residual))
             if pool is not None:
                 out, k, s, p = pooled(y)
-                return ops.pool2d(y, "max", k, s, p, out)
+                return ops.pool2d(y, "max", k, s, p, out, code=dcode)
             return y
         if in_affine is not None or (fast and bf16 and self._twopass_ok(cin, cout, kh, sh, gmax)):
             # statistics from the input's Gram matrix + ONE streaming pass where the shape allows it (the expanding
@@ -299,7 +309,7 @@ class ResNet50Runner:
             # fp32 parity mode / ragged groups / tiny groups (the fused form declined before launching anything):
             # plain convolution, then the shifted statistics pass over the stored output
             conv()
-            affine = ops.bn_batch_stats(y2d, grows, gamma, beta, eps)
+            affine = ops.bn_batch_stats(y2d, grows, gamma, beta, eps, code=dcode)
         if defer:
             return y, affine
         return finish(affine[0], affine[1], grows, gmax)
@@ -325,7 +335,7 @@ class ResNet50Runner:
         uniform = bool((sizes == gsz).all())
         groups = {hw: ((group_frames * hw).to(dev), gsz * hw, uniform)
                   for hw in (112 * 112, 56 * 56, 28 * 28, 14 * 14, 7 * 7)}
-        use_local = self.bn_local and self.bn_mode == "batch" and uniform and dt == torch.bfloat16
+        use_local = self.bn_local and self.bn_mode == "batch" and uniform and (dt == torch.bfloat16 or self.h2)
         plan = iter(self._local_plan(n, gsz)) if use_local else None
 
         def slot():
@@ -345,7 +355,7 @@ class ResNet50Runner:
             if raw:
                 x_aff = (sc0, sh0)
         else:
-            x0 = ops.frames_normalize(frames_u8, dt, 1.0, RESNET_MEAN, RESNET_STD, 230, 232, 3, 3)
+            x0 = ops.frames_normalize(frames_u8, dt, 1.0, RESNET_MEAN, RESNET_STD, 230, 232, 3, 3, code=self.code)
             geom, xs, _ = self._stem_geom(n)
             x = self._conv_bn(geom, xs, x0, w["stem"], w["bn1"], groups, local=stem_local, algo_k=147, pool=(3, 2, 1))
             del x0
@@ -407,7 +417,7 @@ class ResNet50Runner:
                               in_affine=aff2, res_affine=affd)
             del t2, idn
             hcur = hout
-        return ops.global_avgpool(x, out)
+        return ops.global_avgpool(x, out, code=self.code)
 
 
 # ============================================================================ Inception-v3 container

@@ -55,6 +55,51 @@ __device__ __forceinline__ unsigned avs_relu_bf16x2(unsigned v) {
   return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(avs_s16x2, v), z));
 }
 
+// ---- AVS_F16X2: a value as TWO fp16, x ~ hi + lo (hi = fp16(x), lo = fp16(x - hi): 22 significant bits, absolute
+// floor 2^-25 from the fp16 denormals), stored in 4-byte slots like fp32: every aligned run of 8 slots (32 bytes)
+// holds the 8 hi halves, then the 8 lo halves, of 8 consecutive elements.  Magnitudes saturate at 65504.
+typedef _Float16 avs_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 avs_f16x2v __attribute__((ext_vector_type(2)));
+#define AVS_F16_MAX 65504.0f
+
+__device__ __forceinline__ unsigned avs_pack_f16x2(float a, float b) {
+  const avs_f16x2v h = {(_Float16)a, (_Float16)b};   // v_cvt_f16_f32: RNE
+  return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ void avs_unpack_f16x2(unsigned u, float& a, float& b) {
+  const avs_f16x2v h = __builtin_bit_cast(avs_f16x2v, u);
+  a = (float)h[0];
+  b = (float)h[1];
+}
+// 8 fp32 -> the 16 bytes of hi halves and the 16 bytes of lo halves
+__device__ __forceinline__ void avs_f16x2_split8(const float (&v)[8], uint4& hi, uint4& lo) {
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a = fminf(fmaxf(v[2 * j], -AVS_F16_MAX), AVS_F16_MAX);
+    const float b = fminf(fmaxf(v[2 * j + 1], -AVS_F16_MAX), AVS_F16_MAX);
+    h[j] = avs_pack_f16x2(a, b);
+    float ha, hb;
+    avs_unpack_f16x2(h[j], ha, hb);
+    l[j] = avs_pack_f16x2(a - ha, b - hb);
+  }
+  hi = make_uint4(h[0], h[1], h[2], h[3]);
+  lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+__device__ __forceinline__ void avs_f16x2_join8(const uint4& hi, const uint4& lo, float (&v)[8]) {
+  const unsigned h[4] = {hi.x, hi.y, hi.z, hi.w}, l[4] = {lo.x, lo.y, lo.z, lo.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float ha, hb, la, lb;
+    avs_unpack_f16x2(h[j], ha, hb);
+    avs_unpack_f16x2(l[j], la, lb);
+    v[2 * j] = ha + la;
+    v[2 * j + 1] = hb + lb;
+  }
+}
+// element type tag of the elementwise kernels: ONE slot (4 bytes); only whole runs of 8 are ever loaded or stored
+struct avs_h2_tag { unsigned bits; };
+
 template <typename T> struct avs_elem;
 template <> struct avs_elem<float> {
   static __device__ __forceinline__ float load(const float* p) { return *p; }

@@ -154,12 +154,16 @@ __device__ __forceinline__ uint4 avs_lds_read_b128(unsigned byte_addr) {
 // a row's padding test is one bit of a per-row tap mask built once, and a DMA source is base + scalar offset.
 // (Measured on the 3x3 layers: the general staging code issues ~180 vector + scalar instructions per 16 MFMAs and
 // the loop ran at 45 % matrix-core occupancy for that reason alone - with no staging at all it reaches 1.5 PFLOP/s.)
+// SPLIT: 0 = operands as stored; 1 = AVS_F32_SPLIT (fp32 operands split into bf16 hi + lo in the loop);
+// 2 = AVS_F16X2 (operands ARE stored as fp16 hi + lo runs: the 16-byte chunks of a step alternate hi8 | lo8, so the
+// fragments need no arithmetic at all - three v_mfma_f32_32x32x16_f16 per 16 reduction elements - and the epilogue
+// splits each output once, where it is produced, instead of every consumer splitting it per tile and step)
 template <int ES, int BN, bool ACC64, bool SPATIAL, int ROWB, int EPI, bool PIPE, int WR = 2, bool FASTK = false,
-          bool SPLIT = false>
+          int SPLIT = 0>
 __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64 && ES == 2) ? 4 : 3) : 2) void igemm_kernel(
     IgemmParams p) {
-  static_assert(!SPLIT || (ES == 4 && !ACC64), "the split-bf16 arithmetic is for fp32 operands");
-  static_assert(WR == 2 || (WR == 4 && !ACC64 && (ES == 2 || SPLIT)),
+  static_assert(SPLIT == 0 || (ES == 4 && !ACC64), "the split arithmetic is for 4-byte operands");
+  static_assert(WR == 2 || (WR == 4 && !ACC64 && (ES == 2 || SPLIT != 0)),
                 "256-row tiles are built for the bf16 variants and the fp32-split arithmetic");
   static_assert(!PIPE || (ROWB == 64 && !ACC64), "the 3-buffer pipeline is built for the 64-byte-row variants");
   static_assert(!ACC64 || (ES == 4 && BN == 64), "fp64 slice accumulation: fp32 operands, narrow tile only");
@@ -184,7 +188,12 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
   constexpr int TAB_SLOTS = EPI == EPI_BNLOCAL ? (BNLOCAL_MAX_GROUPS * 2 * BN * 4) / 16
                             : EPI == EPI_STATS ? (WR * 2 * 2 * BN * 4) / 16
                                                : 0;
-  constexpr int LDS_SLOTS = NBUF * BUF > CT_SLOTS + TAB_SLOTS ? NBUF * BUF : CT_SLOTS + TAB_SLOTS;
+  // AVS_F16X2 epilogue: every wave stages 32 of its rows at a time as fp32, row-major (pitch WCOLS + 8 words), and
+  // reads them back as runs of 8 columns; the statistics tables alias those regions (a barrier separates the uses)
+  constexpr int H2_P = WCOLS + 8;                               // words per staged row
+  constexpr int H2_SLOTS = SPLIT == 2 ? (4 * 32 * H2_P * 4) / 16 : 0;
+  constexpr int LDS_BASE = NBUF * BUF > CT_SLOTS + TAB_SLOTS ? NBUF * BUF : CT_SLOTS + TAB_SLOTS;
+  constexpr int LDS_SLOTS = LDS_BASE > H2_SLOTS ? LDS_BASE : H2_SLOTS;
 
   __shared__ uint4 lds[LDS_SLOTS];
 
@@ -428,7 +437,9 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
     unsigned fa_off[2][KS], fb_off[NT][KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const int chunk = 2 * ks + lh;
+      // AVS_F16X2: the chunks of a row alternate hi8 | lo8; sub-step pair (ks, ks + 1) = (hi, lo) of the 8 elements
+      // this lane half feeds
+      const int chunk = SPLIT == 2 ? 2 * (ks & ~1) + 2 * lh + (ks & 1) : 2 * ks + lh;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         const int row = wr * 64 + mt * 32 + lr;
@@ -466,7 +477,48 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
       // passed THROUGH an empty asm ("+v"), so that no use of them - not even a register copy the compiler may want -
       // can be scheduled ahead of the wait.  (A copy placed before the wait reads a register whose LDS data has not
       // landed: seen as size-dependent garbage when a runtime branch made the compiler copy the fragments.)
-      if constexpr (SPLIT) {
+      if constexpr (SPLIT == 2) {
+        // operands stored as fp16 hi | lo runs: sub-step kp holds the hi fragments, kp + 1 the lo fragments of the same
+        // 16 reduction elements; hi*hi starts as soon as the hi fragments have landed
+        static_assert(KS == 2, "the pipelined loop runs on 64-byte rows: one hi / lo pair of sub-steps per step");
+        {
+          constexpr int kp = 0;
+          asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 + NT) : "memory");
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) avs_pin(fa[kp][mt]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) avs_pin(fb[kp][nt]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(avs_f16x8, fa[kp][mt]),
+                                                                   __builtin_bit_cast(avs_f16x8, fb[kp][nt]),
+                                                                   acc[mt][nt], 0, 0, 0);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) avs_pin(fa[kp + 1][mt]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) avs_pin(fb[kp + 1][nt]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(avs_f16x8, fa[kp + 1][mt]),
+                                                                   __builtin_bit_cast(avs_f16x8, fb[kp][nt]),
+                                                                   acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(avs_f16x8, fa[kp][mt]),
+                                                                   __builtin_bit_cast(avs_f16x8, fb[kp + 1][nt]),
+                                                                   acc[mt][nt], 0, 0, 0);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        cur = cur == 2 ? 0 : cur + 1;
+        continue;
+      }
+      if constexpr (SPLIT == 1) {
         // fp32 operands on the bf16 matrix cores: the fragments of two sub-steps (8 reduction elements per lane, the
         // same lane -> k map for A and B) are split into hi / lo and contracted as lo*hi + hi*lo + hi*hi
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -545,7 +597,7 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
       uint4 fa[KS][2], fb[KS][NT];
   #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const int chunk = 2 * ks + lh;
+        const int chunk = SPLIT == 2 ? 2 * (ks & ~1) + 2 * lh + (ks & 1) : 2 * ks + lh;
   #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
           const int row = wr * 64 + mt * 32 + lr;
@@ -561,7 +613,21 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
       //    that ended the previous step.  It is in flight during the MFMAs below.
       if (s + 1 < steps) stage(buf ^ 1);
       // 3. matrix cores
-      if constexpr (SPLIT) {
+      if constexpr (SPLIT == 2) {
+#pragma unroll
+        for (int kp = 0; kp < KS; kp += 2)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              const avs_f16x8 ah = __builtin_bit_cast(avs_f16x8, fa[kp][mt]), al = __builtin_bit_cast(avs_f16x8, fa[kp + 1][mt]);
+              const avs_f16x8 bh = __builtin_bit_cast(avs_f16x8, fb[kp][nt]), bl = __builtin_bit_cast(avs_f16x8, fb[kp + 1][nt]);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[mt][nt], 0, 0, 0);
+            }
+      }
+      if constexpr (SPLIT == 1) {
 #pragma unroll
         for (int kp = 0; kp < KS; kp += 2) {
           bf16x8 ah[2], al[2], bh[NT], bl[NT];
@@ -581,7 +647,7 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
             }
         }
       }
-      if constexpr (!SPLIT) {
+      if constexpr (SPLIT == 0) {
   #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
   #pragma unroll
@@ -621,6 +687,252 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
   }
 
   // ---- epilogue ----
+  if constexpr (SPLIT == 2) {
+    // AVS_F16X2 output.  Statistics (EPI_STATS / EPI_BNLOCAL) are taken in TWO rounds over the fp32 accumulators: column
+    // sums -> the mean of the rows a tile holds of each group -> sums of squares ABOUT that mean, so nothing cancels
+    // however large mean^2 / var is (a constant frame, a dead channel); tiles of one group are merged by Chan's update
+    // in tile order (bn_fold_kernel).  Deterministic: fixed orders, no atomics.
+    // Output: every wave stages 32 of its rows at a time in LDS as fp32 (row-major) and reads them back as runs of 8
+    // columns: residual added and ReLU applied in fp32, then ONE split into fp16 hi | lo and two 16-byte stores.
+    static_assert(EPI == EPI_PLAIN || EPI == EPI_STATS || EPI == EPI_BNLOCAL, "epilogue forms built for AVS_F16X2");
+    static_assert(EPI != EPI_BNLOCAL || WR == 4, "the tile-local BatchNorm runs on the 256-row tiles");
+    float* const fl = reinterpret_cast<float*>(lds);
+    // masked sums over this lane's 32 rows of column tile nt: rows with lo <= roff < hi (roff = row inside the wave's
+    // 64 rows minus 4 * lh); both lane halves return the column's total over the wave's rows
+    auto wave_sum = [&](int nt, int lo, int hi) -> float {
+      float s = 0.f;
+      if (lo <= 0 && hi >= 64) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) s += acc[mt][nt][e];
+      } else {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int roff = mt * 32 + (e & 3) + 8 * (e >> 2);
+            s += (roff >= lo && roff < hi) ? acc[mt][nt][e] : 0.f;
+          }
+      }
+      return s + __shfl_xor(s, 32, 64);
+    };
+    auto wave_sq = [&](int nt, int lo, int hi, float mean) -> float {
+      float s = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int roff = mt * 32 + (e & 3) + 8 * (e >> 2);
+          const float d = acc[mt][nt][e] - mean;
+          s = (roff >= lo && roff < hi) ? fmaf(d, d, s) : s;
+        }
+      return s + __shfl_xor(s, 32, 64);
+    };
+    // per-lane BatchNorm affines of the (up to three) groups this wave's rows lie in (EPI_BNLOCAL)
+    float sc0[NT], sf0[NT], sc1[NT], sf1[NT], sc2[NT], sf2[NT];
+    int bnd1 = 1 << 30, bnd2 = 1 << 30;   // first roff of the wave's second / third group
+    int used = A_ROWS;                    // EPI_BNLOCAL: rows of this tile that exist
+    if constexpr (EPI == EPI_STATS) {
+      const int rpg = p.rows_per_group;
+      float* const T1 = fl;                      // [WR][2][BN] sums of the wave rows' (at most two) groups
+      float* const T2 = fl + WR * 2 * BN;        // [WR][2][BN] sums of squares about the tile's group mean
+      const int tile_end = (m0 + A_ROWS < p.M ? m0 + A_ROWS : p.M);
+      const int r_first = m0 + wr * 64;
+      const bool live = r_first < p.M;
+      int g0 = 0, g1 = -1, r_end = r_first;
+      if (live) {
+        r_end = (r_first + 64 < p.M ? r_first + 64 : p.M);     // one past the wave's last existing row
+        g0 = r_first / rpg;
+        g1 = (r_end - 1) / rpg;                                 // g1 - g0 <= 1 (rows_per_group >= 64)
+      }
+      // round 1: column sums per group of the wave's rows
+      for (int g = g0; g <= g1; ++g) {
+        const int lo = (g * rpg > r_first ? g * rpg : r_first) - r_first - 4 * lh;
+        const int hi = ((g + 1) * rpg < r_end ? (g + 1) * rpg : r_end) - r_first - 4 * lh;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const float s = wave_sum(nt, lo, hi);
+          if (lh == 0) T1[(wr * 2 + (g - g0)) * BN + wc * WCOLS + nt * 32 + lr] = s;
+        }
+      }
+      __syncthreads();
+      // the sum of group g over the tile = the wave rows that hold rows of it, added in wave-row order
+      auto tile_total = [&](const float* T, int g, int cc) -> float {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < WR; ++r) {
+          const int rf = m0 + r * 64;
+          if (rf >= p.M) break;
+          const int re = (rf + 64 < p.M ? rf + 64 : p.M);
+          const int a = rf / rpg, b = (re - 1) / rpg;
+          if (g >= a && g <= b) s += T[(r * 2 + (g - a)) * BN + cc];
+        }
+        return s;
+      };
+      // round 2: sums of squares about the mean of the rows this TILE holds of the group
+      for (int g = g0; g <= g1; ++g) {
+        const int lo = (g * rpg > r_first ? g * rpg : r_first) - r_first - 4 * lh;
+        const int hi = ((g + 1) * rpg < r_end ? (g + 1) * rpg : r_end) - r_first - 4 * lh;
+        const int n_g = ((g + 1) * rpg < tile_end ? (g + 1) * rpg : tile_end) - (g * rpg > m0 ? g * rpg : m0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int cc = wc * WCOLS + nt * 32 + lr;
+          const float mean = tile_total(T1, g, cc) / (float)n_g;
+          const float s = wave_sq(nt, lo, hi, mean);
+          if (lh == 0) T2[(wr * 2 + (g - g0)) * BN + cc] = s;
+        }
+      }
+      __syncthreads();
+      {
+        const int g_lo = m0 / rpg;
+        const int nj = (tile_end - 1) / rpg - g_lo + 1;  // <= p.stat_slots
+        for (int i = t; i < nj * BN; i += 256) {
+          const int j = i / BN, cc = i - j * BN;
+          if (n0 + cc < p.N) {
+            float* dst = p.stat_part + (((long long)tm * p.stat_slots + j) * 2) * p.N + n0 + cc;
+            dst[0] = tile_total(T1, g_lo + j, cc);
+            dst[p.N] = tile_total(T2, g_lo + j, cc);
+          }
+        }
+      }
+      __syncthreads();   // the tables alias the staging regions
+    }
+    if constexpr (EPI == EPI_BNLOCAL) {
+      const int rpg = p.rows_per_group;
+      used = (m0 + p.tile_rows <= p.M ? p.tile_rows : p.M - m0);
+      const int ng = used / rpg;                   // whole groups (M is a multiple of rpg)
+      float* const R1 = fl;                        // [WR][ng][BN]
+      float* const R2 = fl + WR * BNLOCAL_MAX_GROUPS * BN;
+      float* const TAB = R2 + WR * BNLOCAL_MAX_GROUPS * BN;   // [ng][scale | shift][BN]
+      const int w_first = wr * 64;
+      const bool live = w_first < used;
+      int k0 = 0, k1 = -1, w_end = w_first;
+      if (live) {
+        w_end = (w_first + 64 < used ? w_first + 64 : used);
+        k0 = w_first / rpg;
+        k1 = (w_end - 1) / rpg;
+      }
+      for (int k = k0; k <= k1; ++k) {
+        const int lo = (k * rpg > w_first ? k * rpg : w_first) - w_first - 4 * lh;
+        const int hi = ((k + 1) * rpg < w_end ? (k + 1) * rpg : w_end) - w_first - 4 * lh;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const float s = wave_sum(nt, lo, hi);
+          if (lh == 0) R1[(wr * ng + k) * BN + wc * WCOLS + nt * 32 + lr] = s;
+        }
+      }
+      __syncthreads();
+      auto tile_total = [&](const float* R, int k, int cc) -> float {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < WR; ++r) {
+          if (r * 64 >= used) break;
+          const int re = (r * 64 + 64 < used ? r * 64 + 64 : used);
+          const int a = (r * 64) / rpg, b = (re - 1) / rpg;
+          if (k >= a && k <= b) s += R[(r * ng + k) * BN + cc];
+        }
+        return s;
+      };
+      const float inv_n = 1.f / (float)rpg;
+      for (int k = k0; k <= k1; ++k) {
+        const int lo = (k * rpg > w_first ? k * rpg : w_first) - w_first - 4 * lh;
+        const int hi = ((k + 1) * rpg < w_end ? (k + 1) * rpg : w_end) - w_first - 4 * lh;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int cc = wc * WCOLS + nt * 32 + lr;
+          const float s = wave_sq(nt, lo, hi, tile_total(R1, k, cc) * inv_n);
+          if (lh == 0) R2[(wr * ng + k) * BN + cc] = s;
+        }
+      }
+      __syncthreads();
+      for (int i = t; i < ng * BN; i += 256) {
+        const int k = i / BN, cc = i - k * BN;
+        const float mean = tile_total(R1, k, cc) * inv_n;
+        const float var = tile_total(R2, k, cc) * inv_n;
+        const int col = n0 + cc;
+        const float sc = (col < p.N ? p.gamma[col] : 0.f) / sqrtf(var + p.eps);
+        TAB[(2 * k) * BN + cc] = sc;
+        TAB[(2 * k + 1) * BN + cc] = (col < p.N ? p.beta[col] : 0.f) - mean * sc;
+      }
+      __syncthreads();
+      {
+        const int kmax = ng > 0 ? ng - 1 : 0;
+        const int kb0 = k0 < kmax ? k0 : kmax;
+        const int kb1 = kb0 + 1 < kmax ? kb0 + 1 : kmax, kb2 = kb0 + 2 < kmax ? kb0 + 2 : kmax;
+        bnd1 = (kb0 + 1) * rpg - w_first - 4 * lh;
+        bnd2 = bnd1 + rpg;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int cc = wc * WCOLS + nt * 32 + lr;
+          sc0[nt] = TAB[(2 * kb0) * BN + cc], sf0[nt] = TAB[(2 * kb0 + 1) * BN + cc];
+          sc1[nt] = TAB[(2 * kb1) * BN + cc], sf1[nt] = TAB[(2 * kb1 + 1) * BN + cc];
+          sc2[nt] = TAB[(2 * kb2) * BN + cc], sf2[nt] = TAB[(2 * kb2 + 1) * BN + cc];
+        }
+      }
+      __syncthreads();   // the tables alias the staging regions
+    }
+    // ---- staging + stores, 32 rows of the wave at a time
+    constexpr int G = WCOLS / 8;            // runs of 8 columns per staged row
+    constexpr int NU = (32 * G) / 64;       // runs per lane and half
+    float* const wreg = fl + wave * (32 * H2_P);
+    const bool relu = EPI == EPI_BNLOCAL && p.act == AVS_ACT_RELU;
+    const bool aligned_rows = (p.ldc % 8 == 0);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int rl = (e & 3) + 8 * (e >> 2);   // + 4 * lh = the row inside this half
+          float v = acc[mt][nt][e];
+          if constexpr (EPI == EPI_BNLOCAL) {
+            const int roff = mt * 32 + rl;
+            const bool in1 = roff >= bnd1, in2 = roff >= bnd2;
+            const float sc = in2 ? sc2[nt] : (in1 ? sc1[nt] : sc0[nt]);
+            const float sf = in2 ? sf2[nt] : (in1 ? sf1[nt] : sf0[nt]);
+            v = fmaf(v, sc, sf);
+          }
+          wreg[(rl + 4 * lh) * H2_P + nt * 32 + lr] = v;
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < NU; ++it) {
+        const int u = it * 64 + lane;
+        const int rl = u / G, grp = u % G;
+        const int trow = wr * 64 + mt * 32 + rl;               // row inside the tile
+        const long long row = (long long)m0 + trow;
+        const int col = n0 + wc * WCOLS + grp * 8;
+        const bool ok = (EPI == EPI_BNLOCAL ? trow < used : row < p.M) && col < p.N;
+        const float4 f0 = *reinterpret_cast<const float4*>(wreg + rl * H2_P + grp * 8);
+        const float4 f1 = *reinterpret_cast<const float4*>(wreg + rl * H2_P + grp * 8 + 4);
+        if (!ok) continue;
+        float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+        if constexpr (EPI == EPI_BNLOCAL) {
+          if (p.residual) {
+            const uint4* rp = reinterpret_cast<const uint4*>(p.residual + (row * p.ldr + col) * 4);
+            float rv[8];
+            avs_f16x2_join8(rp[0], rp[1], rv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += rv[j];
+          }
+          if (relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+          }
+        }
+        uint4 hi, lo;
+        avs_f16x2_split8(v, hi, lo);
+        uint4* dst = reinterpret_cast<uint4*>(y + (row * p.ldc + col) * 4);
+        dst[0] = hi;
+        dst[1] = lo;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    }
+    (void)aligned_rows;
+  } else {
   // Register e of a 32x32 tile is row (e&3) + 8*(e>>2) + 4*lh, column lr.
   constexpr int E_CPRW = BN / 8;           // 16-byte chunks per bf16 tile row
   constexpr int E_RSTEP = 256 / E_CPRW;    // tile rows covered by one pass of the 256 threads
@@ -1005,6 +1317,7 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
       }
     stats_fold();
   }
+  }  // SPLIT != 2
 }
 
 #ifdef AVS_STUDY
@@ -1038,15 +1351,26 @@ static void igemm_dispatch_epi4(int epi, dim3 grid, hipStream_t stream, const Ig
     }
   }
   if constexpr (ES == 4 && !ACC64) {
+    if (p.split == 2) {         // AVS_F16X2: operands stored as fp16 hi | lo runs, three fp16 MFMAs per product
+      if (epi == EPI_PLAIN)
+        hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_PLAIN, PIPE, WR, FK, 2>), grid, dim3(256), 0, stream, p);
+      else if (epi == EPI_STATS)
+        hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE, WR, FK, 2>), grid, dim3(256), 0, stream, p);
+      else if constexpr (WR == 4) {
+        if (epi == EPI_BNLOCAL)
+          hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BNLOCAL, PIPE, WR, FK, 2>), grid, dim3(256), 0, stream, p);
+      }
+      return;
+    }
     if (p.split || WR == 4) {   // AVS_F32_SPLIT: the same tiles, products as three bf16 MFMAs (WR = 4 exists for it only)
       if (epi == EPI_PLAIN)
-        hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_PLAIN, PIPE, WR, FK, true>), grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_PLAIN, PIPE, WR, FK, 1>), grid, dim3(256), 0, stream, p);
       else if (epi == EPI_STATS)
-        hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE, WR, FK, true>), grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE, WR, FK, 1>), grid, dim3(256), 0, stream, p);
       else if (epi == EPI_BRELU)
-        hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BRELU, PIPE, WR, FK, true>), grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BRELU, PIPE, WR, FK, 1>), grid, dim3(256), 0, stream, p);
       else if constexpr (WR == 2)
-        hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_ANY, PIPE, WR, FK, true>), grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_ANY, PIPE, WR, FK, 1>), grid, dim3(256), 0, stream, p);
       return;
     }
   }
@@ -1141,11 +1465,18 @@ static void igemm_dispatch(bool spatial, dim3 grid, hipStream_t stream, const Ig
 static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream, const char* who,
                         bool plan_only = false, long long* tiles_m_out = nullptr) {
   const int es = dtype == AVS_BF16 ? 2 : 4;
-  p.split = dtype == AVS_F32_SPLIT ? 1 : 0;
-  const int ce = 16 / es;
-  AVS_REQUIRE(dtype == AVS_F32 || dtype == AVS_BF16 || dtype == AVS_F32_ACC64 || dtype == AVS_F32_SPLIT, AVS_E_ARG,
-              "%s: bad dtype %d", who,
-              dtype);
+  p.split = dtype == AVS_F32_SPLIT ? 1 : (dtype == AVS_F16X2 ? 2 : 0);
+  const int ce = dtype == AVS_F16X2 ? 8 : 16 / es;   // AVS_F16X2: whole hi | lo runs of 8 slots
+  AVS_REQUIRE(dtype == AVS_F32 || dtype == AVS_BF16 || dtype == AVS_F32_ACC64 || dtype == AVS_F32_SPLIT ||
+                  dtype == AVS_F16X2, AVS_E_ARG, "%s: bad dtype %d", who, dtype);
+  if (dtype == AVS_F16X2) {
+    const bool fixed = p.alpha == 1.0f && p.bias_mode == AVS_BIAS_NONE && (p.act == AVS_ACT_NONE || p.tile_rows);
+    AVS_REQUIRE(fixed, AVS_E_UNSUPPORTED, "%s: AVS_F16X2 takes no bias / scaling / activation outside the BatchNorm form", who);
+    AVS_REQUIRE(p.N % 8 == 0 && p.ldc % 8 == 0 && (p.sC % 8) == 0, AVS_E_SHAPE,
+                "%s: AVS_F16X2 needs cout and the output strides in multiples of 8 slots", who);
+    AVS_REQUIRE(plan_only || ((((uintptr_t)p.x) | ((uintptr_t)p.w) | ((uintptr_t)p.y)) & 31u) == 0, AVS_E_ALIGN,
+                "%s: AVS_F16X2 operands must be 32-byte aligned", who);
+  }
   AVS_REQUIRE(p.M >= 0 && p.N > 0 && p.K > 0 && batch > 0, AVS_E_SHAPE, "%s: bad sizes M=%d N=%d K=%d batch=%d", who,
               p.M, p.N, p.K, batch);
   if (p.M == 0) return AVS_OK;
@@ -1155,9 +1486,10 @@ static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream
               "%s: cin=%d / K=%d must be multiples of %d elements (16 bytes)", who, p.cin, p.K, ce);
   AVS_REQUIRE(plan_only || (avs_aligned16(p.x) && avs_aligned16(p.w)), AVS_E_ALIGN, "%s: x / w must be 16-byte aligned",
               who);
-  AVS_REQUIRE((p.x_img_stride * es) % 16 == 0 && (p.x_row_stride * es) % 16 == 0 && (p.x_px_stride * es) % 16 == 0 &&
-                  (p.ldb * es) % 16 == 0 && (p.sA * es) % 16 == 0 && (p.sB * es) % 16 == 0,
-              AVS_E_ALIGN, "%s: strides must be multiples of 16 bytes", who);
+  AVS_REQUIRE((p.x_img_stride * es) % (ce * es) == 0 && (p.x_row_stride * es) % (ce * es) == 0 &&
+                  (p.x_px_stride * es) % (ce * es) == 0 && (p.ldb * es) % (ce * es) == 0 && (p.sA * es) % (ce * es) == 0 &&
+                  (p.sB * es) % (ce * es) == 0,
+              AVS_E_ALIGN, "%s: strides must be multiples of %d bytes", who, ce * es);
   AVS_REQUIRE(p.ldc >= p.N, AVS_E_SHAPE, "%s: output row stride %lld < N=%d", who, p.ldc, p.N);
   AVS_REQUIRE(batch <= 65535, AVS_E_SHAPE, "%s: batch %d > 65535", who, batch);
 
@@ -1171,8 +1503,8 @@ static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream
     const bool fixed_epi = p.alpha == 1.0f &&
                            ((p.bias_mode == AVS_BIAS_NONE && p.act == AVS_ACT_NONE) ||
                             (p.bias_mode == AVS_BIAS_COL && p.act == AVS_ACT_RELU && !p.stat_part));
-    const bool can = (dtype == AVS_BF16 || dtype == AVS_F32_SPLIT) && fixed_epi && g_pipe3 && (long long)p.K * es > 128 &&
-                     batch == 1;
+    const bool can = (dtype == AVS_BF16 || dtype == AVS_F32_SPLIT || dtype == AVS_F16X2) && fixed_epi && g_pipe3 &&
+                     (long long)p.K * es > 128 && batch == 1;
     const long long tall_tiles = ((long long)p.M + 255) / 256 * p.tiles_n;
     if (can && (g_tall_mode == 2 || (g_tall_mode == 0 && tall_tiles >= g_tall_min_tiles &&
                                      (narrow || (long long)p.K * es >= g_tall_min_k_bytes))))
@@ -1272,16 +1604,38 @@ extern "C" int avs_conv2d_nhwc(const avs_conv_desc* d, const void* d_x, const vo
 // ---- convolution + deterministic BatchNorm batch statistics (EPI_STATS) ----
 // One thread per (group, channel): the group's slots are added in row-tile order, then folded into the affine
 //   scale = gamma / sqrt(var + eps), shift = beta - mean * scale   (biased variance, E[y^2] - E[y]^2 on fp32 sums).
+// chan = 1 (AVS_F16X2): a slot holds (sum, sum of squares about the TILE's mean of the group's rows it holds); the tiles
+// of a group are merged by Chan's update in tile order - no E[y^2] - E[y]^2 anywhere.
 __global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ part, long long total, int c, int slots,
                                                       int tile_rows, long long rpg, long long rows,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      float eps, float* __restrict__ scale, float* __restrict__ shift) {
+                                                      float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                                      int chan) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const long long g = i / c;
     const int ch = (int)(i - g * c);
     const long long first = g * rpg, last = (first + rpg < rows ? first + rpg : rows) - 1;
     float s1 = 0.f, s2 = 0.f;
+    if (chan) {
+      float n = 0.f, mean = 0.f, m2 = 0.f;
+      for (long long tl = first / tile_rows; tl <= last / tile_rows; ++tl) {
+        const long long j = g - (tl * tile_rows) / rpg;
+        const float* src = part + ((tl * slots + j) * 2) * c + ch;
+        const long long lo = first > tl * tile_rows ? first : tl * tile_rows;
+        const long long hi = last + 1 < (tl + 1) * tile_rows ? last + 1 : (tl + 1) * tile_rows;
+        const float nt = (float)(hi - lo);
+        const float mt = src[0] / nt;
+        const float d = mt - mean, nn = n + nt;
+        mean = mean + d * (nt / nn);
+        m2 = m2 + src[c] + d * d * (n * nt / nn);
+        n = nn;
+      }
+      const float sc = gamma[ch] / sqrtf(m2 / n + eps);
+      scale[i] = sc;
+      shift[i] = beta[ch] - mean * sc;
+      continue;
+    }
     for (long long tl = first / tile_rows; tl <= last / tile_rows; ++tl) {
       const long long j = g - (tl * tile_rows) / rpg;
       const float* src = part + ((tl * slots + j) * 2) * c + ch;
@@ -1299,8 +1653,8 @@ __global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ 
 
 static int bnstats_plan(const avs_conv_desc* d, int64_t rpg, IgemmParams& p, int64_t* ws_bytes, int* tile_rows,
                         const char* who) {
-  AVS_REQUIRE(d != nullptr && (d->dtype == AVS_BF16 || d->dtype == AVS_F32 || d->dtype == AVS_F32_SPLIT), AVS_E_ARG,
-              "%s: bf16 / fp32 only", who);
+  AVS_REQUIRE(d != nullptr && (d->dtype == AVS_BF16 || d->dtype == AVS_F32 || d->dtype == AVS_F32_SPLIT ||
+                               d->dtype == AVS_F16X2), AVS_E_ARG, "%s: bf16 / fp32 / f16x2 only", who);
   AVS_REQUIRE(d->act == AVS_ACT_NONE && d->alpha == 1.0f, AVS_E_ARG, "%s: no activation / scaling", who);
   AVS_REQUIRE(rpg > 0 && rpg < (1ll << 30), AVS_E_ARG, "%s: rows_per_group must be positive", who);
   AVS_REQUIRE(rpg >= STATS_MIN_GROUP_ROWS, AVS_E_UNSUPPORTED,
@@ -1357,7 +1711,7 @@ extern "C" int avs_conv2d_nhwc_bnstats(const avs_conv_desc* d, const void* d_x, 
   if (gx > 8192) gx = 8192;
   hipLaunchKernelGGL(bn_fold_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, p.stat_part, total, p.N,
                      p.stat_slots, tile_rows, (long long)rows_per_group, (long long)p.M, d_gamma, d_beta, eps, d_scale,
-                     d_shift);
+                     d_shift, d->dtype == AVS_F16X2 ? 1 : 0);
   AVS_CHECK_LAUNCH(who);
   return AVS_OK;
 }
@@ -1373,12 +1727,14 @@ static int bnlocal_plan(const avs_conv_desc* d, int64_t rpg, IgemmParams& p, con
   if (p.M == 0) return AVS_OK;
   const int bn = p.N <= 64 ? 64 : 128;
   const long long per_tile = 256 / rpg;
-  const bool ok = g_bnlocal && g_pipe3 && d->dtype == AVS_BF16 && p.N % bn == 0 && p.M % rpg == 0 && rpg <= 256 &&
-                  per_tile * rpg * 4 >= 256 * 3 && per_tile <= BNLOCAL_MAX_GROUPS && (long long)p.K * 2 > 128 &&
-                  d->alpha == 1.0f && (p.ldc * 2) % 16 == 0;
+  const bool h2 = d->dtype == AVS_F16X2;
+  const int es = h2 ? 4 : 2;
+  const bool ok = g_bnlocal && g_pipe3 && (d->dtype == AVS_BF16 || h2) && p.N % bn == 0 && p.M % rpg == 0 && rpg <= 256 &&
+                  per_tile * rpg * 4 >= 256 * 3 && per_tile <= BNLOCAL_MAX_GROUPS && (long long)p.K * es > 128 &&
+                  d->alpha == 1.0f && (p.ldc * es) % (h2 ? 32 : 16) == 0;
   AVS_REQUIRE(ok, AVS_E_UNSUPPORTED,
-              "%s: needs bf16, cout a multiple of %d, equal groups of 43..256 rows that fill 3/4 of a 256-row tile, "
-              "a reduction of more than 128 bytes, 16-byte aligned output rows", who, bn);
+              "%s: needs bf16 / f16x2, cout a multiple of %d, equal groups of 43..256 rows that fill 3/4 of a 256-row "
+              "tile, a reduction of more than 128 bytes, aligned output rows", who, bn);
   p.tiles_n = p.N / bn;
   p.tile_rows = (int)(per_tile * rpg);
   return AVS_OK;
@@ -1400,8 +1756,11 @@ extern "C" int avs_conv2d_nhwc_bnlocal(const avs_conv_desc* d, const void* d_x, 
   if (p.M == 0) return AVS_OK;
   AVS_REQUIRE(d_x && d_w && d_y && d_gamma && d_beta, AVS_E_ARG, "%s: null pointer", who);
   AVS_REQUIRE(avs_aligned16(d_y), AVS_E_ALIGN, "%s: y must be 16-byte aligned", who);
+  const bool h2 = d->dtype == AVS_F16X2;
   AVS_REQUIRE(!d_residual || (avs_aligned16(d_residual) && (ldr * 2) % 16 == 0 && ldr >= p.N), AVS_E_ALIGN,
               "%s: residual rows must be 16-byte aligned and at least cout long", who);
+  AVS_REQUIRE(!h2 || !d_residual || ((((uintptr_t)d_residual) & 31u) == 0 && ldr % 8 == 0), AVS_E_ALIGN,
+              "%s: an AVS_F16X2 residual must be 32-byte aligned with a row stride in multiples of 8 slots", who);
   p.x = (const char*)d_x;
   p.w = (const char*)d_w;
   p.y = (char*)d_y;
@@ -1412,7 +1771,7 @@ extern "C" int avs_conv2d_nhwc_bnlocal(const avs_conv_desc* d, const void* d_x, 
   p.residual = (const char*)d_residual;
   p.ldr = ldr;
   p.bias_mode = AVS_BIAS_NONE;
-  return igemm_launch(AVS_BF16, p, 1, (hipStream_t)stream, who);
+  return igemm_launch(d->dtype, p, 1, (hipStream_t)stream, who);
 }
 
 extern "C" int avs_gemm_nt(int dtype, int m, int n, int k, const void* d_a, int64_t lda, int64_t stride_a,

@@ -45,10 +45,99 @@ __global__ __launch_bounds__(256) void frames_normalize_kernel(const uint8_t* __
   }
 }
 
+// AVS_F16X2 image: a thread writes two pixels = one run of 8 slots (2 x (3 channels + a zero channel))
+__global__ __launch_bounds__(256) void frames_normalize_h2_kernel(const uint8_t* __restrict__ src, int n, int h, int w,
+                                                                  NormParams np, uint4* __restrict__ out, int out_h,
+                                                                  int out_w, int pad_t, int pad_l) {
+  const int pw = out_w >> 1;
+  const long long total = (long long)n * out_h * pw;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % pw) * 2;
+    const long long t = i / pw;
+    const int oy = (int)(t % out_h);
+    const long long img = t / out_h;
+    const int sy = oy - pad_t;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int sx = ox + q - pad_l;
+      if ((unsigned)sy < (unsigned)h && (unsigned)sx < (unsigned)w) {
+        const uint8_t* s = src + ((img * h + sy) * (long long)w + sx) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float f = (float)s[c] / np.denom;
+          f = (f - np.mean[c]) / np.stdv[c];
+          if (np.has_affine) {
+            f = f * np.aff_a[c];
+            f = f + np.aff_b[c];
+          }
+          v[4 * q + c] = f;
+        }
+      }
+    }
+    uint4 hi, lo;
+    avs_f16x2_split8(v, hi, lo);
+    out[2 * i] = hi;
+    out[2 * i + 1] = lo;
+  }
+}
+
+// fp32 <-> AVS_F16X2 (weights are converted once per parameter version; tests read activations back)
+__global__ __launch_bounds__(256) void f16x2_pack_kernel(const float* __restrict__ src, uint4* __restrict__ dst,
+                                                         long long runs) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < runs; i += (long long)gridDim.x * blockDim.x) {
+    const float4 a = *reinterpret_cast<const float4*>(src + 8 * i), b = *reinterpret_cast<const float4*>(src + 8 * i + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint4 hi, lo;
+    avs_f16x2_split8(v, hi, lo);
+    dst[2 * i] = hi;
+    dst[2 * i + 1] = lo;
+  }
+}
+__global__ __launch_bounds__(256) void f16x2_unpack_kernel(const uint4* __restrict__ src, float* __restrict__ dst,
+                                                           long long runs) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < runs; i += (long long)gridDim.x * blockDim.x) {
+    float v[8];
+    avs_f16x2_join8(src[2 * i], src[2 * i + 1], v);
+    *reinterpret_cast<float4*>(dst + 8 * i) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(dst + 8 * i + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+}
+
+extern "C" int avs_f16x2_pack_f32(const float* d_src, void* d_dst, int64_t n, avs_stream_t stream) {
+  AVS_REQUIRE(n >= 0 && n % 8 == 0, AVS_E_SHAPE, "avs_f16x2_pack_f32: n = %lld must be a multiple of 8", (long long)n);
+  if (n == 0) return AVS_OK;
+  AVS_REQUIRE(d_src && d_dst, AVS_E_ARG, "avs_f16x2_pack_f32: null pointer");
+  AVS_REQUIRE(avs_aligned16(d_src) && (((uintptr_t)d_dst) & 31u) == 0, AVS_E_ALIGN,
+              "avs_f16x2_pack_f32: src must be 16-byte, dst 32-byte aligned");
+  long long gx = avs_cdiv(n / 8, 256);
+  if (gx > 16384) gx = 16384;
+  hipLaunchKernelGGL(f16x2_pack_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, d_src, (uint4*)d_dst, n / 8);
+  AVS_CHECK_LAUNCH("avs_f16x2_pack_f32");
+  return AVS_OK;
+}
+
+extern "C" int avs_f16x2_unpack_f32(const void* d_src, float* d_dst, int64_t n, avs_stream_t stream) {
+  AVS_REQUIRE(n >= 0 && n % 8 == 0, AVS_E_SHAPE, "avs_f16x2_unpack_f32: n = %lld must be a multiple of 8", (long long)n);
+  if (n == 0) return AVS_OK;
+  AVS_REQUIRE(d_src && d_dst, AVS_E_ARG, "avs_f16x2_unpack_f32: null pointer");
+  AVS_REQUIRE(avs_aligned16(d_dst) && (((uintptr_t)d_src) & 31u) == 0, AVS_E_ALIGN,
+              "avs_f16x2_unpack_f32: dst must be 16-byte, src 32-byte aligned");
+  long long gx = avs_cdiv(n / 8, 256);
+  if (gx > 16384) gx = 16384;
+  hipLaunchKernelGGL(f16x2_unpack_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, (const uint4*)d_src, d_dst,
+                     n / 8);
+  AVS_CHECK_LAUNCH("avs_f16x2_unpack_f32");
+  return AVS_OK;
+}
+
 extern "C" int avs_frames_normalize_u8(int dtype, const uint8_t* d_src, int n, int h, int w, float denom,
                                        const float* mean3, const float* std3, const float* affine6, void* d_out,
                                        int out_h, int out_w, int pad_t, int pad_l, avs_stream_t stream) {
-  AVS_REQUIRE(dtype == AVS_F32 || dtype == AVS_BF16, AVS_E_ARG, "avs_frames_normalize_u8: bad dtype");
+  AVS_REQUIRE(dtype == AVS_F32 || dtype == AVS_BF16 || dtype == AVS_F16X2, AVS_E_ARG, "avs_frames_normalize_u8: bad dtype");
+  AVS_REQUIRE(dtype != AVS_F16X2 || (out_w % 2 == 0 && (((uintptr_t)d_out) & 31u) == 0), AVS_E_ALIGN,
+              "avs_frames_normalize_u8: AVS_F16X2 needs an even output width and a 32-byte aligned output");
   AVS_REQUIRE(n >= 0 && h > 0 && w > 0 && out_h >= h + pad_t && out_w >= w + pad_l && pad_t >= 0 && pad_l >= 0,
               AVS_E_SHAPE, "avs_frames_normalize_u8: bad extents");
   if (n == 0) return AVS_OK;
@@ -65,7 +154,10 @@ extern "C" int avs_frames_normalize_u8(int dtype, const uint8_t* d_src, int n, i
   np.has_affine = affine6 != nullptr;
   const long long total = (long long)n * out_h * out_w;
   const int grid = (int)(avs_cdiv(total, 256) < 16384 ? avs_cdiv(total, 256) : 16384);
-  if (dtype == AVS_F32)
+  if (dtype == AVS_F16X2)
+    hipLaunchKernelGGL(frames_normalize_h2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_src, n, h, w, np,
+                       (uint4*)d_out, out_h, out_w, pad_t, pad_l);
+  else if (dtype == AVS_F32)
     hipLaunchKernelGGL(frames_normalize_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_src, n, h, w,
                        np, (float*)d_out, out_h, out_w, pad_t, pad_l);
   else
@@ -177,29 +269,34 @@ __device__ __forceinline__ void store4<avs_bf16_tag>(avs_bf16_tag* p, const floa
   *reinterpret_cast<uint2*>(p) = u;
 }
 
-template <typename T>
+template <typename T, int V>
+__device__ __forceinline__ void loadv(const T* p, float (&v)[V]);
+
+template <typename T, int V = 4>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, int c, long long ldx,
                                                        const int64_t* __restrict__ group_rows,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float eps, float* __restrict__ scale, float* __restrict__ shift,
                                                        int tc) {
-  __shared__ float red[2][256][4];
+  __shared__ float red[2][256][V];
   const int g = blockIdx.x;
   const int tr = 256 / tc;
   const int ct = threadIdx.x % tc;  // channel-thread
   const int rt = threadIdx.x / tc;  // row-thread
-  const int ch = (blockIdx.y * tc + ct) * 4;
+  const int ch = (blockIdx.y * tc + ct) * V;
   const long long r0 = group_rows[g], r1 = group_rows[g + 1];
   const long long nrows = r1 - r0;
-  float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0}, ref[4] = {0, 0, 0, 0};
+  float s1[V], s2[V], ref[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) s1[j] = s2[j] = ref[j] = 0.f;
   const bool active = ch < c && nrows > 0;
   if (active) {
-    load4<T>(x + r0 * ldx + ch, ref);
+    loadv<T, V>(x + r0 * ldx + ch, ref);
     for (long long r = r0 + rt; r < r1; r += tr) {
-      float v[4];
-      load4<T>(x + r * ldx + ch, v);
+      float v[V];
+      loadv<T, V>(x + r * ldx + ch, v);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < V; ++j) {
         const float d = v[j] - ref[j];
         s1[j] += d;
         s2[j] = fmaf(d, d, s2[j]);
@@ -207,14 +304,14 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
     }
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < V; ++j) {
     red[0][threadIdx.x][j] = s1[j];
     red[1][threadIdx.x][j] = s2[j];
   }
   __syncthreads();
   if (rt == 0 && active) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < V; ++j) {
       float a = 0.f, b = 0.f;
       for (int k = 0; k < tr; ++k) {
         a += red[0][k * tc + ct][j];
@@ -233,38 +330,19 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
   }
 }
 
-extern "C" int avs_bn_batch_stats(int dtype, const void* d_x, int64_t rows, int c, int64_t ldx,
-                                  const int64_t* d_group_rows, int groups, const float* d_gamma, const float* d_beta,
-                                  float eps, float* d_scale, float* d_shift, avs_stream_t stream) {
-  AVS_REQUIRE(dtype == AVS_F32 || dtype == AVS_BF16, AVS_E_ARG, "avs_bn_batch_stats: bad dtype");
-  AVS_REQUIRE(rows >= 0 && c > 0 && c % 4 == 0 && ldx >= c && ldx % 4 == 0 && groups >= 0, AVS_E_SHAPE,
-              "avs_bn_batch_stats: rows=%lld c=%d ldx=%lld groups=%d", (long long)rows, c, (long long)ldx, groups);
-  if (groups == 0) return AVS_OK;
-  AVS_REQUIRE(d_x && d_group_rows && d_gamma && d_beta && d_scale && d_shift, AVS_E_ARG,
-              "avs_bn_batch_stats: null pointer");
-  AVS_REQUIRE(avs_aligned16(d_x), AVS_E_ALIGN, "avs_bn_batch_stats: x not 16-byte aligned");
-  int tc = 1;
-  while (tc < 64 && tc * 4 < c) tc <<= 1;  // power of two <= 64 channel-threads
-  dim3 grid(groups, (unsigned)avs_cdiv(c, tc * 4));
-  if (dtype == AVS_F32)
-    hipLaunchKernelGGL(bn_stats_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)d_x, c,
-                       (long long)ldx, d_group_rows, d_gamma, d_beta, eps, d_scale, d_shift, tc);
-  else
-    hipLaunchKernelGGL(bn_stats_kernel<avs_bf16_tag>, grid, dim3(256), 0, (hipStream_t)stream,
-                       (const avs_bf16_tag*)d_x, c, (long long)ldx, d_group_rows, d_gamma, d_beta, eps, d_scale,
-                       d_shift, tc);
-  AVS_CHECK_LAUNCH("avs_bn_batch_stats");
-  return AVS_OK;
-}
-
 // 16 bytes of channels per thread (4 fp32 / 8 bf16) whenever the channel count allows; the taps of
 // neighbouring outputs overlap, so most loads are L2 hits and the kernel is bound by load issue.
 template <typename T, int V>
 __device__ __forceinline__ void loadv(const T* p, float (&v)[V]) {
   if constexpr (V == 4) {
     load4<T>(p, reinterpret_cast<float(&)[4]>(v));
+  } else if constexpr (sizeof(T) == 4) {
+    // AVS_F16X2: 8 slots = 16 bytes of hi halves + 16 bytes of lo halves
+    static_assert(V == 8, "AVS_F16X2 moves whole runs of 8 slots");
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    avs_f16x2_join8(q[0], q[1], v);
   } else {
-    static_assert(sizeof(T) == 2 && V == 8, "8-wide path is bf16 only");
+    static_assert(sizeof(T) == 2 && V == 8, "8-wide path is bf16 / f16x2 only");
     const uint4 u = *reinterpret_cast<const uint4*>(p);
     const unsigned w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
@@ -278,6 +356,12 @@ template <typename T, int V>
 __device__ __forceinline__ void storev(T* p, const float (&v)[V]) {
   if constexpr (V == 4) {
     store4<T>(p, reinterpret_cast<const float(&)[4]>(v));
+  } else if constexpr (sizeof(T) == 4) {
+    uint4 hi, lo;
+    avs_f16x2_split8(v, hi, lo);
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = hi;
+    q[1] = lo;
   } else {
     uint4 u;
     unsigned* w = reinterpret_cast<unsigned*>(&u);
@@ -287,6 +371,39 @@ __device__ __forceinline__ void storev(T* p, const float (&v)[V]) {
     *reinterpret_cast<uint4*>(p) = u;
   }
 }
+
+extern "C" int avs_bn_batch_stats(int dtype, const void* d_x, int64_t rows, int c, int64_t ldx,
+                                  const int64_t* d_group_rows, int groups, const float* d_gamma, const float* d_beta,
+                                  float eps, float* d_scale, float* d_shift, avs_stream_t stream) {
+  AVS_REQUIRE(dtype == AVS_F32 || dtype == AVS_BF16 || dtype == AVS_F16X2, AVS_E_ARG, "avs_bn_batch_stats: bad dtype");
+  const bool h2 = dtype == AVS_F16X2;
+  AVS_REQUIRE(!h2 || (c % 8 == 0 && ldx % 8 == 0 && (((uintptr_t)d_x) & 31u) == 0), AVS_E_ALIGN,
+              "avs_bn_batch_stats: AVS_F16X2 needs channels / strides in multiples of 8 slots, 32-byte aligned");
+  AVS_REQUIRE(rows >= 0 && c > 0 && c % 4 == 0 && ldx >= c && ldx % 4 == 0 && groups >= 0, AVS_E_SHAPE,
+              "avs_bn_batch_stats: rows=%lld c=%d ldx=%lld groups=%d", (long long)rows, c, (long long)ldx, groups);
+  if (groups == 0) return AVS_OK;
+  AVS_REQUIRE(d_x && d_group_rows && d_gamma && d_beta && d_scale && d_shift, AVS_E_ARG,
+              "avs_bn_batch_stats: null pointer");
+  AVS_REQUIRE(avs_aligned16(d_x), AVS_E_ALIGN, "avs_bn_batch_stats: x not 16-byte aligned");
+  const int vw = h2 ? 8 : 4;
+  int tc = 1;
+  while (tc < 64 && tc * vw < c) tc <<= 1;  // power of two <= 64 channel-threads
+  dim3 grid(groups, (unsigned)avs_cdiv(c, tc * vw));
+  if (h2)
+    hipLaunchKernelGGL((bn_stats_kernel<avs_h2_tag, 8>), grid, dim3(256), 0, (hipStream_t)stream,
+                       (const avs_h2_tag*)d_x, c, (long long)ldx, d_group_rows, d_gamma, d_beta, eps, d_scale,
+                       d_shift, tc);
+  else if (dtype == AVS_F32)
+    hipLaunchKernelGGL(bn_stats_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)d_x, c,
+                       (long long)ldx, d_group_rows, d_gamma, d_beta, eps, d_scale, d_shift, tc);
+  else
+    hipLaunchKernelGGL(bn_stats_kernel<avs_bf16_tag>, grid, dim3(256), 0, (hipStream_t)stream,
+                       (const avs_bf16_tag*)d_x, c, (long long)ldx, d_group_rows, d_gamma, d_beta, eps, d_scale,
+                       d_shift, tc);
+  AVS_CHECK_LAUNCH("avs_bn_batch_stats");
+  return AVS_OK;
+}
+
 
 // V elements (4, or 8 = 16 bytes of bf16) per thread
 template <typename T, int V>
@@ -335,7 +452,11 @@ extern "C" int avs_bn_apply(int dtype, const void* d_x, int64_t rows, int c, int
                             int groups, int64_t max_group_rows, const float* d_scale, const float* d_shift,
                             const void* d_residual, int64_t ldr, int act, void* d_y, int64_t ldy,
                             avs_stream_t stream) {
-  AVS_REQUIRE(dtype == AVS_F32 || dtype == AVS_BF16, AVS_E_ARG, "avs_bn_apply: bad dtype");
+  AVS_REQUIRE(dtype == AVS_F32 || dtype == AVS_BF16 || dtype == AVS_F16X2, AVS_E_ARG, "avs_bn_apply: bad dtype");
+  const bool h2 = dtype == AVS_F16X2;
+  AVS_REQUIRE(!h2 || (c % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && (!d_residual || ldr % 8 == 0) &&
+                      (((uintptr_t)d_x | (uintptr_t)d_y | (uintptr_t)d_residual) & 31u) == 0),
+              AVS_E_ALIGN, "avs_bn_apply: AVS_F16X2 needs channels / strides in multiples of 8 slots, 32-byte aligned");
   AVS_REQUIRE(rows >= 0 && c > 0 && c % 4 == 0 && ldx >= c && ldx % 4 == 0 && ldy >= c && ldy % 4 == 0 &&
                   (!d_residual || (ldr >= c && ldr % 4 == 0)),
               AVS_E_SHAPE, "avs_bn_apply: rows=%lld c=%d ldx=%lld ldy=%lld ldr=%lld", (long long)rows, c,
@@ -345,13 +466,17 @@ extern "C" int avs_bn_apply(int dtype, const void* d_x, int64_t rows, int c, int
   AVS_REQUIRE(d_x && d_scale && d_shift && d_y, AVS_E_ARG, "avs_bn_apply: null pointer");
   const bool wide = dtype == AVS_BF16 && c % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && (!d_residual || ldr % 8 == 0) &&
                     avs_aligned16(d_x) && avs_aligned16(d_y) && avs_aligned16(d_residual);
-  const long long span = (groups > 0 ? max_group_rows : rows) * (c / (wide ? 8 : 4));
+  const long long span = (groups > 0 ? max_group_rows : rows) * (c / ((wide || h2) ? 8 : 4));
   AVS_REQUIRE(span > 0, AVS_E_SHAPE, "avs_bn_apply: max_group_rows must be > 0");
   long long gx = avs_cdiv(span, 256);
   if (gx > 8192) gx = 8192;
   dim3 grid((unsigned)gx, groups > 0 ? groups : 1);
   AVS_REQUIRE(grid.y <= 65535, AVS_E_SHAPE, "avs_bn_apply: more than 65535 groups in one call");
-  if (dtype == AVS_F32)
+  if (h2)
+    hipLaunchKernelGGL((bn_apply_kernel<avs_h2_tag, 8>), grid, dim3(256), 0, (hipStream_t)stream,
+                       (const avs_h2_tag*)d_x, c, (long long)ldx, d_group_rows, (long long)rows, d_scale, d_shift,
+                       (const avs_h2_tag*)d_residual, (long long)ldr, act, (avs_h2_tag*)d_y, (long long)ldy);
+  else if (dtype == AVS_F32)
     hipLaunchKernelGGL((bn_apply_kernel<float, 4>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)d_x, c,
                        (long long)ldx, d_group_rows, (long long)rows, d_scale, d_shift, (const float*)d_residual,
                        (long long)ldr, act, (float*)d_y, (long long)ldy);
@@ -419,7 +544,11 @@ __global__ __launch_bounds__(256) void pool2d_kernel(int mode, const T* __restri
 extern "C" int avs_pool2d_nhwc(int dtype, int mode, const void* d_x, int n, int h, int w, int c, int64_t x_px_stride,
                                int k, int s, int p, const float* d_bias, int act, void* d_y, int ho, int wo,
                                int64_t y_px_stride, avs_stream_t stream) {
-  AVS_REQUIRE(dtype == AVS_F32 || dtype == AVS_BF16, AVS_E_ARG, "avs_pool2d_nhwc: bad dtype");
+  AVS_REQUIRE(dtype == AVS_F32 || dtype == AVS_BF16 || dtype == AVS_F16X2, AVS_E_ARG, "avs_pool2d_nhwc: bad dtype");
+  const bool h2 = dtype == AVS_F16X2;
+  AVS_REQUIRE(!h2 || (c % 8 == 0 && x_px_stride % 8 == 0 && y_px_stride % 8 == 0 &&
+                      (((uintptr_t)d_x | (uintptr_t)d_y) & 31u) == 0),
+              AVS_E_ALIGN, "avs_pool2d_nhwc: AVS_F16X2 needs channels / strides in multiples of 8 slots, 32-byte aligned");
   AVS_REQUIRE(act == AVS_ACT_NONE || act == AVS_ACT_RELU, AVS_E_ARG, "avs_pool2d_nhwc: bad activation %d", act);
   const int relu = act == AVS_ACT_RELU;
   AVS_REQUIRE(mode == 0 || mode == 1, AVS_E_ARG, "avs_pool2d_nhwc: bad mode");
@@ -431,10 +560,14 @@ extern "C" int avs_pool2d_nhwc(int dtype, int mode, const void* d_x, int n, int 
   AVS_REQUIRE(d_x && d_y, AVS_E_ARG, "avs_pool2d_nhwc: null pointer");
   const bool wide = dtype == AVS_BF16 && c % 8 == 0 && x_px_stride % 8 == 0 && y_px_stride % 8 == 0 &&
                     avs_aligned16(d_x) && avs_aligned16(d_y);
-  const long long total = (long long)n * ho * wo * (c / (wide ? 8 : 4));
+  const long long total = (long long)n * ho * wo * (c / ((wide || h2) ? 8 : 4));
   long long gx = avs_cdiv(total, 256);
   if (gx > 65536) gx = 65536;
-  if (dtype == AVS_F32)
+  if (h2)
+    hipLaunchKernelGGL((pool2d_kernel<avs_h2_tag, 8>), dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, mode,
+                       (const avs_h2_tag*)d_x, n, h, w, c, (long long)x_px_stride, k, s, p, d_bias, relu,
+                       (avs_h2_tag*)d_y, ho, wo, (long long)y_px_stride);
+  else if (dtype == AVS_F32)
     hipLaunchKernelGGL((pool2d_kernel<float, 4>), dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, mode,
                        (const float*)d_x, n, h, w, c, (long long)x_px_stride, k, s, p, d_bias, relu, (float*)d_y, ho,
                        wo, (long long)y_px_stride);
@@ -520,7 +653,11 @@ extern "C" int avs_bn_maxpool_nhwc(int dtype, const void* d_x, int n, int h, int
                                    const int64_t* d_group_rows, int groups, const float* d_scale,
                                    const float* d_shift, int relu, int k, int s, int p, void* d_y, int ho, int wo,
                                    int64_t y_px_stride, avs_stream_t stream) {
-  AVS_REQUIRE(dtype == AVS_F32 || dtype == AVS_BF16, AVS_E_ARG, "avs_bn_maxpool_nhwc: bad dtype");
+  AVS_REQUIRE(dtype == AVS_F32 || dtype == AVS_BF16 || dtype == AVS_F16X2, AVS_E_ARG, "avs_bn_maxpool_nhwc: bad dtype");
+  const bool h2 = dtype == AVS_F16X2;
+  AVS_REQUIRE(!h2 || (c % 8 == 0 && x_px_stride % 8 == 0 && y_px_stride % 8 == 0 &&
+                      (((uintptr_t)d_x | (uintptr_t)d_y) & 31u) == 0),
+              AVS_E_ALIGN, "avs_bn_maxpool_nhwc: AVS_F16X2 needs channels / strides in multiples of 8 slots, 32-byte aligned");
   AVS_REQUIRE(n >= 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0 && k > 0 && s > 0 && p >= 0 && p < k && ho > 0 &&
                   wo > 0 && x_px_stride >= c && x_px_stride % 4 == 0 && y_px_stride >= c && y_px_stride % 4 == 0,
               AVS_E_SHAPE, "avs_bn_maxpool_nhwc: bad extents");
@@ -533,10 +670,14 @@ extern "C" int avs_bn_maxpool_nhwc(int dtype, const void* d_x, int n, int h, int
               "avs_bn_maxpool_nhwc: scale / shift must be 16-byte aligned");
   const bool wide = dtype == AVS_BF16 && c % 8 == 0 && x_px_stride % 8 == 0 && y_px_stride % 8 == 0 &&
                     avs_aligned16(d_x) && avs_aligned16(d_y);
-  const long long total = (long long)n * ho * wo * (c / (wide ? 8 : 4));
+  const long long total = (long long)n * ho * wo * (c / ((wide || h2) ? 8 : 4));
   long long gx = avs_cdiv(total, 256);
   if (gx > 65536) gx = 65536;
-  if (dtype == AVS_F32)
+  if (h2)
+    hipLaunchKernelGGL((bn_maxpool_kernel<avs_h2_tag, 8>), dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream,
+                       (const avs_h2_tag*)d_x, n, h, w, c, (long long)x_px_stride, d_group_rows, groups, d_scale,
+                       d_shift, relu, k, s, p, (avs_h2_tag*)d_y, ho, wo, (long long)y_px_stride);
+  else if (dtype == AVS_F32)
     hipLaunchKernelGGL((bn_maxpool_kernel<float, 4>), dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream,
                        (const float*)d_x, n, h, w, c, (long long)x_px_stride, d_group_rows, groups, d_scale, d_shift,
                        relu, k, s, p, (float*)d_y, ho, wo, (long long)y_px_stride);
@@ -552,42 +693,51 @@ extern "C" int avs_bn_maxpool_nhwc(int dtype, const void* d_x, int n, int h, int
   return AVS_OK;
 }
 
-template <typename T>
+template <typename T, int V = 4>
 __global__ __launch_bounds__(256) void global_avgpool_kernel(const T* __restrict__ x, int n, int hw, int c,
                                                              float* __restrict__ y, long long ldy) {
-  const int cv = c >> 2;
+  const int cv = c / V;
   const long long total = (long long)n * cv;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const int ch = (int)(i % cv) * 4;
+    const int ch = (int)(i % cv) * V;
     const long long img = i / cv;
-    float a[4] = {0, 0, 0, 0};
+    float a[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) a[j] = 0.f;
     const T* base = x + img * hw * (long long)c + ch;
     for (int r = 0; r < hw; ++r) {
-      float v[4];
-      load4<T>(base + (long long)r * c, v);
+      float v[V];
+      loadv<T, V>(base + (long long)r * c, v);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) a[j] += v[j];
+      for (int j = 0; j < V; ++j) a[j] += v[j];
     }
     const float d = (float)hw;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a[j] = a[j] / d;
-    store4<float>(y + img * ldy + ch, a);
+    for (int j = 0; j < V; ++j) a[j] = a[j] / d;
+#pragma unroll
+    for (int q = 0; q < V; q += 4) store4<float>(y + img * ldy + ch + q, reinterpret_cast<const float(&)[4]>(a[q]));
   }
 }
 
 extern "C" int avs_global_avgpool_nhwc(int dtype, const void* d_x, int n, int hw, int c, float* d_y, int64_t ldy,
                                        avs_stream_t stream) {
-  AVS_REQUIRE(dtype == AVS_F32 || dtype == AVS_BF16, AVS_E_ARG, "avs_global_avgpool_nhwc: bad dtype");
+  AVS_REQUIRE(dtype == AVS_F32 || dtype == AVS_BF16 || dtype == AVS_F16X2, AVS_E_ARG, "avs_global_avgpool_nhwc: bad dtype");
+  const bool h2 = dtype == AVS_F16X2;
+  AVS_REQUIRE(!h2 || (c % 8 == 0 && (((uintptr_t)d_x) & 31u) == 0), AVS_E_ALIGN,
+              "avs_global_avgpool_nhwc: AVS_F16X2 needs channels in multiples of 8 slots, 32-byte aligned");
   AVS_REQUIRE(n >= 0 && hw > 0 && c > 0 && c % 4 == 0 && ldy >= c && ldy % 4 == 0, AVS_E_SHAPE,
               "avs_global_avgpool_nhwc: bad extents");
   if (n == 0) return AVS_OK;
   AVS_REQUIRE(d_x && d_y, AVS_E_ARG, "avs_global_avgpool_nhwc: null pointer");
   AVS_REQUIRE(avs_aligned16(d_y), AVS_E_ALIGN, "avs_global_avgpool_nhwc: y not 16-byte aligned");
-  const long long total = (long long)n * (c >> 2);
+  const long long total = (long long)n * (c / (h2 ? 8 : 4));
   long long gx = avs_cdiv(total, 256);
   if (gx > 16384) gx = 16384;
-  if (dtype == AVS_F32)
+  if (h2)
+    hipLaunchKernelGGL((global_avgpool_kernel<avs_h2_tag, 8>), dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream,
+                       (const avs_h2_tag*)d_x, n, hw, c, d_y, (long long)ldy);
+  else if (dtype == AVS_F32)
     hipLaunchKernelGGL(global_avgpool_kernel<float>, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream,
                        (const float*)d_x, n, hw, c, d_y, (long long)ldy);
   else

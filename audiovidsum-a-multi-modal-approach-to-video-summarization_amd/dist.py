@@ -13,6 +13,15 @@ import os
 import torch
 import torch.distributed as dist
 
+# True: the three exchanges below run their real collective path even in a process group of ONE rank (normally a
+# single rank returns early).  A one-GPU box can then exercise the product's flat-bucket broadcast, padded score
+# all-gather and gradient bucket on RCCL device tensors (tests/test_gpu_configs.py); set by tests only.
+FORCE_COLLECTIVES = os.environ.get("AVS_DIST_FORCE_COLLECTIVES") == "1"
+
+
+def _collective_path():
+    return dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
+
 
 def init_from_env(backend=None):
     """Initialise from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun); returns (rank, world, local_rank)."""
@@ -45,7 +54,7 @@ def broadcast_module(module, src=0):
     """C1: weights (parameters and buffers) from rank `src` to every rank.  The copies go through the parameters
     themselves (not ``.data``), so their version counters move and the kernel-layout weight caches of the runners
     (keyed on data_ptr + _version) are rebuilt even if a forward ran before the broadcast."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _collective_path():
         return
     with torch.no_grad():
         tensors = list(module.parameters()) + list(module.buffers())
@@ -66,7 +75,7 @@ def allreduce_gradients(module, average=True):
     """C3: data-parallel gradient exchange for the training loop (scripts/train_av_model.py:94-96 run on one
     video per rank): one flat fp32 bucket (38.7 MB for the scorer) all-reduced over RCCL, then averaged.
     On the 8-GPU xGMI mesh a bucket this size is per-link bound (2*(7/8)*38.7 MB / 153 GB/s ~ 0.44 ms)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _collective_path():
         return
     grads = [p.grad for p in module.parameters() if p.grad is not None]
     if not grads:
@@ -84,7 +93,7 @@ def allreduce_gradients(module, average=True):
 def gather_video_scores(local_scores, local_video_ids, local_lengths, num_videos):
     """C2: every rank contributes the concatenated scores of its videos; every rank receives the list
     of per-video score tensors in global video order."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _collective_path():
         out, o = [None] * num_videos, 0
         for vid, ln in zip(local_video_ids, local_lengths):
             out[vid] = local_scores[o:o + ln]

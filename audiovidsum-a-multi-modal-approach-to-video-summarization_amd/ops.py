@@ -8,13 +8,14 @@ from ctypes import c_float, c_void_p
 import torch
 
 from . import _abi
-from ._abi import ACT_NONE, ACT_RELU, AVS_BF16, AVS_F32, AVS_F32_SPLIT, BIAS_COL, BIAS_NONE, BIAS_ROW, check, lib
+from ._abi import (ACT_NONE, ACT_RELU, AVS_BF16, AVS_F16X2, AVS_F32, AVS_F32_SPLIT, BIAS_COL, BIAS_NONE, BIAS_ROW, check,
+                   lib)
 
 __all__ = [
     "ACT_NONE", "ACT_RELU", "linear", "gemm_nt_batched", "conv2d", "conv2d_raw", "conv_bnlocal_tile_rows", "conv1x1_bn", "conv1x1_gram_bn", "bn_gram_affine", "gram_supported", "frames_normalize", "stem_conv_bn_pool", "resize_bilinear",
     "bn_batch_stats", "bn_apply", "bn_maxpool", "pool2d", "global_avgpool", "segment_mean", "hsv_frame_diff", "reflect_pad", "stft_f64", "stft_mel_fused", "power_mel",
     "clamp_topdb", "fill", "quantize", "resample", "lstm", "mha_batchaxis", "score_head", "mhsa_flash", "softmax_rows", "cdist", "dtw_path",
-    "gather_scale", "dtype_code",
+    "gather_scale", "dtype_code", "f16x2_pack", "f16x2_unpack",
 ]
 
 
@@ -89,13 +90,40 @@ def _p(t, offset_elems=0):
 
 
 def dtype_code(dtype, split=False):
-    """C-ABI dtype code of a torch dtype.  split (fp32 only): AVS_F32_SPLIT = fp32 operands contracted on the bf16
-    matrix cores as hi*hi + hi*lo + lo*hi (the contraction entry points only: avs_conv2d_nhwc*, avs_gemm_nt)."""
+    """C-ABI dtype code of a torch dtype.  split (fp32 only): True = AVS_F32_SPLIT, fp32 operands contracted on the bf16
+    matrix cores as hi*hi + hi*lo + lo*hi (the contraction entry points only: avs_conv2d_nhwc*, avs_gemm_nt);
+    "f16x2" = AVS_F16X2: the tensor's 4-byte slots hold fp16 hi | lo runs (carried in float32-typed torch tensors:
+    same shapes, strides and byte size; f16x2_pack / f16x2_unpack convert)."""
     if dtype == torch.float32:
+        if split == "f16x2":
+            return AVS_F16X2
         return AVS_F32_SPLIT if split else AVS_F32
     if dtype == torch.bfloat16:
         return AVS_BF16
     raise TypeError(f"unsupported compute dtype {dtype}")
+
+
+def f16x2_pack(x):
+    """fp32 tensor (contiguous, numel a multiple of 8, rows of the innermost axis multiples of 8) -> the AVS_F16X2
+    image of the same shape, carried in a float32-typed tensor (opaque slots)."""
+    _dev(x)
+    _f32(x, "x")
+    if not x.is_contiguous() or x.numel() % 8 or (x.dim() and x.shape[-1] % 8):
+        raise ValueError("f16x2_pack: contiguous fp32 tensor whose innermost extent is a multiple of 8")
+    out = torch.empty_like(x)
+    check(lib().avs_f16x2_pack_f32(_p(x), _p(out), x.numel(), _stream()), "avs_f16x2_pack_f32")
+    return out
+
+
+def f16x2_unpack(x):
+    """The fp32 values (hi + lo) of an AVS_F16X2 tensor (contiguous)."""
+    _dev(x)
+    _f32(x, "x")
+    if not x.is_contiguous() or x.numel() % 8:
+        raise ValueError("f16x2_unpack: contiguous tensor, numel a multiple of 8")
+    out = torch.empty_like(x)
+    check(lib().avs_f16x2_unpack_f32(_p(x), _p(out), x.numel(), _stream()), "avs_f16x2_unpack_f32")
+    return out
 
 
 def _dev(*ts):
@@ -168,13 +196,20 @@ def conv_bnlocal_tile_rows(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, 
 _stats_ws = {}
 
 
+def _ws_key(device):
+    # one scratch buffer per (device, stream): launches on ONE stream are ordered, so consecutive layers can share
+    # it; two streams must not
+    return (device, torch.cuda.current_stream(device).cuda_stream)
+
+
 def _stats_workspace(device, nbytes):
-    """Scratch for the per-tile partial sums of avs_conv2d_nhwc_bnstats: one buffer per device, grown on demand
-    (launches on one stream are ordered, so consecutive layers can share it)."""
-    ws = _stats_ws.get(device)
+    """Scratch for the per-tile partial sums of avs_conv2d_nhwc_bnstats: one buffer per device and stream, grown on
+    demand."""
+    key = _ws_key(device)
+    ws = _stats_ws.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
-        _stats_ws[device] = ws
+        _stats_ws[key] = ws
     return ws
 
 
@@ -417,8 +452,9 @@ def conv2d(x, wt, kh, kw, stride, pad, out, bias=None, act=ACT_NONE, bnstats=Non
 
 
 # --------------------------------------------------------------------------- visual front end
-def frames_normalize(frames_u8, dtype, denom, mean, std, out_h, out_w, pad_t, pad_l, affine=None, out=None):
-    """frames_u8 [n,h,w,3] uint8 -> [n,out_h,out_w,4] normalised (4th channel 0), zero padded."""
+def frames_normalize(frames_u8, dtype, denom, mean, std, out_h, out_w, pad_t, pad_l, affine=None, out=None, code=None):
+    """frames_u8 [n,h,w,3] uint8 -> [n,out_h,out_w,4] normalised (4th channel 0), zero padded.
+    code: C-ABI dtype code when it is not implied by `dtype` (AVS_F16X2 in a float32-typed tensor)."""
     _dev(frames_u8)
     if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or frames_u8.shape[3] != 3 or not frames_u8.is_contiguous():
         raise ValueError("frames must be contiguous uint8 [n,h,w,3]")
@@ -428,7 +464,8 @@ def frames_normalize(frames_u8, dtype, denom, mean, std, out_h, out_w, pad_t, pa
     m3 = (c_float * 3)(*[float(v) for v in mean])
     s3 = (c_float * 3)(*[float(v) for v in std])
     a6 = (c_float * 6)(*[float(v) for v in affine]) if affine is not None else None
-    check(lib().avs_frames_normalize_u8(dtype_code(dtype), _p(frames_u8), n, h, w, float(denom), m3, s3, a6, _p(out),
+    check(lib().avs_frames_normalize_u8(dtype_code(dtype) if code is None else code, _p(frames_u8), n, h, w,
+                                        float(denom), m3, s3, a6, _p(out),
                                         out_h, out_w, pad_t, pad_l, _stream()), "avs_frames_normalize_u8")
     return out
 
@@ -454,10 +491,10 @@ def stem_conv_bn_pool(frames_u8, wt, denom, mean, std, frames_per_group, gamma, 
     scale = torch.empty((groups, 64), dtype=torch.float32, device=dev)
     shift = torch.empty((groups, 64), dtype=torch.float32, device=dev)
     need = int(lib().avs_stem_workspace_bytes(n))
-    ws = _stem_ws.get(dev)
+    ws = _stem_ws.get(_ws_key(dev))
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
-        _stem_ws[dev] = ws
+        _stem_ws[_ws_key(dev)] = ws
     m3 = (c_float * 3)(*[float(v) for v in mean])
     s3 = (c_float * 3)(*[float(v) for v in std])
     # algorithmic: 2 * 147 MACs per output, uint8 frames in, pooled bf16 map out
@@ -480,7 +517,7 @@ def resize_bilinear(frames_u8, dh, dw):
     return out
 
 
-def bn_batch_stats(x2d, group_rows, gamma, beta, eps):
+def bn_batch_stats(x2d, group_rows, gamma, beta, eps, code=None):
     """x2d [rows, C] (row stride >= C); group_rows int64 [G+1] device.  Returns scale, shift [G, C] fp32."""
     _dev(x2d, group_rows, gamma, beta)
     _rowmajor2d(x2d, "x")
@@ -488,14 +525,16 @@ def bn_batch_stats(x2d, group_rows, gamma, beta, eps):
     g = group_rows.numel() - 1
     scale = torch.empty((g, c), dtype=torch.float32, device=x2d.device)
     shift = torch.empty((g, c), dtype=torch.float32, device=x2d.device)
-    check(lib().avs_bn_batch_stats(dtype_code(x2d.dtype), _p(x2d), rows, c, x2d.stride(0), _p(group_rows), g,
+    check(lib().avs_bn_batch_stats(dtype_code(x2d.dtype) if code is None else code, _p(x2d), rows, c, x2d.stride(0),
+                                   _p(group_rows), g,
                                    _p(gamma), _p(beta), float(eps), _p(scale), _p(shift), _stream()),
           "avs_bn_batch_stats")
     return scale, shift
 
 
-def bn_apply(x2d, scale, shift, group_rows=None, max_group_rows=0, residual=None, act=ACT_NONE, out=None):
+def bn_apply(x2d, scale, shift, group_rows=None, max_group_rows=0, residual=None, act=ACT_NONE, out=None, code=None):
     _dev(x2d, scale, shift, group_rows, residual)
+    code = dtype_code(x2d.dtype) if code is None else code
     _rowmajor2d(x2d, "x")
     rows, c = x2d.shape
     if out is None:
@@ -503,15 +542,15 @@ def bn_apply(x2d, scale, shift, group_rows=None, max_group_rows=0, residual=None
     g = group_rows.numel() - 1 if group_rows is not None else 0
     # algorithmic bytes: read x (+ residual), write y
     nbytes = float(rows) * c * x2d.element_size() * (3 if residual is not None else 2)
-    _timed("bn_apply", dtype_code(x2d.dtype), nbytes, lambda: check(
-        lib().avs_bn_apply(dtype_code(x2d.dtype), _p(x2d), rows, c, x2d.stride(0), _p(group_rows), g,
+    _timed("bn_apply", code, nbytes, lambda: check(
+        lib().avs_bn_apply(code, _p(x2d), rows, c, x2d.stride(0), _p(group_rows), g,
                            int(max_group_rows), _p(scale), _p(shift), _p(residual),
                            residual.stride(0) if residual is not None else 0, act, _p(out), out.stride(0),
                            _stream()), "avs_bn_apply"))
     return out
 
 
-def pool2d(x, mode, k, s, p, out, bias=None, act=ACT_NONE):
+def pool2d(x, mode, k, s, p, out, bias=None, act=ACT_NONE, code=None):
     """x, out: NHWC views (unit channel stride, dense pixels).  mode 'max' | 'avg'.  out = act(pool(x) + bias) with an
     optional fp32 per-channel bias."""
     n, h, w, c = x.shape
@@ -520,12 +559,13 @@ def pool2d(x, mode, k, s, p, out, bias=None, act=ACT_NONE):
         _f32(bias, "bias")
         if bias.numel() != c or not bias.is_contiguous():
             raise ValueError("pool2d: bias must be contiguous fp32 [c]")
-    check(lib().avs_pool2d_nhwc(dtype_code(x.dtype), 0 if mode == "max" else 1, _p(x), n, h, w, c, x.stride(2), k, s,
+    check(lib().avs_pool2d_nhwc(dtype_code(x.dtype) if code is None else code, 0 if mode == "max" else 1, _p(x), n, h,
+                                w, c, x.stride(2), k, s,
                                 p, _p(bias), int(act), _p(out), ho, wo, out.stride(2), _stream()), "avs_pool2d_nhwc")
     return out
 
 
-def bn_maxpool(x, scale, shift, group_rows, relu, k, s, p, out):
+def bn_maxpool(x, scale, shift, group_rows, relu, k, s, p, out, code=None):
     """out = maxpool(act(x*scale[g] + shift[g])) on NHWC views: avs_bn_apply + max pooling in one pass."""
     _dev(x, scale, shift, group_rows, out)
     n, h, w, c = x.shape
@@ -533,21 +573,23 @@ def bn_maxpool(x, scale, shift, group_rows, relu, k, s, p, out):
     g = group_rows.numel() - 1 if group_rows is not None else 0
     # algorithmic bytes: read the raw map once, write the pooled map
     nbytes = float(x.numel() + out.numel()) * x.element_size()
-    _timed("bn_apply", dtype_code(x.dtype), nbytes, lambda: check(
-        lib().avs_bn_maxpool_nhwc(dtype_code(x.dtype), _p(x), n, h, w, c, x.stride(2), _p(group_rows), g, _p(scale),
+    code = dtype_code(x.dtype) if code is None else code
+    _timed("bn_apply", code, nbytes, lambda: check(
+        lib().avs_bn_maxpool_nhwc(code, _p(x), n, h, w, c, x.stride(2), _p(group_rows), g, _p(scale),
                                   _p(shift), 1 if relu else 0, k, s, p, _p(out), ho, wo, out.stride(2), _stream()),
         "avs_bn_maxpool_nhwc"))
     return out
 
 
-def global_avgpool(x, out=None):
+def global_avgpool(x, out=None, code=None):
     """x [n,h,w,c] dense NHWC -> fp32 [n,c]."""
     n, h, w, c = x.shape
     if not x.is_contiguous():
         raise ValueError("global_avgpool needs a dense NHWC tensor")
     if out is None:
         out = torch.empty((n, c), dtype=torch.float32, device=x.device)
-    check(lib().avs_global_avgpool_nhwc(dtype_code(x.dtype), _p(x), n, h * w, c, _p(out), out.stride(0), _stream()),
+    check(lib().avs_global_avgpool_nhwc(dtype_code(x.dtype) if code is None else code, _p(x), n, h * w, c, _p(out),
+                                        out.stride(0), _stream()),
           "avs_global_avgpool_nhwc")
     return out
 

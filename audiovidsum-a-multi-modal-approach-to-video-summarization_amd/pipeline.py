@@ -21,6 +21,10 @@ class _HostStager:
         self.bufs = [torch.empty((max_frames,) + tuple(host_frames.shape[1:]), dtype=torch.uint8, device=device)
                      for _ in range(2)]
         self.copy_stream = torch.cuda.Stream(device=device)
+        # the staging buffers come from the COMPUTE stream's allocator pool: a block may still be read by kernels its
+        # previous owner queued there, so the first upload into each buffer must be ordered behind everything the
+        # compute stream has been given so far (later uploads are ordered by the `freed` events)
+        self.copy_stream.wait_stream(torch.cuda.current_stream(device))
         self.filled = [torch.cuda.Event(), torch.cuda.Event()]
         self.freed = [None, None]
         self.counts = [0, 0]

@@ -6,8 +6,11 @@
 Headline workload at N=1 = BASELINE.json configs[1]: SumMe-shape batch, 25 videos x ~1.8k frames (lengths
 ~N(1800,300) clipped to [900,2700], seed 2002), visual-only (audio = the literal zeros(296)), ResNet-50
 extractor in the reference's batch-statistics BatchNorm mode, every frame its own one-frame shot (= its own
-micro-batch, features/extractors.py:48-56), bf16 MFMA, then the AVBiLSTMModel scorer (fp32) and the mean-threshold
-selection.  One step = one pass of that path over the whole batch, uint8 frames already resident in HBM.  For N>1
+micro-batch, features/extractors.py:48-56), then the AVBiLSTMModel scorer (fp32) and the mean-threshold selection.
+The headline arithmetic is the FASTEST MODE THAT CARRIES PARITY (accuracy.bars_met true): f16x2 - activations and
+weights stored as fp16 hi | lo runs (22 significant bits), every product three v_mfma_f32_32x32x16_f16, centred
+BatchNorm statistics; the bf16 throughput mode (configs[1]'s "bf16", which does NOT meet the accuracy bars) is
+sub_results.bf16_throughput_mode with its accuracy beside it.  One step = one pass of that path over the whole batch, uint8 frames already resident in HBM.  For N>1
 every rank runs its own batch of the same shape (weak scaling; videos are independent, the data path has no
 collective) and the per-video scores are all-gathered (C2) inside the timed region.  `--config 3` runs one rank's
 share of configs[3] instead (50 videos x 5000 frames per rank).
@@ -19,9 +22,10 @@ ONE JSON line on rank 0 (contract in the task description) with, beside the head
   accuracy      the benchmarked arithmetic mode against the fp32 oracle on those same samples: score error,
                 selection agreement, F1 drift, and whether north_star's bars (1e-4 / 0.001) are met by THIS mode;
   sub_results   (N=1, default on) the other claimed configurations, each timed the same way with fewer steps:
-                the reference's 4-frame micro-batches, both trunks, the fp32 parity mode (the mode that meets the
-                accuracy bars), a PCIe-inclusive pass (pinned host frames, upload overlapped with compute), the
-                configs[2] audio+visual+fusion leg with the audio kernels' HBM roofline, one rank's configs[3] share.
+                the bf16 throughput mode, the reference's 4-frame micro-batches, both trunks, the exact-fp32 and
+                fp32-split modes (each with its own roofline block), a PCIe-inclusive pass (pinned host frames,
+                upload overlapped with compute), the configs[2] audio+visual+fusion leg with the audio kernels' HBM
+                roofline, one rank's configs[3] share.
 """
 import argparse
 import json
@@ -40,7 +44,8 @@ if ROOT not in sys.path:
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_F32_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
-PMC_TRAFFIC_FILES = ("r02_pmc_traffic.json", "r01_e_pmc_traffic.json")   # newest first, under profiles/
+PMC_TRAFFIC_FILES = {"bf16": ("r02_pmc_traffic.json", "r01_e_pmc_traffic.json"),   # newest first, under profiles/
+                     "f16x2": ("r03_pmc_traffic.json",)}
 
 T_START = time.perf_counter()
 
@@ -125,6 +130,7 @@ def timed_steps(step, steps, warmup, barrier, profile=None):
 
 
 def roofline_from(prof, dtype, elapsed, traffic, split=False):
+    """split: False | True (AVS_F32_SPLIT) | "f16x2" (AVS_F16X2)."""
     from avsum_amd import ops
     summ = prof.summary()
     code = ops.dtype_code(dtype, split)
@@ -132,7 +138,8 @@ def roofline_from(prof, dtype, elapsed, traffic, split=False):
     if not conv or conv["ms"] <= 0:
         return None
     achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
-    # f32split runs three bf16 MFMAs per algorithmic product: against the bf16 peak the useful rate is a third of it
+    # f32split / f16x2 run three 16-bit MFMAs per algorithmic product: against the dense 16-bit peak (2.5 PF for
+    # bf16 and fp16 alike) the ALGORITHMIC rate can reach a third of it
     peak = MFMA_BF16_PEAK_TFLOPS if dtype == torch.bfloat16 else (MFMA_BF16_PEAK_TFLOPS / 3.0 if split
                                                                    else MFMA_F32_PEAK_TFLOPS)
     seen = prof.seen.get(("conv", code), conv["launches"])
@@ -144,10 +151,14 @@ def roofline_from(prof, dtype, elapsed, traffic, split=False):
                 "algorithmic_flop_per_launch": round(conv["flops"] / conv["launches"], 1),
                 "algorithmic_bytes_per_launch": round(conv["bytes"] / conv["launches"], 1),
                 "share_of_step": round(conv["ms"] * 1e-3 / elapsed * seen / conv["launches"], 3)}
+    if split:
+        roofline["mfma_rate_tflops"] = round(3.0 * achieved, 1)
+        roofline["note"] = ("three 16-bit MFMAs per algorithmic product (hi*hi + hi*lo + lo*hi): peak = 2500 / 3; "
+                            "mfma_rate_tflops = the matrix-core rate behind the algorithmic figure")
     others = []
     for kind, label in (("convbn", "conv1x1_bn_kernel (avs_conv1x1_bn[_in]_bf16)"),
                         ("bn_apply", "bn_apply_kernel / bn_maxpool_kernel (avs_bn_apply, avs_bn_maxpool_nhwc)")):
-        rec = summ.get((kind, code))
+        rec = summ.get((kind, code)) or summ.get((kind, ops.dtype_code(dtype)))
         if rec and rec["ms"] > 0:
             gbs = rec["flops"] / (rec["ms"] * 1e-3) / 1e9
             n = prof.seen.get((kind, code), rec["launches"])
@@ -162,11 +173,11 @@ def roofline_from(prof, dtype, elapsed, traffic, split=False):
     return roofline
 
 
-def pmc_traffic():
+def pmc_traffic(mode):
     """HBM bytes per launch of the contraction kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 on
     gfx950 + WRITE_SIZE, KiB -> bytes; profiles/summarize_pmc.py).  NOT measured in this run: the source file is
-    named beside the number; (None, None) when no summary is committed."""
-    for name in PMC_TRAFFIC_FILES:
+    named beside the number; (None, None) when no summary of this arithmetic mode is committed."""
+    for name in PMC_TRAFFIC_FILES.get(mode, ()):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -174,7 +185,7 @@ def pmc_traffic():
             d = json.load(open(path))
         except (OSError, ValueError):
             continue
-        for key in ("igemm_kernel<2>", "igemm_kernel"):
+        for key in ("igemm_kernel<4,split2>", "igemm_kernel<2>", "igemm_kernel"):
             if key in d:
                 return d[key].get("hbm_bytes_per_launch"), f"profiles/{name} [{key}] (separate rocprofv3 --pmc run)"
     return None, None
@@ -304,13 +315,15 @@ def main():
                          "sharded inference")
     ap.add_argument("--videos", type=int, default=None)
     ap.add_argument("--mean-frames", type=int, default=None)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f32split"],
-                    help="arithmetic of the CNN: bf16 (throughput), f32 (exact parity mode), f32split (fp32 storage, "
-                         "products on the bf16 matrix cores as hi*hi + hi*lo + lo*hi)")
+    ap.add_argument("--dtype", default="f16x2", choices=["f16x2", "bf16", "f32", "f32split"],
+                    help="arithmetic of the CNN: f16x2 (default: the fastest mode that meets the accuracy bars - values "
+                         "stored as fp16 hi | lo runs, three fp16 MFMAs per product), bf16 (throughput, misses the "
+                         "bars), f32 (exact fp32 MFMA), f32split (fp32 storage, products on the bf16 matrix cores as "
+                         "hi*hi + hi*lo + lo*hi)")
     ap.add_argument("--extractor", default="resnet50", choices=["resnet50", "resnet50+inception3"])
-    ap.add_argument("--chunk", type=int, default=24576,
-                    help="most frames per pass of the trunk (passes are made equal: 45 143 frames = 2 x 22 572; the "
-                         "activations of a 22 572-frame bf16 pass take ~160 GB of the 288 GB)")
+    ap.add_argument("--chunk", type=int, default=None,
+                    help="most frames per pass of the trunk (passes are made equal).  Default: 24576 for bf16 (45 143 "
+                         "frames = 2 x 22 572, ~160 GB of activations), 12288 for the 4-byte modes")
     ap.add_argument("--cpu-sample", type=int, default=128, help="frames per CPU-baseline run (0 = skip)")
     ap.add_argument("--cpu-runs", type=int, default=5, help="CPU-baseline runs (the median is reported)")
     ap.add_argument("--frames-per-group", type=int, default=1,
@@ -330,6 +343,18 @@ def main():
     ap.add_argument("--fuse", default=None, help="tuning: min_rows,ratio_num,ratio_den of the one-kernel conv+BN")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the documented launcher as a CHILD process (this
+        # process has not touched the GPU: nothing is re-exec'ed) and pass its exit code and its one JSON line through
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        log("no RANK / WORLD_SIZE in the environment: launching " + " ".join(cmd))
+        raise SystemExit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")).returncode)
     from avsum_amd import _abi, dist as avd, synthetic
     from avsum_amd.evaluation.accuracy import accuracy_report
     from avsum_amd.features.extractors import VisualFeatureExtractor
@@ -341,6 +366,8 @@ def main():
     if args.tall is not None:
         tv = [int(v) for v in args.tall.split(",")] + [0, -1]
         _abi.lib().avs_tune_tall_tiles(tv[0], tv[1], tv[2])
+    if args.chunk is None:
+        args.chunk = 24576 if args.dtype == "bf16" else 12288
     rank, world, local = avd.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
@@ -349,7 +376,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    split = args.dtype == "f32split"
+    split = {"f32split": True, "f16x2": "f16x2"}.get(args.dtype, False)
     use_inception = args.extractor != "resnet50"
     fpg = args.frames_per_group
 
@@ -357,6 +384,12 @@ def main():
     torch.manual_seed(7)
     extractor = VisualFeatureExtractor(dtype, "batch", f32_split=split)
     scorer = AVBiLSTMModel().eval()
+    with torch.no_grad():
+        # seeded RE-SCALED init of the scoring head (tests/test_gpu_accuracy.py uses the same): with the
+        # default init the sigmoid outputs span ~1.7e-3, so the 1e-4 score bar would be 6 % of the range and say
+        # little; with this the scores span ~0.05 and 1e-4 is 0.2 % of it.  Random weights either way, same speed.
+        scorer.scorer[0].weight.mul_(6.0)
+        scorer.scorer[2].weight.mul_(6.0)
     sd_cpu = None
     if rank == 0 and args.cpu_sample > 0 and world == 1:
         sd_cpu = ({k: v.clone() for k, v in extractor.resnet.state_dict().items()},
@@ -373,13 +406,13 @@ def main():
 
     if args.config == 2:
         # the configs[2] leg on its own (what sub_results.config2_audio_visual_fusion runs), for profiling it alone
-        if world != 1 or args.dtype != "bf16":
-            raise SystemExit("--config 2 is the one-GPU bf16 audio + visual + fusion leg")
+        if world != 1:
+            raise SystemExit("--config 2 is the one-GPU audio + visual + fusion leg")
         leg = config2_leg(extractor, scorer, dev, args.steps, args.videos or 50)
         print(json.dumps({"metric": "frames/sec end-to-end (extract+fuse+score), 224x224 + 16kHz", "value": leg["value"],
                           "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": 1,
                           "ms_per_step": leg["ms_per_step"], "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                          "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                           "config": {"workload": leg["workload"]}, "roofline": leg["audio_roofline"],
                           "cpu_baseline": None, "detail": leg}))
         return
@@ -421,8 +454,7 @@ def main():
     frames_all = float(n_all.item())
 
     if rank == 0:
-        roofline = roofline_from(prof, dtype, elapsed, pmc_traffic() if args.dtype == "bf16" else (None, None),
-                                 split) if prof is not None else None
+        roofline = roofline_from(prof, dtype, elapsed, pmc_traffic(args.dtype), split) if prof is not None else None
         group_txt = "per-frame shots" if fpg == 1 else f"{fpg}-frame micro-batches"
 
         # ---- CPU baseline + accuracy of the benchmarked mode on the same samples (outside every timed region)
@@ -443,83 +475,82 @@ def main():
             ref = np.concatenate(s_ref)
             got = pipe.score(dev_frames, s_off).cpu().numpy()
             again = pipe.score(dev_frames, s_off).cpu().numpy()
-            rep = accuracy_report(got, ref, s_off)
-            accuracy = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in rep.items()}
+            rep = accuracy_report(got, ref, s_off)   # guard-banded bars: ONE definition, shared with the tests
+            accuracy = {k: (round(v, 8) if isinstance(v, float) else v) for k, v in rep.items()}
             accuracy.update({"mode": args.dtype, "against": "oracle/ fp32 (CPU) on the cpu_baseline samples",
-                             "deterministic": bool(np.array_equal(got, again)),
-                             "bars": {"score_abs": 1e-4, "f1_drift": 1e-3},
-                             "bars_met": bool(rep["score_max_abs_err"] <= 1e-4 and rep["f1_drift_max"] <= 1e-3)})
+                             "deterministic": bool(np.array_equal(got, again))})
             del dev_frames
 
         # ---- sub-results: the other claimed configurations (N = 1)
         subs = None
-        default_headline = (args.config == 1 and fpg == 1 and not use_inception and args.dtype == "bf16"
+        default_headline = (args.config == 1 and fpg == 1 and not use_inception and args.dtype == "f16x2"
                             and args.videos is None and args.mean_frames is None)
         if world == 1 and (args.sub == "all" or (args.sub == "auto" and default_headline)):
             subs = {}
+            dev_samples = torch.from_numpy(np.concatenate(s_frames)).to(dev) if s_frames is not None else None
 
-            def run_sub(name, pipe_, frames_, offsets_, note, steps_=2):
+            def run_sub(name, pipe_, frames_, offsets_, note, steps_=2, roof=None, acc=False):
+                """roof = (torch dtype, split): also bracket the contraction launches with HIP events -> own roofline
+                block; acc: this mode's accuracy against the oracle on the cpu_baseline samples."""
                 def s_step():
                     sc = pipe_.score(frames_, offsets_)
                     return pipe_.select(sc, offsets_)
-                dt, sel, _ = timed_steps(s_step, steps_, 1, torch.cuda.synchronize)
+                dt, sel, prof_ = timed_steps(s_step, steps_, 1, torch.cuda.synchronize, 1 if roof else None)
                 n = offsets_[-1]
                 subs[name] = {"workload": note, "value": round(n * steps_ / dt, 1), "unit": "frames/s",
                               "steps": steps_, "ms_per_step": round(dt * 1e3 / steps_, 2),
                               "selected_frames": int(sum(len(s) for s in sel))}
+                if roof:
+                    subs[name]["roofline"] = roofline_from(prof_, roof[0], dt, (None, None), roof[1])
+                if acc and dev_samples is not None:
+                    a_ = accuracy_report(pipe_.score(dev_samples, s_off).cpu().numpy(), ref, s_off)
+                    subs[name]["accuracy"] = {k: (round(v, 8) if isinstance(v, float) else v) for k, v in a_.items()}
                 log(f"sub-result {name}: {subs[name]['value']} frames/s")
 
             base = cfg["name"] + f" ({total} frames), "
-            run_sub("frames_per_group_4", FrameScoringPipeline(extractor, scorer, use_inception=False,
-                                                               chunk_frames=args.chunk, frames_per_group=4),
-                    frames, offsets, base + "bf16, frames normalised in the reference's micro-batches of 4 inside "
-                    "each video (extractors.py:48), per-frame scores")
-            run_sub("resnet50+inception3", FrameScoringPipeline(extractor, scorer, use_inception=True,
-                                                                chunk_frames=min(args.chunk, 12288), frames_per_group=1),
+
+            def other_mode(dt_, split_):
+                e = VisualFeatureExtractor(dt_, "batch", f32_split=split_)
+                e.load_state_dict(extractor.state_dict())
+                return e.to(dev)
+
+            # bf16 throughput mode: what configs[1] names ("bf16"); fast, and NOT parity-grade - its accuracy is beside it
+            ext16 = other_mode(torch.bfloat16, False)
+            pipe16 = FrameScoringPipeline(ext16, scorer, use_inception=False, chunk_frames=24576, frames_per_group=1)
+            run_sub("bf16_throughput_mode", pipe16, frames, offsets, base + "bf16 storage and MFMA (8 significant bits "
+                    "per stored activation): the throughput mode; misses north_star's accuracy bars (accuracy beside it)",
+                    roof=(torch.bfloat16, False), acc=True)
+            run_sub("bf16_resnet50+inception3", FrameScoringPipeline(ext16, scorer, use_inception=True,
+                                                                     chunk_frames=min(args.chunk, 12288),
+                                                                     frames_per_group=1),
                     frames, offsets, base + "bf16, both trunks of VisualFeatureExtractor.forward (Inception-v3: eval "
                     "BatchNorm folded, 299x299 bilinear resize on the GPU)")
+            del ext16, pipe16
+            run_sub("frames_per_group_4", FrameScoringPipeline(extractor, scorer, use_inception=False,
+                                                               chunk_frames=args.chunk, frames_per_group=4),
+                    frames, offsets, base + args.dtype + ", frames normalised in the reference's micro-batches of 4 "
+                    "inside each video (extractors.py:48), per-frame scores")
             # PCIe-inclusive: the same headline step with the frames in pinned host memory, each pass uploaded by a
             # copy stream while the previous pass computes
             host_frames = torch.empty(frames.shape, dtype=torch.uint8, pin_memory=True)
             host_frames.copy_(frames)
             torch.cuda.synchronize()
-            run_sub("h2d_inclusive", pipe, host_frames, offsets, base + "bf16 headline step with the uint8 frames in "
-                    "PINNED HOST memory: every pass uploaded over PCIe by a copy stream into one of two staging "
-                    "buffers while the previous pass computes")
+            run_sub("h2d_inclusive", pipe, host_frames, offsets, base + args.dtype + " headline step with the uint8 "
+                    "frames in PINNED HOST memory: every pass uploaded over PCIe by a copy stream into one of two "
+                    "staging buffers while the previous pass computes")
             del host_frames
-            # fp32 parity mode: the arithmetic that meets north_star's accuracy bars
-            ext32 = VisualFeatureExtractor(torch.float32, "batch")
-            ext32.load_state_dict(extractor.state_dict())
-            ext32 = ext32.to(dev)
+            # exact fp32 MFMA
+            ext32 = other_mode(torch.float32, False)
             pipe32 = FrameScoringPipeline(ext32, scorer, use_inception=False, chunk_frames=4096, frames_per_group=1)
-            run_sub("fp32_parity_mode", pipe32, frames, offsets, base + "fp32 MFMA parity mode "
-                    "(v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak): the mode whose scores are within 1e-4 of the oracle",
-                    steps_=1)
-            if s_frames is not None:
-                dev_frames = torch.from_numpy(np.concatenate(s_frames)).to(dev)
-                a32 = accuracy_report(pipe32.score(dev_frames, s_off).cpu().numpy(), ref, s_off)
-                subs["fp32_parity_mode"]["accuracy"] = {k: (round(v, 8) if isinstance(v, float) else v)
-                                                        for k, v in a32.items()}
-                subs["fp32_parity_mode"]["accuracy"]["bars_met"] = bool(a32["score_max_abs_err"] <= 1e-4
-                                                                        and a32["f1_drift_max"] <= 1e-3)
-                del dev_frames
+            run_sub("fp32_exact_mode", pipe32, frames, offsets, base + "exact fp32 MFMA (v_mfma_f32_32x32x2_f32, "
+                    "157 TFLOP/s peak), fp32 storage", roof=(torch.float32, False), acc=True)
             del ext32, pipe32
             # fp32 storage, convolution products on the bf16 matrix cores as hi*hi + hi*lo + lo*hi (AVS_F32_SPLIT)
-            exts = VisualFeatureExtractor(torch.float32, "batch", f32_split=True)
-            exts.load_state_dict(extractor.state_dict())
-            exts = exts.to(dev)
+            exts = other_mode(torch.float32, True)
             pipes = FrameScoringPipeline(exts, scorer, use_inception=False, chunk_frames=4096, frames_per_group=1)
-            run_sub("fp32_split_mode", pipes, frames, offsets, base + "fp32 activations and weights, convolution "
-                    "products on the bf16 matrix cores as hi*hi + hi*lo + lo*hi (~2^-15 relative per product)", steps_=1)
-            if s_frames is not None:
-                dev_frames = torch.from_numpy(np.concatenate(s_frames)).to(dev)
-                asp = accuracy_report(pipes.score(dev_frames, s_off).cpu().numpy(), ref, s_off)
-                subs["fp32_split_mode"]["accuracy"] = {k: (round(v, 8) if isinstance(v, float) else v)
-                                                       for k, v in asp.items()}
-                subs["fp32_split_mode"]["accuracy"]["bars_met"] = bool(asp["score_max_abs_err"] <= 1e-4
-                                                                       and asp["f1_drift_max"] <= 1e-3)
-                del dev_frames
-            del exts, pipes
+            run_sub("fp32_split_mode", pipes, frames, offsets, base + "fp32 activations and weights split into bf16 hi + "
+                    "lo inside the contraction loop (~2^-15 relative per product)", roof=(torch.float32, True), acc=True)
+            del exts, pipes, dev_samples
             frames = None
             torch.cuda.empty_cache()
             subs["config2_audio_visual_fusion"] = config2_leg(extractor, scorer, dev, 1, 50)
@@ -529,8 +560,8 @@ def main():
             log(f"configs[3] share: {off3[-1]} frames ({off3[-1] * 150528 / 1e9:.1f} GB), generating")
             frames3 = synthetic.make_frames_uniform(off3[-1], dev, c3["seed"])
             run_sub("config3_one_rank_share", pipe, frames3, off3, "configs[3]: one rank's share of the 400 x "
-                    "5000-frame sharded inference (50 videos x 5000 frames, 37.6 GB of frames in HBM), bf16, "
-                    "per-frame shots; N > 1 is not measured here (one GPU per box)", steps_=1)
+                    "5000-frame sharded inference (50 videos x 5000 frames, 37.6 GB of frames in HBM), " + args.dtype +
+                    ", per-frame shots; N > 1 is not measured here (one GPU per box)", steps_=1)
             del frames3
 
         out = {

@@ -51,7 +51,18 @@ enum {
   AVS_E_UNSUPPORTED = -6 /* this entry point does not take the shape; use the documented alternative */
 };
 
-enum { AVS_F32 = 0, AVS_BF16 = 1, AVS_F32_ACC64 = 2, AVS_F32_SPLIT = 3 };
+enum { AVS_F32 = 0, AVS_BF16 = 1, AVS_F32_ACC64 = 2, AVS_F32_SPLIT = 3, AVS_F16X2 = 4 };
+/* AVS_F16X2 ("split-half" storage, the fast parity-grade arithmetic of the CNN trunk): a value is TWO fp16 numbers,
+ * x ~ hi + lo with hi = fp16(x), lo = fp16(x - hi) - 22 significant bits, an absolute floor of 2^-25 (fp16
+ * denormals, which the matrix cores keep), magnitudes saturating at 65504.  A tensor has the strides and the byte
+ * size of the fp32 tensor of the same shape ("slots" of 4 bytes, all strides below in slots); every aligned run of
+ * 8 slots (32 bytes) holds the 8 hi halves, then the 8 lo halves, of 8 consecutive elements of the innermost
+ * (channel / reduction) axis - so channel counts, strides and offsets are multiples of 8 slots and pointers 32-byte
+ * aligned.  The contraction kernel feeds the hi and lo runs to v_mfma_f32_32x32x16_f16 as they are: a product is
+ * hi*hi + hi*lo + lo*hi (error ~2^-21 relative, fp32 accumulation) with NO arithmetic on the operands in the loop;
+ * each output is split once, by the kernel that produces it.  Taken by avs_conv2d_nhwc, avs_conv2d_nhwc_bnstats,
+ * avs_conv2d_nhwc_bnlocal (no bias / alpha), avs_bn_batch_stats, avs_bn_apply, avs_bn_maxpool_nhwc, avs_pool2d_nhwc,
+ * avs_global_avgpool_nhwc (fp32 out), avs_frames_normalize_u8; avs_f16x2_pack_f32 / _unpack_f32 convert.         */
 enum { AVS_ACT_NONE = 0, AVS_ACT_RELU = 1 };
 enum { AVS_BIAS_NONE = 0, AVS_BIAS_COL = 1, AVS_BIAS_ROW = 2 };
 
@@ -63,6 +74,11 @@ const char* avs_last_error(void);
 /* CU count, max clock (kHz), total HBM bytes and gcnArchName of device `dev`. */
 int avs_device_info(int dev, int* cu_count, int* clock_khz, int64_t* hbm_bytes,
                     char* arch, int arch_len);
+
+/* fp32 [n] <-> AVS_F16X2 [n] (n a multiple of 8; the fp32 side 16-byte, the f16x2 side 32-byte aligned).  Weights
+ * are converted once per parameter version; the trunk's activations never leave the format.                      */
+int avs_f16x2_pack_f32(const float* d_src, void* d_dst, int64_t n, avs_stream_t stream);
+int avs_f16x2_unpack_f32(const void* d_src, float* d_dst, int64_t n, avs_stream_t stream);
 
 /* ---- dense contraction (K3, K6, K16-K20 of SURVEY §2.3) ------------------ */
 

@@ -82,6 +82,7 @@ def test_bench_pipeline_against_oracle(dev, kind, fpg):
             assert np.array_equal(p32.select(torch.from_numpy(s32[a:b]), [0, b - a])[0],
                                   np.flatnonzero(ref[a:b] > ref[a:b].mean()))
     assert r32["selection_agreement"] >= 1.0 - 2.0 / FRAMES and r32["f1_drift_max"] <= 1e-3
+    assert r32["bars_met"], r32
 
     # ---- fp32-split mode: fp32 storage, convolution products on the bf16 matrix cores as hi*hi + hi*lo + lo*hi
     from avsum_amd.features.extractors import VisualFeatureExtractor
@@ -93,6 +94,20 @@ def test_bench_pipeline_against_oracle(dev, kind, fpg):
     print(f"[{kind} fpg={fpg}] fp32-split vs oracle: {rs}")
     assert rs["score_max_abs_err"] < 1e-4                              # north_star's score bar holds
     assert rs["selection_agreement"] >= 0.99
+    assert rs["bars_met"], rs                                          # ... and so do the guard-banded decision bars
+
+    # ---- f16x2 mode (the bench headline): activations / weights stored as fp16 hi | lo runs, three fp16 MFMAs per
+    # product, centred BatchNorm statistics; must meet north_star's bars as bench.py evaluates them (same helper)
+    exth = VisualFeatureExtractor(torch.float32, "batch", f32_split="f16x2")
+    exth.load_state_dict(ext32.state_dict())
+    ph = FrameScoringPipeline(exth.to(dev), scorer, use_inception=False, chunk_frames=256, frames_per_group=fpg)
+    sh = ph.score(frames, offsets).cpu().numpy()
+    assert np.array_equal(sh, ph.score(frames, offsets).cpu().numpy())   # deterministic
+    rh = accuracy_report(sh, ref, offsets)
+    print(f"[{kind} fpg={fpg}] f16x2 vs oracle: {rh}")
+    assert rh["score_max_abs_err"] < 2e-5                              # measured ~5e-6: fp32-class
+    assert rh["bars_met"], rh
+    assert rh["selection_agreement"] >= 1.0 - 2.0 / FRAMES
 
     # ---- bf16 throughput mode (the bench's): deterministic; measured deviations, asserted as they are
     p16 = FrameScoringPipeline(ext16, scorer, use_inception=False, chunk_frames=12288, frames_per_group=fpg)
@@ -101,7 +116,9 @@ def test_bench_pipeline_against_oracle(dev, kind, fpg):
     r16 = accuracy_report(s16, ref, offsets)
     print(f"[{kind} fpg={fpg}] bf16 vs oracle: {r16}")
     assert np.isfinite(s16).all()
-    assert r16["score_max_abs_err"] < 0.4 * r16["score_range"]       # measured 0.13-0.20 of the range
-    assert r16["selection_agreement"] > 0.6                           # measured 0.72-0.78
-    assert r16["f1_drift_max"] < 0.25                                 # measured 0.02-0.09: NOT within 0.001
-    assert np.corrcoef(s16, ref)[0, 1] > 0.5                          # the ranking signal survives
+    assert not r16["bars_met"]                                        # bf16 does NOT carry parity: said, not hidden
+    # measured deviations + a small margin, so that a regression of a fused bf16 form shows here
+    assert r16["score_max_abs_err"] < 0.25 * r16["score_range"]      # measured 0.13-0.20 of the range
+    assert r16["selection_agreement"] > 0.68                          # measured 0.72-0.78
+    assert r16["f1_drift_max"] < 0.12                                 # measured 0.02-0.09: NOT within 0.001
+    assert np.corrcoef(s16, ref)[0, 1] > 0.9                          # the ranking signal survives

@@ -221,21 +221,23 @@ def test_bench_contract_line(dev):
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
     assert d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["steps"] == 1 and d["scaling"] == "weak"
-    assert d["vs_baseline"] is None and d["dtype"] == "bf16" and d["value"] > 0 and "workload" in d["config"]
+    assert d["vs_baseline"] is None and d["dtype"] == "f16x2" and d["value"] > 0 and "workload" in d["config"]
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["launches"] > 0 and r["avg_launch_us"] > 0 and r["algorithmic_bytes_per_launch"] > 0
+    assert abs(r["peak"] - 2500.0 / 3.0) < 1.0 and abs(r["mfma_rate_tflops"] - 3 * r["achieved"]) < 0.5
     assert r["traffic"] is None or "profiles/" in r["traffic_source"]   # replayed from a committed PMC summary, labelled
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "frames/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
     assert c["runs"] == 5 and c["min"] <= c["value"] <= c["max"]       # median of 5 runs
     a = d["accuracy"]                                                   # the timed arithmetic mode against the oracle
-    assert a["mode"] == "bf16" and a["deterministic"] is True and a["frames"] == 20 and a["videos"] == 5
-    assert 0.0 <= a["selection_agreement"] <= 1.0 and a["score_max_abs_err"] >= 0 and isinstance(a["bars_met"], bool)
+    assert a["mode"] == "f16x2" and a["deterministic"] is True and a["frames"] == 20 and a["videos"] == 5
+    assert 0.0 <= a["selection_agreement"] <= 1.0 and a["score_max_abs_err"] >= 0
+    assert a["bars_met"] is True and a["guard_band"] == 2e-4 and a["guarded_frames"] >= 0   # the headline carries parity
     assert d["sub_results"] is None                                     # only with the default headline
 
 
-@pytest.mark.parametrize("dtype,config", [("f32split", "1"), ("f32", "1"), ("bf16", "3")])
+@pytest.mark.parametrize("dtype,config", [("f32split", "1"), ("f32", "1"), ("bf16", "1"), ("f16x2", "3")])
 def test_bench_other_headlines(dev, dtype, config):
     """The non-default headlines of bench.py stay runnable: the fp32 parity / fp32-split arithmetic modes (whose
     roofline is priced against the fp32 peak / a third of the bf16 peak) and one rank's share of configs[3]."""
@@ -293,6 +295,7 @@ import os, sys, torch
 sys.path.insert(0, os.environ["AVS_ROOT"])
 import torch.distributed as dist
 from avsum_amd import dist as avd
+avd.FORCE_COLLECTIVES = True      # the product's exchanges take their real collective path in this one-rank group
 torch.cuda.set_device(0)
 dist.init_process_group(backend="nccl", rank=0, world_size=1)
 dev = torch.device("cuda", 0)
@@ -305,12 +308,16 @@ dist.all_gather(parts, t)
 assert torch.equal(parts[0], t)
 mod = torch.nn.Sequential(torch.nn.Linear(8, 3), torch.nn.BatchNorm1d(3)).to(dev)
 before = [p.detach().clone() for p in mod.parameters()]
-avd.broadcast_module(mod, 0)                         # C1 (world 1: identity)
+versions = [p._version for p in mod.parameters()]
+avd.broadcast_module(mod, 0)                         # C1: flat bucket per dtype through RCCL, copied back
 assert all(torch.equal(a, b) for a, b in zip(before, mod.parameters()))
+assert all(p._version > v for p, v in zip(mod.parameters(), versions))   # the bucket path really ran
 lengths = [5, 9, 2]
 local = torch.cat([torch.full((n,), float(v), device=dev) for v, n in enumerate(lengths)])
-out = avd.gather_video_scores(local, [0, 1, 2], lengths, 3)      # C2
-assert [o.shape[0] for o in out] == lengths and all(float(o[0]) == v for v, o in enumerate(out))
+out = avd.gather_video_scores(local, [2, 0, 1], lengths, 4)      # C2: padded all-gather, global ids, one id absent
+assert out[3] is None and [out[v].shape[0] for v in (2, 0, 1)] == lengths
+assert [float(out[v][0]) for v in (2, 0, 1)] == [0.0, 1.0, 2.0]
+assert all(o.data_ptr() != local.data_ptr() for o in out if o is not None)   # slices of the GATHERED buffers
 for i, p in enumerate(mod.parameters()):
     p.grad = torch.full_like(p, float(i + 1))
 avd.allreduce_gradients(mod)                         # C3
