@@ -131,7 +131,8 @@ class ResNet50Runner:
         self.trunk, self.dtype, self.bn_mode = trunk, dtype, bn_mode
         self.h2 = f32_split == "f16x2" and dtype == torch.float32
         self.f32_split = bool(f32_split) and not self.h2 and dtype == torch.float32
-        self.code = ops.dtype_code(dtype, "f16x2" if self.h2 else self.f32_split)
+        self.code = ops.dtype_code(dtype, "f16x2" if self.h2 else self.f32_split)   # the contraction entry points
+        self.ecode = self.code if self.h2 else ops.dtype_code(dtype)                 # storage format (elementwise kernels)
         self.fuse_conv_bn = True
         self.fuse_min_rows, self.fuse_ratio_num, self.fuse_ratio_den = 128, 2, 1
         self.twopass_max_cin = 128   # wider inputs (256 -> 1024 at 4-frame groups): the second matrix pass costs more than
@@ -265,11 +266,11 @@ class ResNet50Runner:
         def finish(scale, shift, grows, gmax):
             if pool is not None and residual is None:
                 out, k, s, p = pooled(y)
-                return ops.bn_maxpool(y, scale, shift, grows, relu, k, s, p, out, code=dcode)
-            ops.bn_apply(y2d, scale, shift, grows, gmax, residual, act, y2d, code=dcode)
+                return ops.bn_maxpool(y, scale, shift, grows, relu, k, s, p, out, code=self.ecode)
+            ops.bn_apply(y2d, scale, shift, grows, gmax, residual, act, y2d, code=self.ecode)
             if pool is not None:
                 out, k, s, p = pooled(y)
-                return ops.pool2d(y, "max", k, s, p, out, code=dcode)
+                return ops.pool2d(y, "max", k, s, p, out, code=self.ecode)
             return y
 
         if self.bn_mode != "batch":
@@ -287,7 +288,7 @@ class ResNet50Runner:
             conv(act=act, bnlocal=(gmax, gamma, beta, eps, residual))
             if pool is not None:
                 out, k, s, p = pooled(y)
-                return ops.pool2d(y, "max", k, s, p, out, code=dcode)
+                return ops.pool2d(y, "max", k, s, p, out, code=self.ecode)
             return y
         if in_affine is not None or (fast and bf16 and self._twopass_ok(cin, cout, kh, sh, gmax)):
             # statistics from the input's Gram matrix + ONE streaming pass where the shape allows it (the expanding
@@ -309,7 +310,7 @@ class ResNet50Runner:
             # fp32 parity mode / ragged groups / tiny groups (the fused form declined before launching anything):
             # plain convolution, then the shifted statistics pass over the stored output
             conv()
-            affine = ops.bn_batch_stats(y2d, grows, gamma, beta, eps, code=dcode)
+            affine = ops.bn_batch_stats(y2d, grows, gamma, beta, eps, code=self.ecode)
         if defer:
             return y, affine
         return finish(affine[0], affine[1], grows, gmax)
@@ -355,7 +356,7 @@ class ResNet50Runner:
             if raw:
                 x_aff = (sc0, sh0)
         else:
-            x0 = ops.frames_normalize(frames_u8, dt, 1.0, RESNET_MEAN, RESNET_STD, 230, 232, 3, 3, code=self.code)
+            x0 = ops.frames_normalize(frames_u8, dt, 1.0, RESNET_MEAN, RESNET_STD, 230, 232, 3, 3, code=self.ecode)
             geom, xs, _ = self._stem_geom(n)
             x = self._conv_bn(geom, xs, x0, w["stem"], w["bn1"], groups, local=stem_local, algo_k=147, pool=(3, 2, 1))
             del x0
@@ -417,7 +418,7 @@ class ResNet50Runner:
                               in_affine=aff2, res_affine=affd)
             del t2, idn
             hcur = hout
-        return ops.global_avgpool(x, out, code=self.code)
+        return ops.global_avgpool(x, out, code=self.ecode)
 
 
 # ============================================================================ Inception-v3 container

@@ -236,9 +236,8 @@ extern "C" int avs_resize_bilinear_u8(const uint8_t* d_src, int n, int sh, int s
 // ---------------------------------------------------------------------------
 // Batch-statistics BatchNorm: per (group, channel) mean / biased variance over
 // the group's rows, folded with gamma/beta into scale/shift.
-// Thread = 4 channels; a block is TC channel-threads x TR row-threads.  Sums
-// are taken about the group's first row (shifted data) so that the
-// E[d^2] - E[d]^2 form does not cancel.
+// Thread = 4 (8) channels; a block is TC channel-threads x TR row-threads; Welford
+// per row-thread + Chan's merge (see the kernel).
 // ---------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ void load4(const T* p, float (&v)[4]);
@@ -278,7 +277,11 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float eps, float* __restrict__ scale, float* __restrict__ shift,
                                                        int tc) {
+  // Welford's update per row-thread (running mean + sum of squares about it: nothing of the E[d^2] - E[d]^2 form, so a
+  // constant frame - whose first row, a border pixel, is an outlier - loses nothing), then Chan's merge of the
+  // row-threads in a fixed order.  Deterministic.
   __shared__ float red[2][256][V];
+  __shared__ int cnt[256];
   const int g = blockIdx.x;
   const int tr = 256 / tc;
   const int ct = threadIdx.x % tc;  // channel-thread
@@ -286,46 +289,49 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
   const int ch = (blockIdx.y * tc + ct) * V;
   const long long r0 = group_rows[g], r1 = group_rows[g + 1];
   const long long nrows = r1 - r0;
-  float s1[V], s2[V], ref[V];
+  float mean[V], m2[V];
 #pragma unroll
-  for (int j = 0; j < V; ++j) s1[j] = s2[j] = ref[j] = 0.f;
+  for (int j = 0; j < V; ++j) mean[j] = m2[j] = 0.f;
   const bool active = ch < c && nrows > 0;
+  int k = 0;
   if (active) {
-    loadv<T, V>(x + r0 * ldx + ch, ref);
     for (long long r = r0 + rt; r < r1; r += tr) {
       float v[V];
       loadv<T, V>(x + r * ldx + ch, v);
+      ++k;
+      const float inv_k = 1.f / (float)k;
 #pragma unroll
       for (int j = 0; j < V; ++j) {
-        const float d = v[j] - ref[j];
-        s1[j] += d;
-        s2[j] = fmaf(d, d, s2[j]);
+        const float d = v[j] - mean[j];
+        mean[j] = fmaf(d, inv_k, mean[j]);
+        m2[j] = fmaf(d, v[j] - mean[j], m2[j]);
       }
     }
   }
 #pragma unroll
   for (int j = 0; j < V; ++j) {
-    red[0][threadIdx.x][j] = s1[j];
-    red[1][threadIdx.x][j] = s2[j];
+    red[0][threadIdx.x][j] = mean[j];
+    red[1][threadIdx.x][j] = m2[j];
   }
+  cnt[threadIdx.x] = k;
   __syncthreads();
   if (rt == 0 && active) {
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-      float a = 0.f, b = 0.f;
-      for (int k = 0; k < tr; ++k) {
-        a += red[0][k * tc + ct][j];
-        b += red[1][k * tc + ct][j];
+      float n = 0.f, mu = 0.f, s2 = 0.f;
+      for (int q = 0; q < tr; ++q) {
+        const float nq = (float)cnt[q * tc + ct];
+        if (nq == 0.f) continue;
+        const float d = red[0][q * tc + ct][j] - mu, nn = n + nq;
+        mu = mu + d * (nq / nn);
+        s2 = s2 + red[1][q * tc + ct][j] + d * d * (n * nq / nn);
+        n = nn;
       }
-      const float inv_n = 1.f / (float)nrows;
-      const float md = a * inv_n;
-      float var = b * inv_n - md * md;
-      var = fmaxf(var, 0.f);
-      const float mean = ref[j] + md;
+      const float var = fmaxf(s2 / n, 0.f);
       const float rstd = 1.f / sqrtf(var + eps);
       const float sc = rstd * gamma[ch + j];
       scale[(long long)g * c + ch + j] = sc;
-      shift[(long long)g * c + ch + j] = beta[ch + j] - mean * sc;
+      shift[(long long)g * c + ch + j] = beta[ch + j] - mu * sc;
     }
   }
 }

@@ -117,14 +117,15 @@ def test_conv2d_f16x2_stem_geometry(dev):
     xn = (frames.float() / 1.0 - mean) / std                      # (x - mean) / std WITHOUT / 255 (extractors.py:133-139)
     ref_img = torch.zeros(3, 230, 232, 4)
     ref_img[:, 3:227, 3:227, :3] = xn
-    assert torch.equal(img.cpu().view(torch.int32), emu_pack(ref_img).view(torch.int32))
+    ref_p = emu_pack(ref_img.reshape(3, 230, 232 * 4)).reshape(3, 230, 232, 4)   # runs of 8 slots = two pixels
+    assert torch.equal(img.cpu().view(torch.int32), ref_p.view(torch.int32))
     g = torch.Generator().manual_seed(9)
     w4 = torch.randn(64, 3, 7, 7, generator=g) * 0.05
     wp = emu_pack(_stem_weight(w4, 8, torch.float32))
     geom, xs, wrs = ResNet50Runner._stem_geom(3)
     y = torch.empty((3, 112, 112, 64), device=dev)
     ops.conv2d_raw(ops.dtype_code(torch.float32, "f16x2"), *geom, img, *xs, wp.to(dev), wrs, y, 64, algo_k=147)
-    xv = emu_unpack(emu_pack(ref_img))[..., :3].double()
+    xv = emu_unpack(ref_p.reshape(3, 230, 232 * 4)).reshape(3, 230, 232, 4)[..., :3].double()
     wv = emu_unpack(wp).reshape(64, 7, 8, 4)[:, :, :7, :3].double()
     ref = F.conv2d(xv.permute(0, 3, 1, 2), wv.permute(0, 3, 1, 2), None, 2, 0).permute(0, 2, 3, 1)[:, :112, :112]
     got = ops.f16x2_unpack(y).cpu().double()
@@ -180,10 +181,17 @@ def test_conv_bnstats_f16x2(dev, cfg):
     y, sc, sh = res[0]
     got = ops.f16x2_unpack(y).cpu().double().reshape(-1, cout)
     assert (got - raw).abs().max().item() <= TOL * max(1.0, raw.abs().max().item())
-    # the variance is what is hard: relative error of scale = 0.5 * relative error of (var + eps)
-    assert ((sc.cpu().double() - sc_ref).abs() / sc_ref.abs()).max().item() < 2e-5
+    # the variance is what is hard: relative error of scale = 0.5 * relative error of (var + eps).  The statistics
+    # ALGORITHM is judged on the kernel's own output (float64 statistics of the values it stored): 2e-5.  Against the
+    # float64 convolution the fp32 accumulation error e of the outputs themselves enters through 2 cov(y, e) / var:
+    # with |y| ~ 2000 against a spread of 1 (the offset cases) that is a few 1e-5 more.
+    sc_own, sh_own = _group_stats(got, rpg, gamma, beta, 1e-5)
+    assert ((sc.cpu().double() - sc_own).abs() / sc_own.abs()).max().item() < 2e-5
     ynorm = raw.abs().max().item() * sc_ref.abs().max().item()
-    assert (sh.cpu().double() - sh_ref).abs().max().item() < 2e-5 * max(1.0, ynorm)
+    assert (sh.cpu().double() - sh_own).abs().max().item() < 2e-5 * max(1.0, ynorm)
+    loose = 2e-5 if not offset else 2e-4
+    assert ((sc.cpu().double() - sc_ref).abs() / sc_ref.abs()).max().item() < loose
+    assert (sh.cpu().double() - sh_ref).abs().max().item() < loose * max(1.0, ynorm)
 
 
 def test_bnstats_f16x2_declines_small_groups(dev):
@@ -339,13 +347,18 @@ def test_resnet50_trunk_f16x2_ragged_groups(dev):
 
 
 def test_low_contrast_frames_f16x2_vs_fp32(dev):
-    """Near-constant frames (black, a fade, letterbox bars): the stem's convolution output is then almost constant
-    per channel (mean^2 >> variance, inputs up to ~1100 because the reference does not divide by 255).  The f16x2
-    mode takes its statistics as centred two-round sums, so it stays with the exact-fp32 mode's shifted statistics
-    pass; the features must agree like on ordinary frames."""
+    """Near-constant frames (black, white, +-1 grey level of noise, letterbox bars, a faint ramp): the stem's convolution
+    output is then almost constant per channel (mean^2 >> variance; inputs reach ~1100 because the reference does not
+    divide by 255), which is where statistics of the E[y^2] - E[y]^2 form cancel.  The f16x2 mode takes centred
+    two-round sums.  Such frames are ill-conditioned for ANY arithmetic (interior pixels are identical, BatchNorm divides
+    by the little variance the borders leave, 53 times), so the bar is relative: against the fp32 ORACLE on the CPU the
+    f16x2 mode must not be materially worse than the exact-fp32 GPU mode is on the same frame."""
     from avsum_amd.cnn import ResNet50Runner, resnet50_trunk
+    from oracle import cnn as ocnn
     torch.manual_seed(3)
-    trunk = resnet50_trunk().to(dev)
+    trunk = resnet50_trunk()
+    sd = {k: v.clone() for k, v in trunk.state_dict().items()}
+    trunk = trunk.to(dev)
     rng = np.random.default_rng(0)
     frames = np.zeros((6, 224, 224, 3), dtype=np.uint8)
     frames[1] = 255
@@ -353,12 +366,19 @@ def test_low_contrast_frames_f16x2_vs_fp32(dev):
     frames[3, 40:184] = rng.integers(100, 104, (144, 224, 3))      # letterbox bars around a low-contrast picture
     frames[4] = np.linspace(0, 8, 224, dtype=np.float32)[None, :, None].astype(np.uint8)   # a faint ramp
     frames[5] = rng.integers(0, 256, (224, 224, 3))                # an ordinary frame for scale
+    with torch.no_grad():
+        oracle = torch.cat([ocnn.resnet50_trunk_forward(sd, ocnn.preprocess_frame(f)) for f in frames])
     fd = torch.from_numpy(frames).to(dev)
     got = ResNet50Runner(trunk, torch.float32, "batch", f32_split="f16x2").forward(fd).cpu()
-    ref = ResNet50Runner(trunk, torch.float32, "batch").forward(fd).cpu()
-    assert torch.isfinite(got).all() and torch.isfinite(ref).all()
+    g32 = ResNet50Runner(trunk, torch.float32, "batch").forward(fd).cpu()
+    assert torch.isfinite(got).all() and torch.isfinite(g32).all()
+    bad = []
     for i in range(6):
-        scale = max(1.0, ref[i].abs().max().item())
-        err = (got[i] - ref[i]).abs().max().item()
-        print(f"\nframe {i}: |f16x2 - fp32| = {err / scale:.2e} of the largest feature")
-        assert err < 2e-3 * scale
+        scale = max(1.0, oracle[i].abs().max().item())
+        e_h2 = (got[i] - oracle[i]).abs().max().item() / scale
+        e_32 = (g32[i] - oracle[i]).abs().max().item() / scale
+        print(f"\nframe {i}: f16x2 vs oracle {e_h2:.2e}, exact fp32 (GPU) vs oracle {e_32:.2e}, "
+              f"f16x2 vs exact fp32 (GPU) {(got[i] - g32[i]).abs().max().item() / scale:.2e} (of the largest feature)")
+        if e_h2 > 3.0 * max(e_32, 1e-4) or e_32 > 1e-3:   # (the exact mode's Welford statistics pass holds too)
+            bad.append(i)
+    assert not bad, bad
