@@ -235,6 +235,12 @@ class ResNet50Runner:
         return (kh == 1 and sh == 1 and self.fuse_conv_bn and gmax >= self.fuse_min_rows
                 and cout * self.fuse_ratio_den >= cin * self.fuse_ratio_num and cin <= self.twopass_max_cin)
 
+    def _gram_h2_ok(self, cin, cout, kh, sh, gmax):
+        """AVS_F16X2: the expanding 1x1 layers whose groups are too large for a tile take Gram statistics + one
+        streaming pass (64 / 128 input channels: conv3 of layers 1-2 and layer 1's downsample)."""
+        return (self.h2 and self.gram_stats and kh == 1 and sh == 1 and cin in (64, 128) and cout % 32 == 0
+                and cout >= 2 * cin and gmax >= self.fuse_min_rows)
+
     def _conv_bn(self, geom, xs, x, wt, bnp, groups, residual=None, relu=True, local=False, algo_k=None, pool=None,
                  defer=False, in_affine=None, res_affine=None):
         """One convolution + BatchNorm (+ residual, + ReLU) -> NHWC activation; picks the form (class docstring).
@@ -289,6 +295,15 @@ class ResNet50Runner:
             if pool is not None:
                 out, k, s, p = pooled(y)
                 return ops.pool2d(y, "max", k, s, p, out, code=self.ecode)
+            return y
+        if self.h2 and (in_affine is not None or (fast and not local and self._gram_h2_ok(cin, cout, kh, sh, gmax))):
+            # AVS_F16X2: statistics from the input's second moments (the pass that also applies the BatchNorm + ReLU of
+            # the layer before, in place), then ONE streaming convolution pass with the affine in its epilogue
+            x2d = x.view(-1, cin)
+            sc, sf = ops.bn_gram_affine_h2(x2d, wt.rows, gmax, gamma, beta, eps, in_affine, store_input=in_affine is not None)
+            wsel, layout = wt.conv_operand()
+            ops.conv2d_affine(dcode, n, geom[1], geom[2], cin, sh, geom[7], ho, wo, cout, x, *xs, wsel, wsel.stride(0), y, cout,
+                              gmax, sc, sf, residual, relu, res_affine, w_layout=layout)
             return y
         if in_affine is not None or (fast and bf16 and self._twopass_ok(cin, cout, kh, sh, gmax)):
             # statistics from the input's Gram matrix + ONE streaming pass where the shape allows it (the expanding
@@ -388,9 +403,9 @@ class ResNet50Runner:
             # bn2 + ReLU ride in conv3's input staging when conv3 takes the two-pass kernel: conv2 then only
             # writes its raw output and statistics (no apply pass over it)
             gmax3 = gsz * hout * hout
-            defer2 = (self.defer_bn_apply and self.bn_mode == "batch" and uniform and dt == torch.bfloat16
-                      and not s2 and not s3 and planes <= 512
-                      and self._twopass_ok(planes, planes * 4, 1, 1, gmax3))
+            defer2 = (self.defer_bn_apply and self.bn_mode == "batch" and uniform and not s2 and not s3 and
+                      ((dt == torch.bfloat16 and planes <= 512 and self._twopass_ok(planes, planes * 4, 1, 1, gmax3))
+                       or self._gram_h2_ok(planes, planes * 4, 1, 1, gmax3)))
             geom, xs, _ = self._nhwc_geom(n, hcur, planes, 3, s, 1, planes)
             t2 = self._conv_bn(geom, xs, t1, blk["c2"], blk["b2"], groups, local=s2, defer=defer2)
             aff2 = None

@@ -31,6 +31,7 @@
 // With SPATIAL = false (1x1 kernels without padding, linears, GEMMs) the
 // per-tap bounds tests compile away.
 #include "avs_internal.h"
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -69,6 +70,11 @@ struct IgemmParams {
   int w_kstep;       // 1: w is stored reduction-step major (AVS_W_KSTEP32), [K / S][N][S], S = 32 bf16 / 16 fp32: the 64 bytes a B row needs
                      //    in one step sit next to the neighbouring rows' (whole cache lines per DMA instruction)
   int tile_rows;     // EPI_BNLOCAL: rows of the tile that are used (whole groups), also the pitch between tiles
+  // EPI_AFFINE (AVS_F16X2): y = act((conv * scale[g] + shift[g]) + residual (* res_scale[g] + res_shift[g])), the folded
+  // affines given per group of rows_per_group rows: gamma / beta point at scale / shift [groups, N]
+  int affine;
+  const float* res_scale;
+  const float* res_shift;
 #ifdef AVS_STUDY
   int debug;  // ablation switches of the kernel-study build (tools/): 1 = skip output stores, 2 = skip A/B loads, ...
 #endif
@@ -123,7 +129,10 @@ __device__ __forceinline__ void avs_split_bf16(const float4& p0, const float4& p
 // (A form in which tiles of larger groups exchanged statistics through float atomics and waited for each other inside
 //  one launch was built in round 1 and removed: results were not reproducible run to run and it only won for groups of
 //  two or three tiles, which the tile-local form covers.)
-enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_ANY = 2, EPI_BRELU = 3, EPI_BNLOCAL = 5 };
+//   EPI_AFFINE AVS_F16X2, 1x1 convolutions on the 256-row tiles: a folded BatchNorm affine GIVEN per group of rows (computed
+//              beforehand from the input's Gram matrix, avs_bn_gram_affine_f16x2) + residual + ReLU: the one streaming
+//              pass of the expanding 1x1 layers whose groups are too large for a tile
+enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_ANY = 2, EPI_BRELU = 3, EPI_BNLOCAL = 5, EPI_AFFINE = 6 };
 constexpr int BNLOCAL_MAX_GROUPS = 6;  // groups per 256-row tile (rows_per_group >= 43)
 constexpr int STATS_MIN_GROUP_ROWS = 64;  // EPI_STATS: a wave's 64 rows then overlap at most two groups
 
@@ -694,8 +703,9 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
     // in tile order (bn_fold_kernel).  Deterministic: fixed orders, no atomics.
     // Output: every wave stages 32 of its rows at a time in LDS as fp32 (row-major) and reads them back as runs of 8
     // columns: residual added and ReLU applied in fp32, then ONE split into fp16 hi | lo and two 16-byte stores.
-    static_assert(EPI == EPI_PLAIN || EPI == EPI_STATS || EPI == EPI_BNLOCAL, "epilogue forms built for AVS_F16X2");
-    static_assert(EPI != EPI_BNLOCAL || WR == 4, "the tile-local BatchNorm runs on the 256-row tiles");
+    static_assert(EPI == EPI_PLAIN || EPI == EPI_STATS || EPI == EPI_BNLOCAL || EPI == EPI_AFFINE,
+                  "epilogue forms built for AVS_F16X2");
+    static_assert((EPI != EPI_BNLOCAL && EPI != EPI_AFFINE) || WR == 4, "the BatchNorm forms run on the 256-row tiles");
     float* const fl = reinterpret_cast<float*>(lds);
     // masked sums over this lane's 32 rows of column tile nt: rows with lo <= roff < hi (roff = row inside the wave's
     // 64 rows minus 4 * lh); both lane halves return the column's total over the wave's rows
@@ -733,6 +743,38 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
     float sc0[NT], sf0[NT], sc1[NT], sf1[NT], sc2[NT], sf2[NT];
     int bnd1 = 1 << 30, bnd2 = 1 << 30;   // first roff of the wave's second / third group
     int used = A_ROWS;                    // EPI_BNLOCAL: rows of this tile that exist
+    if constexpr (EPI == EPI_BNLOCAL) used = (m0 + p.tile_rows <= p.M ? p.tile_rows : p.M - m0);
+    constexpr int G = WCOLS / 8;            // runs of 8 columns per staged row
+    constexpr int NU = (32 * G) / 64;       // runs per lane and half
+    constexpr int RSTEP = 64 / G;           // staged rows between a lane's consecutive runs
+    constexpr bool NORM = EPI == EPI_BNLOCAL || EPI == EPI_AFFINE;
+    float* const wreg = fl + wave * (32 * H2_P);
+    const bool relu = NORM && p.act == AVS_ACT_RELU;
+    // a lane's runs: staged row rl0 + it * RSTEP of a half, columns 8 * grp .. + 7
+    const int rl0 = lane / G, grp = lane % G;
+    const int col8 = n0 + wc * WCOLS + grp * 8;
+    const int row_lim = (EPI == EPI_BNLOCAL ? m0 + used : p.M);   // rows at or past this one do not exist
+    const bool col_ok = col8 < p.N;
+    // the residual rows of a half are in flight before that half is staged: one memory latency per half instead of one
+    // per run.  Rows / columns that do not exist read the residual's first run (never used): no divergent branch
+    // around the loads (and hipcc 7.2 crashes in machine copy propagation on a zero-filling else branch).
+    uint4 rhi[2][NORM ? NU : 1], rlo[2][NORM ? NU : 1];
+    auto res_fetch = [&](auto half) {
+      constexpr int mt = decltype(half)::value;
+      if constexpr (NORM) {
+        const long long row0 = (long long)m0 + wr * 64 + mt * 32 + rl0;
+        const char* base = p.residual + (row0 * p.ldr + col8) * 4;
+        const long long step = (long long)RSTEP * p.ldr * 4;
+#pragma unroll
+        for (int it = 0; it < NU; ++it) {
+          const bool ok = col_ok && row0 + it * RSTEP < row_lim;
+          const uint4* rp = reinterpret_cast<const uint4*>(ok ? base + it * step : p.residual);
+          rhi[mt][it] = rp[0];
+          rlo[mt][it] = rp[1];
+        }
+      }
+    };
+    if (NORM && p.residual) res_fetch(std::integral_constant<int, 0>{});   // in flight during the statistics rounds
     if constexpr (EPI == EPI_STATS) {
       const int rpg = p.rows_per_group;
       float* const T1 = fl;                      // [WR][2][BN] sums of the wave rows' (at most two) groups
@@ -800,7 +842,6 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
     }
     if constexpr (EPI == EPI_BNLOCAL) {
       const int rpg = p.rows_per_group;
-      used = (m0 + p.tile_rows <= p.M ? p.tile_rows : p.M - m0);
       const int ng = used / rpg;                   // whole groups (M is a multiple of rpg)
       float* const R1 = fl;                        // [WR][ng][BN]
       float* const R2 = fl + WR * BNLOCAL_MAX_GROUPS * BN;
@@ -872,48 +913,83 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
       }
       __syncthreads();   // the tables alias the staging regions
     }
+    if constexpr (EPI == EPI_AFFINE) {
+      // the given affines of the (up to three) groups this wave's 64 rows lie in
+      const int rpg = p.rows_per_group;
+      const int r_first = m0 + wr * 64;
+      const int gl = (p.M - 1) / rpg;                       // last group
+      const int ga = r_first / rpg < gl ? r_first / rpg : gl;
+      const int gb = ga + 1 < gl ? ga + 1 : gl, gc = ga + 2 < gl ? ga + 2 : gl;
+      bnd1 = (ga + 1) * rpg - r_first - 4 * lh;
+      bnd2 = bnd1 + rpg;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int col = n0 + wc * WCOLS + nt * 32 + lr;
+        const bool cv = col < p.N;
+        sc0[nt] = cv ? p.gamma[(long long)ga * p.N + col] : 0.f, sf0[nt] = cv ? p.beta[(long long)ga * p.N + col] : 0.f;
+        sc1[nt] = cv ? p.gamma[(long long)gb * p.N + col] : 0.f, sf1[nt] = cv ? p.beta[(long long)gb * p.N + col] : 0.f;
+        sc2[nt] = cv ? p.gamma[(long long)gc * p.N + col] : 0.f, sf2[nt] = cv ? p.beta[(long long)gc * p.N + col] : 0.f;
+      }
+    }
     // ---- staging + stores, 32 rows of the wave at a time
-    constexpr int G = WCOLS / 8;            // runs of 8 columns per staged row
-    constexpr int NU = (32 * G) / 64;       // runs per lane and half
-    float* const wreg = fl + wave * (32 * H2_P);
-    const bool relu = EPI == EPI_BNLOCAL && p.act == AVS_ACT_RELU;
-    const bool aligned_rows = (p.ldc % 8 == 0);
+    if constexpr (NORM) {
+      // normalise in place first: the affines' registers are free before the residual rows of the second half arrive
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int roff = mt * 32 + (e & 3) + 8 * (e >> 2);
+            const bool in1 = roff >= bnd1, in2 = roff >= bnd2;
+            const float sc = in2 ? sc2[nt] : (in1 ? sc1[nt] : sc0[nt]);
+            const float sf = in2 ? sf2[nt] : (in1 ? sf1[nt] : sf0[nt]);
+            acc[mt][nt][e] = fmaf(acc[mt][nt][e], sc, sf);
+          }
+    }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int rl = (e & 3) + 8 * (e >> 2);   // + 4 * lh = the row inside this half
-          float v = acc[mt][nt][e];
-          if constexpr (EPI == EPI_BNLOCAL) {
-            const int roff = mt * 32 + rl;
-            const bool in1 = roff >= bnd1, in2 = roff >= bnd2;
-            const float sc = in2 ? sc2[nt] : (in1 ? sc1[nt] : sc0[nt]);
-            const float sf = in2 ? sf2[nt] : (in1 ? sf1[nt] : sf0[nt]);
-            v = fmaf(v, sc, sf);
-          }
-          wreg[(rl + 4 * lh) * H2_P + nt * 32 + lr] = v;
-        }
+        for (int e = 0; e < 16; ++e)
+          wreg[((e & 3) + 8 * (e >> 2) + 4 * lh) * H2_P + nt * 32 + lr] = acc[mt][nt][e];
+      // half 1's residual rows: in flight while half 0 is processed (its accumulators have just left their registers)
+      if (mt == 0 && NORM && p.residual) res_fetch(std::integral_constant<int, 1>{});
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
+      const long long row0 = (long long)m0 + wr * 64 + mt * 32 + rl0;
+      char* const ybase = y + (row0 * p.ldc + col8) * 4;
+      const long long ystep = (long long)RSTEP * p.ldc * 4;
 #pragma unroll
       for (int it = 0; it < NU; ++it) {
-        const int u = it * 64 + lane;
-        const int rl = u / G, grp = u % G;
-        const int trow = wr * 64 + mt * 32 + rl;               // row inside the tile
-        const long long row = (long long)m0 + trow;
-        const int col = n0 + wc * WCOLS + grp * 8;
-        const bool ok = (EPI == EPI_BNLOCAL ? trow < used : row < p.M) && col < p.N;
-        const float4 f0 = *reinterpret_cast<const float4*>(wreg + rl * H2_P + grp * 8);
-        const float4 f1 = *reinterpret_cast<const float4*>(wreg + rl * H2_P + grp * 8 + 4);
-        if (!ok) continue;
+        const float* src = wreg + (rl0 + it * RSTEP) * H2_P + grp * 8;
+        const float4 f0 = *reinterpret_cast<const float4*>(src);
+        const float4 f1 = *reinterpret_cast<const float4*>(src + 4);
+        const long long row = row0 + it * RSTEP;
+        if (!(col_ok && row < row_lim)) continue;
         float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-        if constexpr (EPI == EPI_BNLOCAL) {
+        if constexpr (NORM) {
           if (p.residual) {
-            const uint4* rp = reinterpret_cast<const uint4*>(p.residual + (row * p.ldr + col) * 4);
             float rv[8];
-            avs_f16x2_join8(rp[0], rp[1], rv);
+            // (through an empty asm: the conversions below then stay HERE - the scheduler otherwise expands every packed
+            //  residual run to floats right behind the loads and the 128-column tiles spill)
+            avs_pin(rhi[mt][it]);
+            avs_pin(rlo[mt][it]);
+            avs_f16x2_join8(rhi[mt][it], rlo[mt][it], rv);
+            if constexpr (EPI == EPI_AFFINE) {
+              if (p.res_scale) {   // the residual is a raw convolution output: its BatchNorm rides in the add
+                const long long gq = (row / p.rows_per_group) * p.N + col8;
+                const float4 a0 = *reinterpret_cast<const float4*>(p.res_scale + gq);
+                const float4 a1 = *reinterpret_cast<const float4*>(p.res_scale + gq + 4);
+                const float4 b0 = *reinterpret_cast<const float4*>(p.res_shift + gq);
+                const float4 b1 = *reinterpret_cast<const float4*>(p.res_shift + gq + 4);
+                const float as[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                const float bs[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) rv[j] = fmaf(rv[j], as[j], bs[j]);
+              }
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += rv[j];
           }
@@ -924,14 +1000,13 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
         }
         uint4 hi, lo;
         avs_f16x2_split8(v, hi, lo);
-        uint4* dst = reinterpret_cast<uint4*>(y + (row * p.ldc + col) * 4);
+        uint4* dst = reinterpret_cast<uint4*>(ybase + it * ystep);
         dst[0] = hi;
         dst[1] = lo;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
     }
-    (void)aligned_rows;
   } else {
   // Register e of a 32x32 tile is row (e&3) + 8*(e>>2) + 4*lh, column lr.
   constexpr int E_CPRW = BN / 8;           // 16-byte chunks per bf16 tile row
@@ -1359,6 +1434,10 @@ static void igemm_dispatch_epi4(int epi, dim3 grid, hipStream_t stream, const Ig
       else if constexpr (WR == 4) {
         if (epi == EPI_BNLOCAL)
           hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BNLOCAL, PIPE, WR, FK, 2>), grid, dim3(256), 0, stream, p);
+        if constexpr (!SP && ROWB == 64 && PIPE) {   // (the launcher only sends 1x1 shapes on the pipelined 256-row tiles here)
+          if (epi == EPI_AFFINE)
+            hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_AFFINE, PIPE, WR, FK, 2>), grid, dim3(256), 0, stream, p);
+        }
       }
       return;
     }
@@ -1444,6 +1523,8 @@ static void igemm_dispatch(bool spatial, dim3 grid, hipStream_t stream, const Ig
   int epi = EPI_ANY;
   if (p.tile_rows)
     epi = EPI_BNLOCAL;
+  else if (p.affine)
+    epi = EPI_AFFINE;
   else if (p.bias_mode == AVS_BIAS_NONE && p.act == AVS_ACT_NONE && p.alpha == 1.0f)
     epi = p.stat_part ? EPI_STATS : EPI_PLAIN;
   else if (p.bias_mode == AVS_BIAS_COL && p.act == AVS_ACT_RELU && p.alpha == 1.0f && !p.stat_part)
@@ -1470,7 +1551,7 @@ static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream
   AVS_REQUIRE(dtype == AVS_F32 || dtype == AVS_BF16 || dtype == AVS_F32_ACC64 || dtype == AVS_F32_SPLIT ||
                   dtype == AVS_F16X2, AVS_E_ARG, "%s: bad dtype %d", who, dtype);
   if (dtype == AVS_F16X2) {
-    const bool fixed = p.alpha == 1.0f && p.bias_mode == AVS_BIAS_NONE && (p.act == AVS_ACT_NONE || p.tile_rows);
+    const bool fixed = p.alpha == 1.0f && p.bias_mode == AVS_BIAS_NONE && (p.act == AVS_ACT_NONE || p.tile_rows || p.affine);
     AVS_REQUIRE(fixed, AVS_E_UNSUPPORTED, "%s: AVS_F16X2 takes no bias / scaling / activation outside the BatchNorm form", who);
     AVS_REQUIRE(p.N % 8 == 0 && p.ldc % 8 == 0 && (p.sC % 8) == 0, AVS_E_SHAPE,
                 "%s: AVS_F16X2 needs cout and the output strides in multiples of 8 slots", who);
@@ -1510,7 +1591,7 @@ static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream
                                      (narrow || (long long)p.K * es >= g_tall_min_k_bytes))))
       p.tall = 1;
   }
-  if (p.tile_rows) p.tall = 1;  // EPI_BNLOCAL (validated by bnsync_plan): 256-row tiles at a pitch of tile_rows
+  if (p.tile_rows || p.affine) p.tall = 1;  // EPI_BNLOCAL (validated by bnlocal_plan): 256-row tiles at a pitch of tile_rows
   const int tile_rows = p.tile_rows ? p.tile_rows : (p.tall ? 256 : 128);
   const long long tiles_m = ((long long)p.M + tile_rows - 1) / tile_rows;
   const long long total = tiles_m * p.tiles_n;
@@ -1772,6 +1853,43 @@ extern "C" int avs_conv2d_nhwc_bnlocal(const avs_conv_desc* d, const void* d_x, 
   p.ldr = ldr;
   p.bias_mode = AVS_BIAS_NONE;
   return igemm_launch(d->dtype, p, 1, (hipStream_t)stream, who);
+}
+
+// ---- 1x1 convolution with a GIVEN per-group affine (+ residual, + its affine, + ReLU): one streaming pass (EPI_AFFINE) ----
+extern "C" int avs_conv2d_nhwc_affine(const avs_conv_desc* d, const void* d_x, const void* d_w, void* d_y,
+                                      int64_t rows_per_group, const float* d_scale, const float* d_shift,
+                                      const void* d_residual, int64_t ldr, const float* d_res_scale,
+                                      const float* d_res_shift, avs_stream_t stream) {
+  const char* who = "avs_conv2d_nhwc_affine";
+  IgemmParams p{};
+  int st = conv_fill_params(d, d_x, d_w, nullptr, d_y, p, who);
+  if (st != AVS_OK) return st;
+  if (p.M == 0) return AVS_OK;
+  AVS_REQUIRE(d->dtype == AVS_F16X2, AVS_E_UNSUPPORTED, "%s: built for AVS_F16X2", who);
+  AVS_REQUIRE(d->kh == 1 && d->kw == 1 && d->ph == 0 && d->pw == 0 && (long long)p.K * 4 > 128 && d->alpha == 1.0f,
+              AVS_E_UNSUPPORTED, "%s: 1x1 convolutions without padding, more than 32 input channels, alpha = 1", who);
+  AVS_REQUIRE(rows_per_group >= 32 && rows_per_group < (1ll << 30), AVS_E_UNSUPPORTED,
+              "%s: groups of at least 32 rows (a wave's 64 rows then lie in at most three groups)", who);
+  AVS_REQUIRE(d_scale && d_shift && avs_aligned16(d_scale) && avs_aligned16(d_shift), AVS_E_ARG,
+              "%s: scale / shift [groups, cout] must be given, 16-byte aligned", who);
+  AVS_REQUIRE((d_res_scale == nullptr) == (d_res_shift == nullptr) && (!d_res_scale || d_residual), AVS_E_ARG,
+              "%s: residual scale and shift go together, with a residual", who);
+  AVS_REQUIRE(!d_res_scale || (avs_aligned16(d_res_scale) && avs_aligned16(d_res_shift)), AVS_E_ALIGN,
+              "%s: residual scale / shift must be 16-byte aligned", who);
+  AVS_REQUIRE(!d_residual || ((((uintptr_t)d_residual) & 31u) == 0 && ldr % 8 == 0 && ldr >= p.N), AVS_E_ALIGN,
+              "%s: the residual must be 32-byte aligned with a row stride in multiples of 8 slots, at least cout", who);
+  AVS_REQUIRE(g_pipe3, AVS_E_UNSUPPORTED, "%s: needs the pipelined tile variants (avs_tune_pipeline(1))", who);
+  p.affine = 1;
+  p.rows_per_group = (int)rows_per_group;
+  p.gamma = d_scale;
+  p.beta = d_shift;
+  p.residual = (const char*)d_residual;
+  p.ldr = ldr;
+  p.res_scale = d_res_scale;
+  p.res_shift = d_res_shift;
+  p.bias_mode = AVS_BIAS_NONE;
+  st = igemm_launch(d->dtype, p, 1, (hipStream_t)stream, who);
+  return st;
 }
 
 extern "C" int avs_gemm_nt(int dtype, int m, int n, int k, const void* d_a, int64_t lda, int64_t stride_a,

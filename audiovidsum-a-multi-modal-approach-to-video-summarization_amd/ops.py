@@ -15,7 +15,7 @@ __all__ = [
     "ACT_NONE", "ACT_RELU", "linear", "gemm_nt_batched", "conv2d", "conv2d_raw", "conv_bnlocal_tile_rows", "conv1x1_bn", "conv1x1_gram_bn", "bn_gram_affine", "gram_supported", "frames_normalize", "stem_conv_bn_pool", "resize_bilinear",
     "bn_batch_stats", "bn_apply", "bn_maxpool", "pool2d", "global_avgpool", "segment_mean", "hsv_frame_diff", "reflect_pad", "stft_f64", "stft_mel_fused", "power_mel",
     "clamp_topdb", "fill", "quantize", "resample", "lstm", "mha_batchaxis", "score_head", "mhsa_flash", "softmax_rows", "cdist", "dtw_path",
-    "gather_scale", "dtype_code", "f16x2_pack", "f16x2_unpack",
+    "gather_scale", "dtype_code", "f16x2_pack", "f16x2_unpack", "bn_gram_affine_h2", "conv2d_affine",
 ]
 
 
@@ -411,6 +411,65 @@ def conv1x1_gram_bn(x2d, wt, rows_per_group, gamma, beta, eps, out2d, residual=N
     else:
         scale, shift = bn_gram_affine(x2d, wt, rows_per_group, gamma, beta, eps, in_affine)
     return conv1x1_affine(x2d, wt, rows_per_group, scale, shift, out2d, residual, relu, in_affine, res_affine)
+
+
+def bn_gram_affine_h2(x2d, wt, rows_per_group, gamma, beta, eps, in_affine=None, store_input=False):
+    """AVS_F16X2 counterpart of bn_gram_affine (avs_bn_gram_affine_f16x2): x2d / wt are f16x2 tensors (float32-typed).
+    Returns the folded affine (scale, shift) fp32 [groups, N] of the BatchNorm of y = a . wt^T.  in_affine = (isc, ish)
+    fp32 [groups, K]: x2d is a raw convolution output, a = relu(x2d * isc + ish); store_input: a overwrites x2d."""
+    _dev(x2d, wt, gamma, beta)
+    _rowmajor2d(x2d, "x")
+    _rowmajor2d(wt, "w")
+    _f32(x2d, "x")
+    _f32(wt, "w")
+    rows, k = x2d.shape
+    n = wt.shape[0]
+    if rows % rows_per_group or wt.shape[1] != k:
+        raise ValueError("bn_gram_affine_h2: shapes do not match")
+    groups = rows // rows_per_group
+    isc = ish = None
+    if in_affine is not None:
+        isc, ish = in_affine
+        _dev(isc, ish)
+        if isc.shape != (groups, k) or ish.shape != (groups, k) or not isc.is_contiguous() or not ish.is_contiguous():
+            raise ValueError("in_affine must be contiguous fp32 [groups, K]")
+    if store_input and in_affine is None:
+        raise ValueError("store_input needs in_affine")
+    scale = torch.empty((groups, n), dtype=torch.float32, device=x2d.device)
+    shift = torch.empty((groups, n), dtype=torch.float32, device=x2d.device)
+    _timed("gram", AVS_F16X2, 4.0 * rows * k * (2 if store_input else 1), lambda: check(
+        lib().avs_bn_gram_affine_f16x2(_p(x2d), x2d.stride(0), k, _p(isc), _p(ish), _p(wt), wt.stride(0), n,
+                                       rows_per_group, groups, _p(gamma), _p(beta), float(eps), _p(scale), _p(shift),
+                                       _p(x2d) if store_input else None, x2d.stride(0), _stream()),
+        "avs_bn_gram_affine_f16x2"))
+    return scale, shift
+
+
+def conv2d_affine(dtype, n, h, w, cin, sh, sw, ho, wo, cout, x, x_img_stride, x_row_stride, x_px_stride, wt,
+                  w_row_stride, y, y_px_stride, rows_per_group, scale, shift, residual=None, relu=True,
+                  res_affine=None, w_layout=0):
+    """1x1 convolution + a GIVEN per-group affine (+ residual, + its affine, + ReLU) in one streaming pass
+    (avs_conv2d_nhwc_affine, AVS_F16X2).  scale / shift fp32 [groups, cout]; residual f16x2 [rows, cout]."""
+    _dev(x, wt, y, scale, shift, residual)
+    d = _abi.ConvDesc(dtype, n, h, w, cin, 1, 1, sh, sw, 0, 0, ho, wo, cout, x_img_stride, x_row_stride, x_px_stride,
+                      w_row_stride, y_px_stride, ACT_RELU if relu else ACT_NONE, 1.0, int(w_layout))
+    rows = n * ho * wo
+    groups = (rows + rows_per_group - 1) // rows_per_group
+    for a in (scale, shift):
+        if a.dtype != torch.float32 or a.shape != (groups, cout) or not a.is_contiguous():
+            raise ValueError("scale / shift must be contiguous fp32 [groups, cout]")
+    rsc, rsh = res_affine if res_affine is not None else (None, None)
+    if residual is not None:
+        _rowmajor2d(residual, "residual")
+        if residual.shape != (rows, cout):
+            raise ValueError("residual must be [rows, cout]")
+    flops = 2.0 * rows * cout * cin
+    nbytes = 4.0 * (rows * cin + rows * cout * (2 if residual is not None else 1))
+    _timed("conv", dtype, flops, lambda: check(
+        lib().avs_conv2d_nhwc_affine(ctypes.byref(d), _p(x), _p(wt), _p(y), int(rows_per_group), _p(scale), _p(shift),
+                                     _p(residual), residual.stride(0) if residual is not None else 0, _p(rsc), _p(rsh),
+                                     _stream()), "avs_conv2d_nhwc_affine"), nbytes)
+    return y
 
 
 def weights_kstep32(wt):

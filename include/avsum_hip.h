@@ -144,6 +144,31 @@ int avs_conv2d_bnlocal_tile_rows(const avs_conv_desc* desc, int64_t rows_per_gro
 int avs_conv2d_nhwc_bnlocal(const avs_conv_desc* desc, const void* d_x, const void* d_w, void* d_y,
                             int64_t rows_per_group, const float* d_gamma, const float* d_beta, float eps,
                             const void* d_residual, int64_t ldr, avs_stream_t stream);
+/* AVS_F16X2, 1x1 convolutions whose BatchNorm groups are too large for a tile (the expanding 1x1 layers of ResNet
+ * layers 1-2: conv3 and the downsample branch, features/extractors.py:29,65): the batch statistics of the OUTPUT are
+ * taken from the second moments of the narrow INPUT (avs_bn_gram_affine_f16x2: mean_y = W mean(a),
+ * var_y[n] = w_n^T C w_n, C = a^T a / R - mean mean^T per group), then the convolution is ONE streaming pass with the
+ * folded affine in its epilogue (avs_conv2d_nhwc_affine) - the wide output is written once and never re-read.
+ *
+ * avs_bn_gram_affine_f16x2: x [groups * rows_per_group, k] (k = 64 | 128, row stride lin_stride slots), w [n, k]
+ * (n a multiple of 32), both AVS_F16X2.  With d_in_scale / d_in_shift fp32 [groups, k] x is the RAW output of the
+ * convolution before, a = relu(x * in_scale + in_shift) (that layer's BatchNorm + ReLU: this pass is its apply
+ * pass) and, with d_a_out (may be d_x itself), the finished activation is stored.  Out: the folded affine of the
+ * output BatchNorm, d_scale / d_shift fp32 [groups, n] = gamma / sqrt(var_y + eps), beta - mean_y * scale.
+ * Deterministic; ~1e-6 relative on var_y for post-ReLU inputs (E[a a^T] - m m^T is formed in fp32).
+ *
+ * avs_conv2d_nhwc_affine: y = act((conv(x) * scale[g] + shift[g]) + residual * res_scale[g] + res_shift[g]),
+ * g = output_row / rows_per_group (>= 32), desc->dtype AVS_F16X2, 1x1 kernel without padding, more than 32 input
+ * channels; scale / shift (and the optional residual affine: the residual is then itself a raw convolution output)
+ * fp32 [groups, cout]; residual AVS_F16X2 [rows, cout] with row stride ldr or NULL; act = desc->act.              */
+int avs_bn_gram_affine_f16x2(const void* d_x, int64_t lin_stride, int k, const float* d_in_scale,
+                             const float* d_in_shift, const void* d_w, int64_t ldb, int n, int64_t rows_per_group,
+                             int groups, const float* d_gamma, const float* d_beta, float eps, float* d_scale,
+                             float* d_shift, void* d_a_out, int64_t lda, avs_stream_t stream);
+int avs_conv2d_nhwc_affine(const avs_conv_desc* desc, const void* d_x, const void* d_w, void* d_y,
+                           int64_t rows_per_group, const float* d_scale, const float* d_shift,
+                           const void* d_residual, int64_t ldr, const float* d_res_scale, const float* d_res_shift,
+                           avs_stream_t stream);
 /* Tuning knob: 0 makes avs_conv2d_bnlocal_tile_rows decline every shape.                                      */
 void avs_tune_bnlocal(int enabled);
 

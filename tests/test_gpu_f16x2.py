@@ -382,3 +382,74 @@ def test_low_contrast_frames_f16x2_vs_fp32(dev):
         if e_h2 > 3.0 * max(e_32, 1e-4) or e_32 > 1e-3:   # (the exact mode's Welford statistics pass holds too)
             bad.append(i)
     assert not bad, bad
+
+
+@pytest.mark.parametrize("rpg,k,n,xf,with_res,ra", [
+    (3136, 64, 256, True, True, False),     # layer1 conv3: raw conv2 output in, identity residual
+    (3136, 64, 256, False, False, False),   # layer1 downsample: finished input, no residual, no ReLU
+    (784, 128, 512, True, True, True),      # layer2 conv3 of the first block: the residual is the RAW downsample output
+    (784, 128, 512, True, True, False),
+    (196, 64, 96, True, False, False),      # odd sizes: 196-row groups, 96 outputs (one 128-wide tile, partly used)
+    (100, 128, 64, False, True, False),     # 64-wide tile, groups of 100 rows (a wave's rows straddle groups)
+])
+def test_gram_statistics_and_affine_pass_f16x2(dev, rpg, k, n, xf, with_res, ra):
+    """avs_bn_gram_affine_f16x2 (statistics of y = a . w^T from the second moments of a, the input's BatchNorm + ReLU
+    applied and stored in place) + avs_conv2d_nhwc_affine (one streaming pass) against float64; deterministic."""
+    ops = _ops()
+    code = ops.dtype_code(torch.float32, "f16x2")
+    groups = 5
+    rows = groups * rpg
+    g = torch.Generator().manual_seed(rpg + k + n)
+    xp = emu_pack(torch.randn(rows, k, generator=g) * 2 + 0.5)
+    wp = emu_pack(torch.randn(n, k, generator=g) / k ** 0.5)
+    gamma, beta = torch.rand(n, generator=g) + 0.5, torch.randn(n, generator=g)
+    isc, ish = torch.rand(groups, k, generator=g) + 0.5, torch.randn(groups, k, generator=g) * 0.5
+    xv, wv = emu_unpack(xp).double(), emu_unpack(wp).double()
+    gid = torch.arange(rows) // rpg
+    if xf:
+        a32 = torch.relu(torch.addcmul(ish[gid], emu_unpack(xp), isc[gid]))      # fp32, like the kernel (fmaf)
+        a_st = emu_unpack(emu_pack(a32)).double()
+    else:
+        a_st = xv
+    yref = a_st @ wv.t()
+    sc_ref, sh_ref = _group_stats(yref, rpg, gamma, beta, 1e-5)
+    xd, wd = xp.to(dev), wp.to(dev)
+    res = []
+    for _ in range(2):
+        xin = xd.clone()
+        sc, sh = ops.bn_gram_affine_h2(xin, wd, rpg, gamma.to(dev), beta.to(dev), 1e-5,
+                                       (isc.to(dev), ish.to(dev)) if xf else None, store_input=xf)
+        res.append((xin, sc, sh))
+    assert all(torch.equal(a, b) for a, b in zip(res[0], res[1]))
+    xin, sc, sh = res[0]
+    if xf:   # the finished activation, in place (a fused multiply-add against torch's: one rounding of difference)
+        a_gpu = ops.f16x2_unpack(xin).cpu().double()
+        assert (a_gpu - a_st).abs().max().item() <= 1e-6 * max(1.0, a_st.abs().max().item())
+        a_st = a_gpu
+        yref = a_st @ wv.t()
+        sc_ref, sh_ref = _group_stats(yref, rpg, gamma, beta, 1e-5)
+    assert ((sc.cpu().double() - sc_ref).abs() / sc_ref.abs()).max().item() < 2e-5
+    ynorm = yref.abs().max().item() * sc_ref.abs().max().item()
+    assert (sh.cpu().double() - sh_ref).abs().max().item() < 2e-5 * max(1.0, ynorm)
+    # the streaming pass with the kernel's own affine
+    resp = emu_pack(torch.randn(rows, n, generator=g)) if with_res else None
+    rsc = (torch.rand(groups, n, generator=g) + 0.5) if ra else None
+    rsh = torch.randn(groups, n, generator=g) if ra else None
+    out_ref = yref * sc.cpu().double()[gid] + sh.cpu().double()[gid]
+    if with_res:
+        r = emu_unpack(resp).double()
+        out_ref = out_ref + (r * rsc.double()[gid] + rsh.double()[gid] if ra else r)
+    relu = with_res or xf
+    if relu:
+        out_ref = torch.relu(out_ref)
+    outs = []
+    for layout in (0, 1):
+        y = torch.empty((rows, n), device=dev)
+        wsel = ops.weights_kstep32(wd) if layout else wd
+        ops.conv2d_affine(code, rows, 1, 1, k, 1, 1, 1, 1, n, xin, k, k, k, wsel, k, y, n, rpg, sc, sh,
+                          resp.to(dev) if with_res else None, relu, (rsc.to(dev), rsh.to(dev)) if ra else None,
+                          w_layout=layout)
+        outs.append(y)
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
+    got = ops.f16x2_unpack(outs[0]).cpu().double()
+    assert (got - out_ref).abs().max().item() <= TOL * max(1.0, out_ref.abs().max().item())

@@ -17,7 +17,7 @@ from avsum_amd.features.extractors import VisualFeatureExtractor
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=8192)
 ap.add_argument("--gf", type=int, default=1)
-ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32split", "f32"])
+ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32split", "f32", "f16x2"])
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--set", action="append", default=[], help="runner attribute override, e.g. --set gram_finish_min_k=64")
 args = ap.parse_args()
@@ -25,7 +25,9 @@ dev = torch.device("cuda", 0)
 dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 es = 2 if dt == torch.bfloat16 else 4
 torch.manual_seed(0)
-ext = VisualFeatureExtractor(dt, "batch", f32_split=args.dtype == "f32split").to(dev)
+SPLIT = {"f32split": True, "f16x2": "f16x2"}.get(args.dtype, False)
+MFMA_IDEAL = 1.2e15 / (3.0 if SPLIT else 1.0)   # three 16-bit MFMAs per product in the split modes
+ext = VisualFeatureExtractor(dt, "batch", f32_split=SPLIT).to(dev)
 runner = ext._resnet_runner if hasattr(ext, "_resnet_runner") else None
 if runner is None:
     runner = next(v for v in vars(ext).values() if isinstance(v, cnn.ResNet50Runner))
@@ -129,7 +131,7 @@ print(f"{'layer':34s} {'form':11s} {'ms':>8s} {'TFLOP/s':>8s} {'TB/s':>6s} {'ide
 tsum = isum = 0.0
 agg = {}
 for (name, form, flops, byts, _, _), ms in zip(records, acc):
-    ideal = max(flops / 1.2e15, byts / 5.5e12) * 1e3
+    ideal = max(flops / MFMA_IDEAL, byts / 5.5e12) * 1e3
     tsum += ms
     isum += ideal
     k = (name, form)

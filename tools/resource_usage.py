@@ -8,7 +8,8 @@ import re
 import subprocess
 import sys
 
-CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "avsum_amd", "csrc")
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                    "audiovidsum-a-multi-modal-approach-to-video-summarization_amd", "csrc")
 
 
 def main():
