@@ -21,9 +21,16 @@ def load(path, counter):
         name = re.sub(r"<.*", "", full).split("(")[0]
         # the contraction kernel serves the bf16 convolutions (element size 2) AND the fp32 scorer GEMMs (4): keep
         # them apart, or the per-launch average mixes 180 convolutions with 7 small GEMMs
-        m = re.match(r"igemm_kernel<(\d+)", full)
+        m = re.match(r"igemm_kernel<(\d+)(?:, [^,>]+)*?(?:, (\d+))?>", full)
         if m:
             name = f"igemm_kernel<{m.group(1)}>"
+            last = re.search(r", (\d+)>\(", full + "(")
+            if m.group(1) == "4" and last and last.group(1) == "2":
+                name = "igemm_kernel<4,split2>"      # AVS_F16X2 convolutions (the last template argument)
+                v = re.match(r"igemm_kernel<(\d+), (\d+), \w+, (\w+), (\d+), (\d+)", full)
+                sub = f"igemm_kernel<4,split2,bn={v.group(2)},spatial={v.group(3)},epi={v.group(5)}>"
+                agg[sub][0] += 1
+                agg[sub][1] += float(r["Counter_Value"])
         agg[name][0] += 1
         agg[name][1] += float(r["Counter_Value"])
     return agg

@@ -27,7 +27,10 @@ def main():
         m = re.match(r"igemm_kernel<(\d+), (\d+), \w+, (\w+), (\d+), (\d+)", full)
         if m:   # element size, column tile, spatial, row bytes, epilogue form
             name = f"igemm_kernel<es={m.group(1)},bn={m.group(2)},spatial={m.group(3)},epi={m.group(5)}>"
-        if not name.startswith(("igemm", "conv1x1", "bn_", "lstm", "stft", "frames_", "global_avg", "power_mel")):
+            last = re.search(r", (\d+)>\(", full + "(")
+            if m.group(1) == "4" and last and last.group(1) in ("1", "2"):
+                name = name[:-1] + f",split={last.group(1)}>"
+        if not name.startswith(("igemm", "conv1x1", "bn_", "lstm", "stft", "frames_", "global_avg", "power_mel", "stem")):
             continue
         agg[name][r["Counter_Name"]] += float(r["Counter_Value"])
         calls[name].add(r["Dispatch_Id"])
