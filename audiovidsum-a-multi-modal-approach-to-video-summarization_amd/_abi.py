@@ -16,8 +16,12 @@ import torch  # noqa: F401  (memory, streams and the HIP runtime come from here)
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # AVS_STUDY_LIB=1 loads the kernel-study build (`make study`: the same library with the ablation switches of tools/
 # compiled in, plus avs_debug_flags); the product never sets it
+# AVS_STUDY_LIB=fp16emu loads the accuracy-study flavour (`make fp16emu`: AVS_F16X2 with the lo halves forced to zero =
+# the arithmetic of a plain fp16-storage mode); tools/fp16_storage_study.py only
 STUDY = os.environ.get("AVS_STUDY_LIB") == "1"
-LIB_PATH = os.path.join(_PKG_DIR, "lib", "libavsum_hip_study.so" if STUDY else "libavsum_hip.so")
+_FLAVOUR = os.environ.get("AVS_STUDY_LIB")
+LIB_PATH = os.path.join(_PKG_DIR, "lib", "libavsum_hip_study.so" if STUDY else
+                        "libavsum_hip_fp16emu.so" if _FLAVOUR == "fp16emu" else "libavsum_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "avsum_hip.h")
 
 AVS_F32, AVS_BF16, AVS_F32_ACC64, AVS_F32_SPLIT, AVS_F16X2 = 0, 1, 2, 3, 4

@@ -330,10 +330,13 @@ class ResNet50Runner:
             return y, affine
         return finish(affine[0], affine[1], grows, gmax)
 
-    def forward(self, frames_u8, group_frames=None, out=None):
+    def forward(self, frames_u8, group_frames=None, out=None, mid_hook=None):
         """frames_u8: device uint8 [N,224,224,3] (already 224x224, extractors.py:132).
         group_frames: int64 CPU tensor / list [G+1] of frame offsets of the BatchNorm micro-batch groups
-        (extractors.py:48-56); default = one group per frame."""
+        (extractors.py:48-56); default = one group per frame.
+        mid_hook: called (no arguments) once layers 1-2 - the HBM-bound half of the trunk - have been launched and
+        before layers 3-4 - the matrix-core-bound half: the pipeline records a stream event there, so that the next
+        pass (on another stream) runs its memory-bound half under this pass's compute-bound half."""
         n, h, w_, _ = frames_u8.shape
         if (h, w_) != (224, 224):
             raise ValueError("ResNet50Runner expects 224x224 frames (resize first)")
@@ -376,7 +379,9 @@ class ResNet50Runner:
             x = self._conv_bn(geom, xs, x0, w["stem"], w["bn1"], groups, local=stem_local, algo_k=147, pool=(3, 2, 1))
             del x0
         hcur = 56
-        for blk in w["blocks"]:
+        for bi, blk in enumerate(w["blocks"]):
+            if bi == 7 and mid_hook is not None:   # blocks 0-2 = layer 1, 3-6 = layer 2
+                mid_hook()
             s, planes = blk["stride"], blk["planes"]
             cin = x.shape[3]
             hout = hcur // s

@@ -81,7 +81,13 @@ __device__ __forceinline__ void avs_f16x2_split8(const float (&v)[8], uint4& hi,
     h[j] = avs_pack_f16x2(a, b);
     float ha, hb;
     avs_unpack_f16x2(h[j], ha, hb);
+#ifdef AVS_H2_DROP_LO
+    // accuracy-study build only (make fp16emu): every value is stored as ONE fp16 - what a plain fp16-storage mode
+    // (fp16 activations and weights, fp32 accumulation) computes, at the f16x2 kernels' speed-irrelevant cost
+    l[j] = 0u;
+#else
     l[j] = avs_pack_f16x2(a - ha, b - hb);
+#endif
   }
   hi = make_uint4(h[0], h[1], h[2], h[3]);
   lo = make_uint4(l[0], l[1], l[2], l[3]);

@@ -57,7 +57,7 @@ class _HostStager:
 
 
 class FrameScoringPipeline:
-    def __init__(self, visual_extractor, scorer, use_inception=True, chunk_frames=256, frames_per_group=1):
+    def __init__(self, visual_extractor, scorer, use_inception=True, chunk_frames=256, frames_per_group=1, streams=1):
         """visual_extractor: features.extractors.VisualFeatureExtractor (on the device);
         scorer: models.av_model.AVBiLSTMModel (on the device, eval mode).
         frames_per_group: BatchNorm micro-batch size inside one video (reference: 4 per shot; the
@@ -70,6 +70,11 @@ class FrameScoringPipeline:
         # frames in pinned host memory: the first pass's upload has no computation to hide behind, so the first pass is
         # a short one (its upload is the only exposed copy of the step)
         self.host_lead_frames = 4096
+        # streams = 2: consecutive passes of the ResNet trunk run on two HIP streams, pass i + 1 starting when pass i
+        # has launched its layers 1-2: the HBM-bound half of one pass then shares the chip with the matrix-core-bound
+        # half (layers 3-4) of the other.  Passes are independent (disjoint frames, disjoint rows of the output).
+        self.streams = int(streams)
+        self._side = None
 
     def _group_offsets(self, video_offsets):
         """BatchNorm groups never straddle a video: per video, groups of frames_per_group (+ remainder)."""
@@ -149,6 +154,13 @@ class FrameScoringPipeline:
             if host and passes else None
         if stage is not None:
             stage.upload(0, passes[0])
+        # two-stream overlap: device-resident contiguous passes of the ResNet-only path (the common case)
+        overlap = (self.streams == 2 and stage is None and not self.use_inception and len(passes) > 1
+                   and all(p[2] for p in passes))
+        if overlap:
+            if self._side is None:
+                self._side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+            side, main, mid_prev = self._side, torch.cuda.current_stream(dev), None
         for i, (gsz, where, contiguous) in enumerate(passes):
             idx = None
             if stage is not None:
@@ -172,6 +184,19 @@ class FrameScoringPipeline:
                 if not self.use_inception:
                     out[:, 2048:].zero_()
             groups = torch.arange(0, cnt + 1, gsz, dtype=torch.int64)
+            if overlap:
+                # pass i on stream i % 2, behind: everything queued before embed() (main), the same stream's previous
+                # pass (stream order), and the MIDDLE of pass i - 1 (its layers 1-2 launched)
+                st = side[i % 2]
+                st.wait_stream(main)
+                if mid_prev is not None:
+                    st.wait_event(mid_prev)
+                mid = torch.cuda.Event()
+                with torch.cuda.stream(st):
+                    self.visual._resnet_runner.forward(chunk, groups, out=out[:, :2048], mid_hook=lambda: mid.record(st))
+                chunk.record_stream(st)
+                mid_prev = mid
+                continue
             self.visual._resnet_runner.forward(chunk, groups, out=out[:, :2048])
             if self.use_inception:
                 big = ops.resize_bilinear(chunk, 299, 299)
@@ -180,6 +205,9 @@ class FrameScoringPipeline:
                 visual.index_copy_(0, idx, out)
             if stage is not None:
                 stage.release(i)
+        if overlap:
+            for st in side:
+                main.wait_stream(st)
         return visual
 
     @torch.no_grad()

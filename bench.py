@@ -324,6 +324,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=None,
                     help="most frames per pass of the trunk (passes are made equal).  Default: 24576 for bf16 (45 143 "
                          "frames = 2 x 22 572, ~160 GB of activations), 12288 for the 4-byte modes")
+    ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
+                    help="2: consecutive passes of the trunk on two HIP streams, staggered by half a pass (the HBM-bound "
+                         "layers 1-2 of one pass under the matrix-core-bound layers 3-4 of the other)")
     ap.add_argument("--cpu-sample", type=int, default=128, help="frames per CPU-baseline run (0 = skip)")
     ap.add_argument("--cpu-runs", type=int, default=5, help="CPU-baseline runs (the median is reported)")
     ap.add_argument("--frames-per-group", type=int, default=1,
@@ -427,7 +430,7 @@ def main():
     torch.cuda.synchronize()
     log("frames ready")
     pipe = FrameScoringPipeline(extractor, scorer, use_inception=use_inception, chunk_frames=args.chunk,
-                                frames_per_group=fpg)
+                                frames_per_group=fpg, streams=args.streams)
 
     def step():
         scores = pipe.score(frames, offsets)
