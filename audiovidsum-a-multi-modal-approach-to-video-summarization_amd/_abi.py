@@ -26,6 +26,8 @@ HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "avsum_hip.h")
 
 AVS_F32, AVS_BF16, AVS_F32_ACC64, AVS_F32_SPLIT, AVS_F16X2 = 0, 1, 2, 3, 4
 AVS_W_ROWS, AVS_W_KSTEP32 = 0, 1
+TILE_AUTO, TILE_128, TILE_256, STAGING_GENERIC = 0, 1, 2, 4      # avs_conv_desc.variant
+LSTM_AUTO, LSTM_STREAM, LSTM_RESIDENT_20_8, LSTM_RESIDENT_16_8 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU = 0, 1
 BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
 E_UNSUPPORTED = -6
@@ -44,7 +46,7 @@ class ConvDesc(ctypes.Structure):
         ("ho", c_int), ("wo", c_int), ("cout", c_int),
         ("x_img_stride", c_int64), ("x_row_stride", c_int64), ("x_px_stride", c_int64),
         ("w_row_stride", c_int64), ("y_px_stride", c_int64),
-        ("act", c_int), ("alpha", c_float), ("w_layout", c_int),
+        ("act", c_int), ("alpha", c_float), ("w_layout", c_int), ("variant", c_int),
     ]
 
 
@@ -74,13 +76,6 @@ _SIGNATURES = {
     "avs_conv2d_nhwc_affine": (c_int, [POINTER(ConvDesc), P, P, P, c_int64, P, P, P, c_int64, P, P, P]),
     "avs_conv2d_bnlocal_tile_rows": (c_int, [POINTER(ConvDesc), c_int64]),
     "avs_conv2d_nhwc_bnlocal": (c_int, [POINTER(ConvDesc), P, P, P, c_int64, P, P, c_float, P, c_int64, P]),
-    "avs_tune_bnlocal": (None, [c_int]),
-    "avs_tune_short_reduction_bytes": (None, [c_int]),
-    "avs_tune_pipeline": (None, [c_int]),
-    "avs_tune_fast_staging": (None, [c_int]),
-    "avs_tune_tall_tiles": (None, [c_int, c_int64, c_int64]),
-    "avs_tune_convbn_narrow": (None, [c_int]),
-    "avs_tune_lstm_resident": (None, [c_int]),
     "avs_gemm_nt": (c_int, [c_int, c_int, c_int, c_int, P, c_int64, c_int64, P, c_int64, c_int64, P, c_int64,
                             c_int64, P, c_int, c_int64, c_float, c_int, c_int, P]),
     "avs_frames_normalize_u8": (c_int, [c_int, P, c_int, c_int, c_int, c_float, POINTER(c_float), POINTER(c_float),
@@ -104,7 +99,7 @@ _SIGNATURES = {
     "avs_fill_f32": (c_int, [P, c_int64, c_float, P]),
     "avs_quantize_f32": (c_int, [P, c_int64, c_float, c_float, c_float, P, P]),
     "avs_resample_f32": (c_int, [P, c_int64, c_int, P, c_int, c_int, c_int, c_int, P, c_int64, P]),
-    "avs_lstm_f32": (c_int, [P, P, c_int, c_int, c_uint, P, c_int, P, c_int64, c_int, P]),
+    "avs_lstm_f32": (c_int, [P, P, c_int, c_int, c_uint, P, c_int, P, c_int64, c_int, c_int, P]),
     "avs_mha_batchaxis_f32": (c_int, [P, c_int, c_int, c_int, c_int, P, P]),
     "avs_score_head_f32": (c_int, [P, c_int64, c_int, c_int64, P, P, P, P]),
     "avs_mhsa_flash_f32": (c_int, [P, P, P, c_int64, c_int, c_int, c_int, c_int, P, c_int64, P]),
@@ -144,18 +139,23 @@ def lib():
             "(run __graft_entry__.build() or `make -C <package>/csrc`). There is no CPU fallback."
         )
     handle = ctypes.CDLL(LIB_PATH)
-    if STUDY:
+    if STUDY:   # the kernel-study build's ablation switches and rule setters (tools/ only)
         handle.avs_debug_flags.restype = None
         handle.avs_debug_flags.argtypes = [c_int]
+        for name, args in (("avs_tune_short_reduction_bytes", [c_int]), ("avs_tune_tall_rule", [c_int, c_int]),
+                           ("avs_tune_pipeline", [c_int]), ("avs_tune_bnlocal", [c_int]),
+                           ("avs_tune_convbn_narrow", [c_int])):
+            getattr(handle, name).restype = None
+            getattr(handle, name).argtypes = args
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(handle, name)
         fn.restype = res
         fn.argtypes = args
-    if handle.avs_abi_version() != 1:
-        raise AvsError(f"ABI version mismatch: library reports {handle.avs_abi_version()}, binding expects 1")
-    if os.environ.get("AVS_TUNE_CONVBN_NARROW") is not None:
+    if handle.avs_abi_version() != 2:
+        raise AvsError(f"ABI version mismatch: library reports {handle.avs_abi_version()}, binding expects 2")
+    if STUDY and os.environ.get("AVS_TUNE_CONVBN_NARROW") is not None:
         handle.avs_tune_convbn_narrow(int(os.environ["AVS_TUNE_CONVBN_NARROW"]))
-    if os.environ.get("AVS_TUNE_PIPELINE") is not None:  # kernel-study override of the library default
+    if STUDY and os.environ.get("AVS_TUNE_PIPELINE") is not None:  # kernel-study override of the library default
         handle.avs_tune_pipeline(int(os.environ["AVS_TUNE_PIPELINE"]))
     _lib = handle
     return _lib

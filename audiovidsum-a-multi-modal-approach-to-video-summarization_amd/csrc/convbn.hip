@@ -343,8 +343,13 @@ __global__ __launch_bounds__(256, 3) void conv1x1_bn_kernel(ConvBnParams p) {
   }
 }
 
+// 1 = 64-channel slabs whatever n is (kernel-study build only; the shipped library has no mutable global state)
+#ifdef AVS_STUDY
 static int g_convbn_narrow = 0;
 extern "C" void avs_tune_convbn_narrow(int enabled) { g_convbn_narrow = enabled; }
+#else
+static constexpr int g_convbn_narrow = 0;
+#endif
 
 static int conv1x1_bn_launch(const char* who, const void* d_x, int64_t lin_stride, int k, const void* d_w, int64_t ldb,
                              int n, int64_t rows_per_group, int groups, const float* d_gamma, const float* d_beta,

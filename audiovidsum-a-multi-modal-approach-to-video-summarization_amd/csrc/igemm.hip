@@ -75,6 +75,7 @@ struct IgemmParams {
   int affine;
   const float* res_scale;
   const float* res_shift;
+  int variant;       // avs_conv_desc.variant: AVS_TILE_128 / AVS_TILE_256 (bits 0-1), AVS_STAGING_GENERIC (bit 2)
 #ifdef AVS_STUDY
   int debug;  // ablation switches of the kernel-study build (tools/): 1 = skip output stores, 2 = skip A/B loads, ...
 #endif
@@ -1399,23 +1400,27 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
 static int g_debug_flags = 0;
 extern "C" void avs_debug_flags(int flags) { g_debug_flags = flags; }
 #endif
-static int g_rowb_threshold_bytes = 2048;  // reductions of at most this many bytes per row use 64-byte steps
-
+// The rules' thresholds: compile-time constants in the shipped library (no process-global mutable state); the
+// kernel-study build makes them settable (tools/).
+#ifdef AVS_STUDY
+#define AVS_RULE static int
+#else
+#define AVS_RULE static constexpr int
+#endif
+AVS_RULE g_rowb_threshold_bytes = 2048;  // reductions of at most this many bytes per row use 64-byte steps
+AVS_RULE g_tall_min_tiles = 2048;        // 256-row tiles by rule: at least this many of them (~4 full waves of workgroups)
+AVS_RULE g_tall_min_k_bytes = 1024;      // ... and, at BN = 128, a reduction long enough to be bound by the loop
+AVS_RULE g_pipe3 = 1;                    // the 3-buffer hand-counted pipeline for the 64-byte-row variants
+AVS_RULE g_bnlocal = 1;                  // 0: avs_conv2d_bnlocal_tile_rows declines every shape
+#ifdef AVS_STUDY
 extern "C" void avs_tune_short_reduction_bytes(int bytes) { g_rowb_threshold_bytes = bytes; }
-
-// 256-row tiles: 0 = by the rule in igemm_launch, 1 = never, 2 = whenever the variant exists
-static int g_tall_mode = 0;
-static long long g_tall_min_tiles = 2048;   // at least this many 256-row tiles (~4 full waves of workgroups)
-static long long g_tall_min_k_bytes = 1024; // BN = 128: only reductions long enough to be bound by the loop
-extern "C" void avs_tune_tall_tiles(int mode, int64_t min_tiles, int64_t min_k_bytes) {
-  g_tall_mode = mode;
+extern "C" void avs_tune_tall_rule(int min_tiles, int min_k_bytes) {
   if (min_tiles > 0) g_tall_min_tiles = min_tiles;
   if (min_k_bytes >= 0) g_tall_min_k_bytes = min_k_bytes;
 }
-static int g_fastk = 1;  // 1: the scalar tap-walk staging where the shape allows it
-extern "C" void avs_tune_fast_staging(int enabled) { g_fastk = enabled; }
-static int g_pipe3 = 1;  // 1: the 3-buffer hand-counted pipeline for the 64-byte-row variants
 extern "C" void avs_tune_pipeline(int enabled) { g_pipe3 = enabled; }
+extern "C" void avs_tune_bnlocal(int enabled) { g_bnlocal = enabled; }
+#endif
 
 template <int ES, int BN, bool ACC64, bool SP, int ROWB, bool PIPE, int WR, bool FK>
 static void igemm_dispatch_epi4(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p) {
@@ -1479,7 +1484,7 @@ static void igemm_dispatch_epi3(int epi, dim3 grid, hipStream_t stream, const Ig
              (long long)(p.KW + p.pw) * p.x_px_stride + p.cin;
   const bool window_ok = extent * ES < (1ll << 31) && (long long)BN * p.ldb * ES + (long long)p.K * ES < (1ll << 31) &&
                          p.x_img_stride >= 0 && p.x_row_stride >= 0 && p.x_px_stride >= 0;
-  if (g_fastk && window_ok && p.cin % BKE == 0 && p.K % BKE == 0 && p.K / p.cin <= 32 && p.K % p.cin == 0)
+  if (!(p.variant & AVS_STAGING_GENERIC) && window_ok && p.cin % BKE == 0 && p.K % BKE == 0 && p.K / p.cin <= 32 && p.K % p.cin == 0)
     igemm_dispatch_epi4<ES, BN, ACC64, SP, ROWB, PIPE, WR, true>(epi, grid, stream, p);
   else
     igemm_dispatch_epi4<ES, BN, ACC64, SP, ROWB, PIPE, WR, false>(epi, grid, stream, p);
@@ -1518,7 +1523,7 @@ static void igemm_dispatch(bool spatial, dim3 grid, hipStream_t stream, const Ig
 #endif
   // 64-byte rows: short reductions, the 256-row tiles, and shapes whose channel count fits the scalar tap walk only
   // at the 64-byte step (cin = 96, 160, 288 ... of Inception-v3): the cheaper staging is worth more than the longer step
-  const bool fast64_only = g_fastk && p.cin % (64 / ES) == 0 && p.cin % (128 / ES) != 0 && p.K / p.cin <= 32;
+  const bool fast64_only = !(p.variant & AVS_STAGING_GENERIC) && p.cin % (64 / ES) == 0 && p.cin % (128 / ES) != 0 && p.K / p.cin <= 32;
   const bool short_k = p.tall || fast64_only || (long long)p.K * ES <= g_rowb_threshold_bytes;
   int epi = EPI_ANY;
   if (p.tile_rows)
@@ -1587,8 +1592,9 @@ static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream
     const bool can = (dtype == AVS_BF16 || dtype == AVS_F32_SPLIT || dtype == AVS_F16X2) && fixed_epi && g_pipe3 &&
                      (long long)p.K * es > 128 && batch == 1;
     const long long tall_tiles = ((long long)p.M + 255) / 256 * p.tiles_n;
-    if (can && (g_tall_mode == 2 || (g_tall_mode == 0 && tall_tiles >= g_tall_min_tiles &&
-                                     (narrow || (long long)p.K * es >= g_tall_min_k_bytes))))
+    const int tile_mode = p.variant & 3;   // AVS_TILE_AUTO: by rule; AVS_TILE_128: never; AVS_TILE_256: wherever it exists
+    if (can && (tile_mode == AVS_TILE_256 || (tile_mode == AVS_TILE_AUTO && tall_tiles >= g_tall_min_tiles &&
+                                              (narrow || (long long)p.K * es >= g_tall_min_k_bytes))))
       p.tall = 1;
   }
   if (p.tile_rows || p.affine) p.tall = 1;  // EPI_BNLOCAL (validated by bnlocal_plan): 256-row tiles at a pitch of tile_rows
@@ -1663,6 +1669,8 @@ static int conv_fill_params(const avs_conv_desc* d, const void* d_x, const void*
   AVS_REQUIRE(d->w_layout == AVS_W_ROWS || d->w_layout == AVS_W_KSTEP32, AVS_E_ARG, "%s: bad w_layout %d", who,
               d->w_layout);
   p.w_kstep = d->w_layout == AVS_W_KSTEP32 ? 1 : 0;
+  AVS_REQUIRE((d->variant & ~7) == 0 && (d->variant & 3) != 3, AVS_E_ARG, "%s: bad variant %d", who, d->variant);
+  p.variant = d->variant;
   AVS_REQUIRE(!p.w_kstep || (d->dtype != AVS_F32_ACC64 && p.K % (d->dtype == AVS_BF16 ? 32 : 16) == 0), AVS_E_UNSUPPORTED,
               "%s: the reduction-step-major weight layout needs a reduction that is a multiple of a 64-byte step (K = %d)",
               who, p.K);
@@ -1798,8 +1806,6 @@ extern "C" int avs_conv2d_nhwc_bnstats(const avs_conv_desc* d, const void* d_x, 
 }
 
 // ---- convolution + whole BatchNorm in one launch, statistics local to a tile (EPI_BNLOCAL) ----
-static int g_bnlocal = 1;  // 0: the query declines every shape (callers then run the unfused sequence)
-extern "C" void avs_tune_bnlocal(int enabled) { g_bnlocal = enabled; }
 
 static int bnlocal_plan(const avs_conv_desc* d, int64_t rpg, IgemmParams& p, const char* who) {
   int st = conv_fill_params(d, (const void*)16, (const void*)16, nullptr, (void*)16, p, who);
@@ -1878,7 +1884,7 @@ extern "C" int avs_conv2d_nhwc_affine(const avs_conv_desc* d, const void* d_x, c
               "%s: residual scale / shift must be 16-byte aligned", who);
   AVS_REQUIRE(!d_residual || ((((uintptr_t)d_residual) & 31u) == 0 && ldr % 8 == 0 && ldr >= p.N), AVS_E_ALIGN,
               "%s: the residual must be 32-byte aligned with a row stride in multiples of 8 slots, at least cout", who);
-  AVS_REQUIRE(g_pipe3, AVS_E_UNSUPPORTED, "%s: needs the pipelined tile variants (avs_tune_pipeline(1))", who);
+  AVS_REQUIRE(g_pipe3, AVS_E_UNSUPPORTED, "%s: needs the pipelined tile variants", who);
   p.affine = 1;
   p.rows_per_group = (int)rows_per_group;
   p.gamma = d_scale;

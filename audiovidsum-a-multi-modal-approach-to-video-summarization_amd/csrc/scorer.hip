@@ -206,12 +206,13 @@ __global__ __launch_bounds__(1024) void lstm_h256_kernel(const float* __restrict
   }
 }
 
-static int g_lstm_resident = 1;  // 0: always the generic kernel; 1 / 2: which resident split (see avs_lstm_f32)
-extern "C" void avs_tune_lstm_resident(int enabled) { g_lstm_resident = enabled; }
-
 extern "C" int avs_lstm_f32(const float* d_xproj, const float* d_whh_t, int hidden, int ndir, unsigned reverse_mask,
-                            const int64_t* d_seq_rows, int nseq, float* d_out, int64_t ldo, int out_col0,
+                            const int64_t* d_seq_rows, int nseq, float* d_out, int64_t ldo, int out_col0, int variant,
                             avs_stream_t stream) {
+  AVS_REQUIRE(variant >= AVS_LSTM_AUTO && variant <= AVS_LSTM_RESIDENT_16_8, AVS_E_ARG, "avs_lstm_f32: bad variant %d",
+              variant);
+  AVS_REQUIRE(variant <= AVS_LSTM_STREAM || hidden == 256, AVS_E_UNSUPPORTED,
+              "avs_lstm_f32: the resident variants are built for hidden = 256");
   AVS_REQUIRE(hidden > 0 && hidden <= 1024 && ndir > 0 && ndir <= 32 && nseq >= 0 && out_col0 >= 0 &&
                   ldo >= out_col0 + (int64_t)ndir * hidden,
               AVS_E_SHAPE, "avs_lstm_f32: hidden=%d ndir=%d nseq=%d ldo=%lld out_col0=%d", hidden, ndir, nseq,
@@ -220,7 +221,7 @@ extern "C" int avs_lstm_f32(const float* d_xproj, const float* d_whh_t, int hidd
   AVS_REQUIRE(d_xproj && d_whh_t && d_seq_rows && d_out, AVS_E_ARG, "avs_lstm_f32: null pointer");
   AVS_REQUIRE(avs_aligned16(d_whh_t), AVS_E_ALIGN, "avs_lstm_f32: whh_t not 16-byte aligned");
   AVS_REQUIRE(nseq <= 65535 * 32767, AVS_E_SHAPE, "avs_lstm_f32: too many sequences");
-  if (hidden == 256 && g_lstm_resident) {
+  if (hidden == 256 && variant != AVS_LSTM_STREAM) {
     // 1: 20 row-vectors in registers + 8 in LDS, batches of 4;  2: 16 + 8, batches of 8
 #define AVS_LSTM_RESIDENT(RK_, LK_, D_)                                                                              \
     {                                                                                                                \
@@ -232,7 +233,7 @@ extern "C" int avs_lstm_f32(const float* d_xproj, const float* d_whh_t, int hidd
       hipLaunchKernelGGL((lstm_h256_kernel<RK_, LK_, D_>), dim3(nseq, ndir), dim3(1024), shm, (hipStream_t)stream,   \
                          d_xproj, d_whh_t, ndir, reverse_mask, d_seq_rows, d_out, (long long)ldo, out_col0);         \
     }
-    if (g_lstm_resident == 2) AVS_LSTM_RESIDENT(16, 8, 8)
+    if (variant == AVS_LSTM_RESIDENT_16_8) AVS_LSTM_RESIDENT(16, 8, 8)
     else AVS_LSTM_RESIDENT(20, 8, 4)
 #undef AVS_LSTM_RESIDENT
     AVS_CHECK_LAUNCH("avs_lstm_f32");

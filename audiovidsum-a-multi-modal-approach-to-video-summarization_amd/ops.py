@@ -215,7 +215,7 @@ def _stats_workspace(device, nbytes):
 
 def conv2d_raw(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x, x_img_stride, x_row_stride, x_px_stride,
                wt, w_row_stride, y, y_px_stride, bias=None, act=ACT_NONE, alpha=1.0, x_off=0, y_off=0, algo_k=None,
-               bnstats=None, bnlocal=None, algo_in_elems=None, w_layout=0):
+               bnstats=None, bnlocal=None, algo_in_elems=None, w_layout=0, variant=0):
     """algo_k: the algorithmic reduction length when it differs from kh*kw*cin (zero-padded stem rows);
     algo_in_elems: input elements the launch reads when the geometry does not say (the re-viewed stem image).
     bnstats = (rows_per_group, gamma, beta, eps): the BatchNorm batch statistics of equal-sized row groups from the
@@ -223,10 +223,12 @@ def conv2d_raw(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x, x_i
     (scale, shift) [G, cout], or None when the library declines the shape (groups of < 64 rows).
     bnlocal = (rows_per_group, gamma, beta, eps, residual2d | None): the whole BatchNorm (+ residual, then `act`) in
     the convolution's launch (avs_conv2d_nhwc_bnlocal; shapes for which conv_bnlocal_tile_rows is not None).
-    w_layout: _abi.AVS_W_ROWS (wt[cout, K]) or AVS_W_KSTEP32 (the image weights_kstep32() makes)."""
+    w_layout: _abi.AVS_W_ROWS (wt[cout, K]) or AVS_W_KSTEP32 (the image weights_kstep32() makes).
+    variant: avs_conv_desc.variant (_abi.TILE_128 / TILE_256 | STAGING_GENERIC): a per-call override of the tile /
+    staging choice, for tests and the study tools (the library has no global tuning state)."""
     _dev(x, wt, y, bias)
     d = _abi.ConvDesc(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x_img_stride, x_row_stride,
-                      x_px_stride, w_row_stride, y_px_stride, act, float(alpha), int(w_layout))
+                      x_px_stride, w_row_stride, y_px_stride, act, float(alpha), int(w_layout), int(variant))
     flops = 2.0 * n * ho * wo * cout * (algo_k if algo_k is not None else kh * kw * cin)
     # algorithmic HBM bytes: the input map read once (the pixels a strided 1x1 skips are not needed), the output
     # written once (+ the residual read once); weights are negligible and L2-resident
@@ -486,7 +488,7 @@ def weights_kstep32(wt):
     return wt.reshape(cout, k // step, step).permute(1, 0, 2).contiguous().view(cout, k)
 
 
-def conv2d(x, wt, kh, kw, stride, pad, out, bias=None, act=ACT_NONE, bnstats=None, split=False, w_layout=0):
+def conv2d(x, wt, kh, kw, stride, pad, out, bias=None, act=ACT_NONE, bnstats=None, split=False, w_layout=0, variant=0):
     """x: NHWC view [n,h,w,cin] (unit channel stride); wt: [cout, kh*kw*cin]; out: NHWC view [n,ho,wo,cout]
     whose pixels are dense in (n,ho,wo) order (a channel slice of a dense buffer is fine).
     bnstats: see conv2d_raw (returns (scale, shift) then, else `out`)."""
@@ -506,7 +508,8 @@ def conv2d(x, wt, kh, kw, stride, pad, out, bias=None, act=ACT_NONE, bnstats=Non
     if bias is not None:
         _f32(bias, "bias")
     r = conv2d_raw(dtype_code(x.dtype, split), n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x, x.stride(0),
-                   x.stride(1), x.stride(2), wt, wt.stride(0), out, yps, bias, act, bnstats=bnstats, w_layout=w_layout)
+                   x.stride(1), x.stride(2), wt, wt.stride(0), out, yps, bias, act, bnstats=bnstats, w_layout=w_layout,
+                   variant=variant)
     return out if bnstats is None else r
 
 
@@ -764,7 +767,7 @@ def resample(x, taps, up, down, width, out_len):
 
 
 # --------------------------------------------------------------------------- scorer
-def lstm(xproj, whh_t, hidden, ndir, reverse_mask, seq_rows, out, out_col0):
+def lstm(xproj, whh_t, hidden, ndir, reverse_mask, seq_rows, out, out_col0, variant=0):
     _f32(xproj, "xproj")
     _f32(whh_t, "whh_t")
     _f32(out, "out")
@@ -774,7 +777,7 @@ def lstm(xproj, whh_t, hidden, ndir, reverse_mask, seq_rows, out, out_col0):
         raise ValueError(f"whh_t shape {tuple(whh_t.shape)}")
     nseq = seq_rows.numel() - 1
     check(lib().avs_lstm_f32(_p(xproj), _p(whh_t), hidden, ndir, reverse_mask, _p(seq_rows), nseq, _p(out),
-                             out.stride(0), out_col0, _stream()), "avs_lstm_f32")
+                             out.stride(0), out_col0, int(variant), _stream()), "avs_lstm_f32")
     return out
 
 

@@ -341,8 +341,6 @@ def main():
                          "small passes, nothing at 12288 frames)")
     ap.add_argument("--bn-local", default="on", choices=["on", "off"],
                     help="tuning: one-launch tile-local convolution + BatchNorm on the layers that take it")
-    ap.add_argument("--short-k-bytes", type=int, default=None, help="tuning: avs_tune_short_reduction_bytes")
-    ap.add_argument("--tall", default=None, help="tuning: mode[,min_tiles[,min_k_bytes]] of avs_tune_tall_tiles")
     ap.add_argument("--fuse", default=None, help="tuning: min_rows,ratio_num,ratio_den of the one-kernel conv+BN")
     args = ap.parse_args()
 
@@ -364,11 +362,6 @@ def main():
     from avsum_amd.models.av_model import AVBiLSTMModel
     from avsum_amd.pipeline import FrameScoringPipeline
 
-    if args.short_k_bytes is not None:
-        _abi.lib().avs_tune_short_reduction_bytes(args.short_k_bytes)
-    if args.tall is not None:
-        tv = [int(v) for v in args.tall.split(",")] + [0, -1]
-        _abi.lib().avs_tune_tall_tiles(tv[0], tv[1], tv[2])
     if args.chunk is None:
         args.chunk = 24576 if args.dtype == "bf16" else 12288
     rank, world, local = avd.init_from_env()

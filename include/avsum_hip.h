@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define AVS_ABI_VERSION 1
+#define AVS_ABI_VERSION 2
 
 enum {
   AVS_OK = 0,
@@ -109,8 +109,14 @@ typedef struct {
                              * reduction step reads sit next to the neighbouring filters', so the weight tile of
                              * a step is contiguous whole cache lines (+2..6 % on the ResNet layers);
                              * w_row_stride is ignored.  Weights are re-laid out once, offline.              */
+  int variant;              /* 0 = the library's own choice.  Per-call overrides of the tile / staging variant (what the
+                             * tests and the kernel-study tools force; there is NO process-global tuning state):
+                             * AVS_TILE_128 / AVS_TILE_256 (bits 0-1): 128-row or, wherever the variant exists, 256-row
+                             * output tiles; AVS_STAGING_GENERIC (bit 2): the general per-lane gather staging even where
+                             * the scalar tap walk applies.  Results do not depend on it beyond fp32 summation order. */
 } avs_conv_desc;
 enum { AVS_W_ROWS = 0, AVS_W_KSTEP32 = 1 };
+enum { AVS_TILE_AUTO = 0, AVS_TILE_128 = 1, AVS_TILE_256 = 2, AVS_STAGING_GENERIC = 4 };
 
 int avs_conv2d_nhwc(const avs_conv_desc* desc, const void* d_x, const void* d_w,
                     const float* d_bias, void* d_y, avs_stream_t stream);
@@ -169,8 +175,6 @@ int avs_conv2d_nhwc_affine(const avs_conv_desc* desc, const void* d_x, const voi
                            int64_t rows_per_group, const float* d_scale, const float* d_shift,
                            const void* d_residual, int64_t ldr, const float* d_res_scale, const float* d_res_shift,
                            avs_stream_t stream);
-/* Tuning knob: 0 makes avs_conv2d_bnlocal_tile_rows decline every shape.                                      */
-void avs_tune_bnlocal(int enabled);
 
 /* The whole ResNet-50 stem of the bf16 throughput path: uint8 frames [n,224,224,3] -> (x / denom - mean) / std ->
  * conv1 7x7/2 (64 channels) -> bn1 in batch-statistics mode over groups of frames_per_group frames -> ReLU ->
@@ -245,25 +249,10 @@ int avs_conv1x1_affine_bf16(const void* d_x, int64_t lin_stride, int k, const fl
                             int64_t ldr, const float* d_res_scale, const float* d_res_shift, int relu, void* d_y,
                             int64_t ldc, avs_stream_t stream);
 
-/* Tuning knob: 1 = 64-channel slabs (4 workgroups per CU) in avs_conv1x1_bn_bf16 whatever n is.          */
-void avs_tune_convbn_narrow(int enabled);
-
-/* Tuning knob (process-wide, not thread-safe): reductions of at most `bytes` bytes per output row run with
- * 64-byte LDS rows / 3 workgroups per CU instead of 128-byte rows / 2 workgroups per CU.  Default 2048.    */
-void avs_tune_short_reduction_bytes(int bytes);
-/* Tuning knob: 1 selects the 3-buffer, hand-counted-wait pipeline of the contraction kernel (DMA two steps
- * ahead) for reductions of three or more 64-byte steps.  Default on.                                     */
-void avs_tune_pipeline(int enabled);
-/* Tuning knob: 256-row output tiles of the contraction kernel (bf16, compile-time epilogue forms).  mode 0 = by
- * rule (at least min_tiles such tiles, and cout <= 64 or a reduction of at least min_k_bytes), 1 = never,
- * 2 = whenever the variant exists.  min_tiles <= 0 / min_k_bytes < 0 keep the current values.               */
-void avs_tune_tall_tiles(int mode, int64_t min_tiles, int64_t min_k_bytes);
-/* Tuning knob: 0 switches off the scalar tap-walk operand staging of the contraction kernel (taken when cin is a
- * multiple of one reduction step and the kernel has at most 32 taps); the general staging code then serves every
- * shape.  Default on.                                                                                        */
-void avs_tune_fast_staging(int enabled);
-/* (The kernel-study build, `make study` -> lib/libavsum_hip_study.so, additionally exports
- * void avs_debug_flags(int): ablation switches for tools/; the shipped library has no such code paths.)     */
+/* The library holds NO process-global mutable state: the tile / staging variant of a convolution is chosen per call
+ * (avs_conv_desc.variant), everything else by fixed rules.  (The kernel-study build, `make study` ->
+ * lib/libavsum_hip_study.so, additionally exports void avs_debug_flags(int) and the avs_tune_* setters of the rules'
+ * thresholds for tools/; the shipped library has no such code paths and no such symbols.)                        */
 
 /* Batched C[b] = act(alpha * A[b] . B[b]^T + bias):  A [M,K] (row stride lda),
  * B [N,K] (row stride ldb; the nn.Linear weight layout), C [M,N] (ldc).
@@ -426,14 +415,15 @@ int avs_resample_f32(const float* d_x, int64_t t, int channels, const float* d_t
  *   d_whh_t [ndir, H, 4H]: W_hh TRANSPOSED per direction;
  *   d_seq_rows[s]..d_seq_rows[s+1]: the rows of sequence s;
  *   reverse_mask bit d set = direction d runs t = T-1..0;
- *   d_out [rows, ldo]: h_t of direction d at columns out_col0 + d*H.         */
+ *   d_out [rows, ldo]: h_t of direction d at columns out_col0 + d*H.
+ *   variant: 0 = the library's choice.  hidden = 256 keeps part of W_hh^T on chip for the whole sequence
+ *           (AVS_LSTM_RESIDENT_20_8: 20 of a thread's 64 row-vectors in registers + 8 in LDS, the default there;
+ *           AVS_LSTM_RESIDENT_16_8: 16 + 8) instead of streaming all of it from L2 every step (AVS_LSTM_STREAM).
+ *           Same arithmetic in the same order: bit-identical outputs.                                             */
+enum { AVS_LSTM_AUTO = 0, AVS_LSTM_STREAM = 1, AVS_LSTM_RESIDENT_20_8 = 2, AVS_LSTM_RESIDENT_16_8 = 3 };
 int avs_lstm_f32(const float* d_xproj, const float* d_whh_t, int hidden, int ndir,
                  unsigned reverse_mask, const int64_t* d_seq_rows, int nseq,
-                 float* d_out, int64_t ldo, int out_col0, avs_stream_t stream);
-/* Tuning knob: hidden = 256 keeps part of W_hh^T on chip for the whole sequence (1: 20 of a thread's 64 row-vectors in
- * registers + 8 in LDS, default; 2: 16 + 8) instead of streaming all of it from L2 every step (0).  Same arithmetic in
- * the same order: bit-identical outputs.                                                                          */
-void avs_tune_lstm_resident(int mode);
+                 float* d_out, int64_t ldo, int out_col0, int variant, avs_stream_t stream);
 
 /* Attention core of nn.MultiheadAttention fed [B,T,E] WITHOUT batch_first
  * (models/av_model.py:26,44): for every time-step t and head h,

@@ -16,8 +16,33 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) == set(_abi._SIGNATURES)
-    assert lib.avs_abi_version() == 1
+    assert lib.avs_abi_version() == 2
     assert os.path.dirname(_abi.LIB_PATH).startswith(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def test_shipped_library_has_no_global_tuning_state():
+    """the C-ABI holds no process-global mutable state.  The tile / staging variant of a convolution and
+    the LSTM variant are per-call arguments; the rule thresholds are compile-time constants; the avs_tune_* setters and
+    avs_debug_flags exist in the kernel-study build only - the shipped library does not even export the symbols."""
+    import re
+    import subprocess
+    from avsum_amd import _abi
+    out = subprocess.run(["nm", "-D", "--defined-only", _abi.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r"\b(avs_[a-z0-9_]+)\b", out))
+    assert exported, "nm found no avs_ symbols"
+    assert not [n for n in exported if n.startswith(("avs_tune", "avs_debug"))]
+    assert exported == set(_abi.declared_symbols())          # exactly the header's functions, nothing else
+    header = open(_abi.HEADER_PATH).read()
+    assert "avs_tune_" not in re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    # no writable file-scope variables in the kernel sources outside the study build and the thread-local error text
+    src_dir = os.path.join(os.path.dirname(_abi.LIB_PATH), "..", "csrc")
+    for name in sorted(os.listdir(src_dir)):
+        if not name.endswith(".hip"):
+            continue
+        text = open(os.path.join(src_dir, name)).read()
+        text = re.sub(r"#ifdef AVS_STUDY.*?#(?:else|endif)", "", text, flags=re.S)
+        for m in re.finditer(r"^static (?!constexpr|inline|int [a-z_0-9]+\(|void|bool [a-z_0-9]+\()[^;(]*;", text, flags=re.M):
+            assert "thread_local" in m.group(0) or "const" in m.group(0), (name, m.group(0))
 
 
 def test_validation_before_launch_needs_no_gpu():
@@ -30,7 +55,7 @@ def test_validation_before_launch_needs_no_gpu():
     st = lib.avs_gemm_nt(7, 8, 8, 8, None, 8, 0, None, 8, 0, None, 8, 0, None, 0, 0, 1.0, 0, 1, None)
     assert st == -1 and b"dtype" in lib.avs_last_error()
     assert lib.avs_dtw_workspace_bytes(10, 20) >= 200
-    assert lib.avs_lstm_f32(None, None, 0, 2, 0, None, 1, None, 0, 0, None) == -2
+    assert lib.avs_lstm_f32(None, None, 0, 2, 0, None, 1, None, 0, 0, 0, None) == -2
     assert lib.avs_cdist_f64(None, 4, None, 4, 0, None, None) == -2
 
 

@@ -76,32 +76,27 @@ def _conv_ref(xv, wv, stride, pad):
 ])
 @pytest.mark.parametrize("tall", [0, 2])
 def test_conv2d_f16x2(dev, cfg, tall):
-    """Plain convolution (both weight layouts; the library's own tile choice and the 256-row tiles forced on)."""
-    from avsum_amd import _abi
+    """Plain convolution (both weight layouts; the library's own tile choice and the 256-row tiles forced on per call:
+    avs_conv_desc.variant = AVS_TILE_256)."""
     ops = _ops()
     n, h, w, cin, cout, kh, kw, stride, pad = cfg
     xp, wp, xv, wv = _conv_operands(n, h, w, cin, cout, kh, kw, h * 13 + cin)
     ref = _conv_ref(xv, wv, stride, pad)
     ho, wo = ref.shape[1], ref.shape[2]
     scale = max(1.0, ref.abs().max().item())
-    L = _abi.lib()
-    try:
-        L.avs_tune_tall_tiles(tall, 0, -1)
-        outs = []
-        for layout in (0, 1):
-            if layout == 1 and (kh * kw * cin) % 16:
-                continue
-            wd = wp.to(dev)
-            wsel = ops.weights_kstep32(wd) if layout else wd
-            out = torch.empty((n, ho, wo, cout), device=dev)
-            ops.conv2d(xp.to(dev), wsel, kh, kw, stride, pad, out, split="f16x2", w_layout=layout)
-            outs.append(out)
-            got = ops.f16x2_unpack(out).cpu().double()
-            assert (got - ref).abs().max().item() <= TOL * scale
-        if len(outs) == 2:
-            assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))   # same products, same order
-    finally:
-        L.avs_tune_tall_tiles(0, 0, -1)
+    outs = []
+    for layout in (0, 1):
+        if layout == 1 and (kh * kw * cin) % 16:
+            continue
+        wd = wp.to(dev)
+        wsel = ops.weights_kstep32(wd) if layout else wd
+        out = torch.empty((n, ho, wo, cout), device=dev)
+        ops.conv2d(xp.to(dev), wsel, kh, kw, stride, pad, out, split="f16x2", w_layout=layout, variant=tall)
+        outs.append(out)
+        got = ops.f16x2_unpack(out).cpu().double()
+        assert (got - ref).abs().max().item() <= TOL * scale
+    if len(outs) == 2:
+        assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))   # same products, same order
 
 
 def test_conv2d_f16x2_stem_geometry(dev):

@@ -121,7 +121,7 @@ def test_abi_rejects_bad_arguments(dev):
 
 
 # ----------------------------------------------------------------------------- conv
-def _conv_case(dev, dtype, n, h, w, cin, cout, kh, kw, stride, pad, tol, split=False):
+def _conv_case(dev, dtype, n, h, w, cin, cout, kh, kw, stride, pad, tol, split=False, variant=0):
     ops = _ops()
     g = torch.Generator().manual_seed(h * 13 + cin)
     x = torch.randn(n, cin, h, w, generator=g)
@@ -134,7 +134,7 @@ def _conv_case(dev, dtype, n, h, w, cin, cout, kh, kw, stride, pad, tol, split=F
     xn = x.permute(0, 2, 3, 1).contiguous().to(dtype).to(dev)
     wk = wt.permute(0, 2, 3, 1).reshape(cout, -1).contiguous().to(dtype).to(dev)
     out = torch.empty((n, ho, wo, cout), dtype=dtype, device=dev)
-    ops.conv2d(xn, wk, kh, kw, stride, pad, out, b.to(dev), 1, split=split)
+    ops.conv2d(xn, wk, kh, kw, stride, pad, out, b.to(dev), 1, split=split, variant=variant)
     got = out.float().cpu().permute(0, 3, 1, 2)
     assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
 
@@ -162,7 +162,6 @@ def test_conv2d_f32_split(dev, cfg):
     # values as the 128-row tiles, also with the fused BatchNorm statistics
     from avsum_amd import _abi
     ops = _ops()
-    L = _abi.lib()
     n, h, w, cin, cout, kh, kw, stride, pad = cfg
     g = torch.Generator().manual_seed(cin + cout)
     x = torch.randn(n, h, w, cin, generator=g).to(dev)
@@ -171,19 +170,16 @@ def test_conv2d_f32_split(dev, cfg):
     ho, wo = (h + 2 * ph - kh) // stride + 1, (w + 2 * pw - kw) // stride + 1
     gamma, beta = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
     rpg = max(64, ho * wo)
-    try:
-        L.avs_tune_tall_tiles(2, 0, -1)
-        _conv_case(dev, torch.float32, *cfg, tol=1e-4, split=True)
-        tall = torch.empty((n, ho, wo, cout), device=dev)
-        sc_t, sh_t = ops.conv2d(x, wk, kh, kw, stride, pad, tall, bnstats=(rpg, gamma, beta, 1e-5), split=True)
-        L.avs_tune_tall_tiles(1, 0, -1)
-        base = torch.empty_like(tall)
-        sc_b, sh_b = ops.conv2d(x, wk, kh, kw, stride, pad, base, bnstats=(rpg, gamma, beta, 1e-5), split=True)
-        assert torch.equal(tall, base)
-        assert (sc_t - sc_b).abs().max().item() < 1e-4 * sc_b.abs().max().item()
-        assert (sh_t - sh_b).abs().max().item() < 1e-4 * max(1.0, sh_b.abs().max().item())
-    finally:
-        L.avs_tune_tall_tiles(0, 0, -1)
+    _conv_case(dev, torch.float32, *cfg, tol=1e-4, split=True, variant=_abi.TILE_256)
+    tall = torch.empty((n, ho, wo, cout), device=dev)
+    sc_t, sh_t = ops.conv2d(x, wk, kh, kw, stride, pad, tall, bnstats=(rpg, gamma, beta, 1e-5), split=True,
+                            variant=_abi.TILE_256)
+    base = torch.empty_like(tall)
+    sc_b, sh_b = ops.conv2d(x, wk, kh, kw, stride, pad, base, bnstats=(rpg, gamma, beta, 1e-5), split=True,
+                            variant=_abi.TILE_128)
+    assert torch.equal(tall, base)
+    assert (sc_t - sc_b).abs().max().item() < 1e-4 * sc_b.abs().max().item()
+    assert (sh_t - sh_b).abs().max().item() < 1e-4 * max(1.0, sh_b.abs().max().item())
 
 
 @pytest.mark.parametrize("cfg", [(2, 14, 14, 64, 64, 3, 3, 1, 1), (2, 16, 16, 128, 256, 1, 1, 2, 0),
@@ -200,28 +196,22 @@ def test_conv2d_bf16_tall_tiles(dev, cfg):
     BatchNorm statistics and on a plain (no bias) convolution, ragged last tile included."""
     from avsum_amd import _abi
     ops = _ops()
-    L = _abi.lib()
-    try:
-        L.avs_tune_tall_tiles(2, 0, -1)
-        _conv_case(dev, torch.bfloat16, *cfg, tol=1.2e-2)
-        n, h, w, cin, cout, kh, kw, stride, pad = cfg
-        g = torch.Generator().manual_seed(cin + cout)
-        x = torch.randn(n, h, w, cin, generator=g).bfloat16().to(dev)
-        wk = (torch.randn(cout, kh * kw * cin, generator=g) / (kh * kw * cin) ** 0.5).bfloat16().to(dev)
-        ph, pw = pad if isinstance(pad, tuple) else (pad, pad)
-        ho, wo = (h + 2 * ph - kh) // stride + 1, (w + 2 * pw - kw) // stride + 1
-        gamma, beta = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
-        tall = torch.empty((n, ho, wo, cout), dtype=torch.bfloat16, device=dev)
-        rpg = max(64, ho * wo)  # groups of fewer than 64 rows are declined by the fused-statistics form
-        sc_t, sh_t = ops.conv2d(x, wk, kh, kw, stride, pad, tall, bnstats=(rpg, gamma, beta, 1e-5))
-        L.avs_tune_tall_tiles(1, 0, -1)
-        base = torch.empty_like(tall)
-        sc_b, sh_b = ops.conv2d(x, wk, kh, kw, stride, pad, base, bnstats=(rpg, gamma, beta, 1e-5))
-        assert torch.equal(tall, base)          # same products, same k order per output element
-        assert (sc_t - sc_b).abs().max().item() < 2e-3 * sc_b.abs().max().item()
-        assert (sh_t - sh_b).abs().max().item() < 2e-3 * max(1.0, sh_b.abs().max().item())
-    finally:
-        L.avs_tune_tall_tiles(0, 0, -1)
+    _conv_case(dev, torch.bfloat16, *cfg, tol=1.2e-2, variant=_abi.TILE_256)
+    n, h, w, cin, cout, kh, kw, stride, pad = cfg
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(n, h, w, cin, generator=g).bfloat16().to(dev)
+    wk = (torch.randn(cout, kh * kw * cin, generator=g) / (kh * kw * cin) ** 0.5).bfloat16().to(dev)
+    ph, pw = pad if isinstance(pad, tuple) else (pad, pad)
+    ho, wo = (h + 2 * ph - kh) // stride + 1, (w + 2 * pw - kw) // stride + 1
+    gamma, beta = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
+    tall = torch.empty((n, ho, wo, cout), dtype=torch.bfloat16, device=dev)
+    rpg = max(64, ho * wo)  # groups of fewer than 64 rows are declined by the fused-statistics form
+    sc_t, sh_t = ops.conv2d(x, wk, kh, kw, stride, pad, tall, bnstats=(rpg, gamma, beta, 1e-5), variant=_abi.TILE_256)
+    base = torch.empty_like(tall)
+    sc_b, sh_b = ops.conv2d(x, wk, kh, kw, stride, pad, base, bnstats=(rpg, gamma, beta, 1e-5), variant=_abi.TILE_128)
+    assert torch.equal(tall, base)          # same products, same k order per output element
+    assert (sc_t - sc_b).abs().max().item() < 2e-3 * sc_b.abs().max().item()
+    assert (sh_t - sh_b).abs().max().item() < 2e-3 * max(1.0, sh_b.abs().max().item())
 
 
 @pytest.mark.parametrize("cfg", [(3, 14, 14, 64, 96, 3, 1, 1), (2, 9, 11, 32, 40, 1, 1, 0), (2, 12, 12, 128, 64, 3, 2, 1),
@@ -240,13 +230,9 @@ def test_conv2d_bf16_kstep_weight_layout(dev, cfg):
     ref = ops.conv2d(x, wt, k, k, s, p, torch.empty((n, ho, wo, cout), dtype=torch.bfloat16, device=dev), bias, ops.ACT_RELU)
     wk = ops.weights_kstep32(wt)
     assert wk.shape == wt.shape and (k * k * cin == 32 or not torch.equal(wk, wt))   # one step: the layouts coincide
-    for tall in (1, 2):
-        try:
-            _lib().avs_tune_tall_tiles(tall, 0, -1)
-            got = ops.conv2d(x, wk, k, k, s, p, torch.empty_like(ref), bias, ops.ACT_RELU, w_layout=1)
-            want = ops.conv2d(x, wt, k, k, s, p, torch.empty_like(ref), bias, ops.ACT_RELU)
-        finally:
-            _lib().avs_tune_tall_tiles(0, 0, -1)
+    for tall in (1, 2):   # _abi.TILE_128, _abi.TILE_256: the per-call tile override of the descriptor
+        got = ops.conv2d(x, wk, k, k, s, p, torch.empty_like(ref), bias, ops.ACT_RELU, w_layout=1, variant=tall)
+        want = ops.conv2d(x, wt, k, k, s, p, torch.empty_like(ref), bias, ops.ACT_RELU, variant=tall)
         assert torch.equal(got, want)
     assert torch.equal(want, ref) or (want.float() - ref.float()).abs().max().item() < 0.05
     # fp32 (16-element steps), exact and split arithmetic
@@ -267,7 +253,6 @@ def test_conv2d_seeded_shape_sweep(dev):
     (cin a multiple of one reduction step or not), 1..49 taps (more than 32 taps use the general staging), strides,
     asymmetric kernels / padding, ragged tiles, both dtypes, with and without the 256-row tiles."""
     from avsum_amd import _abi
-    L = _abi.lib()
     rng = np.random.default_rng(20261004)
     kernels = [(1, 1), (3, 3), (5, 5), (7, 7), (1, 7), (7, 1), (3, 1), (2, 2)]
     cases = []
@@ -280,15 +265,10 @@ def test_conv2d_seeded_shape_sweep(dev):
         cout = int(rng.choice([8, 24, 64, 72, 128, 136, 200, 256]))
         n = int(rng.integers(1, 6))
         cases.append((n, h, w, cin, cout, kh, kw, stride, (ph, pw)))
-    try:
-        for i, cfg in enumerate(cases):
-            dtype, tol = (torch.bfloat16, 1.2e-2) if i % 3 else (torch.float32, 2e-5)
-            L.avs_tune_tall_tiles(2 if i % 2 else 1, 0, -1)
-            L.avs_tune_fast_staging(0 if i % 5 == 4 else 1)
-            _conv_case(dev, dtype, *cfg, tol=tol)
-    finally:
-        L.avs_tune_tall_tiles(0, 0, -1)
-        L.avs_tune_fast_staging(1)
+    for i, cfg in enumerate(cases):
+        dtype, tol = (torch.bfloat16, 1.2e-2) if i % 3 else (torch.float32, 2e-5)
+        variant = (_abi.TILE_256 if i % 2 else _abi.TILE_128) | (_abi.STAGING_GENERIC if i % 5 == 4 else 0)
+        _conv_case(dev, dtype, *cfg, tol=tol, variant=variant)
 
 
 def test_conv2d_channel_slice_output(dev):
@@ -507,14 +487,10 @@ def test_lstm_vs_oracle(dev):
             # the scorer's size keeps part of W_hh^T in registers / LDS (default); the generic streaming kernel and the
             # other resident split run the same fmaf chain in the same order: bit-identical
             from avsum_amd import _abi
-            try:
-                for mode in (0, 2):
-                    _abi.lib().avs_tune_lstm_resident(mode)
-                    alt = torch.zeros_like(out)
-                    ops.lstm(xproj, whh_t, hid, 2, 0b10, seq, alt, 4)
-                    assert torch.equal(alt, out)
-            finally:
-                _abi.lib().avs_tune_lstm_resident(1)
+            for variant in (_abi.LSTM_STREAM, _abi.LSTM_RESIDENT_16_8):
+                alt = torch.zeros_like(out)
+                ops.lstm(xproj, whh_t, hid, 2, 0b10, seq, alt, 4, variant=variant)
+                assert torch.equal(alt, out)
 
 
 def test_softmax_score_head_mha(dev):

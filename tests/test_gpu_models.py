@@ -623,11 +623,6 @@ def test_conv_bnlocal_declines(dev):
     g, xs = geom(4, 14, 128, 64)
     assert ops.conv_bnlocal_tile_rows(ops.dtype_code(torch.float32), *g, *xs, 128, 64, 196) is None
     assert ops.conv_bnlocal_tile_rows(code, *g, *xs, 128, 64, 196) == 196
-    try:
-        _abi.lib().avs_tune_bnlocal(0)
-        assert ops.conv_bnlocal_tile_rows(code, *g, *xs, 128, 64, 196) is None
-    finally:
-        _abi.lib().avs_tune_bnlocal(1)
 
 
 @pytest.mark.parametrize("gsize", [1, 4])

@@ -19,7 +19,6 @@ dt = torch.bfloat16
 shapes = [("l1.conv1 1x1 256->64", 56, 256, 64), ("l2.conv1 1x1 512->128", 28, 512, 128),
           ("l3.conv1 1x1 1024->256", 14, 1024, 256), ("l3.conv3 1x1 256->1024", 14, 256, 1024),
           ("l4.conv1 1x1 2048->512", 7, 2048, 512), ("l4.conv3 1x1 512->2048", 7, 512, 2048)]
-L.avs_tune_tall_tiles(2, 0, -1)
 for name, hw, cin, cout in shapes:
     # the study switch walks the blocks with the kernel's 32-bit scalar offset: the whole input must stay below 2 GiB
     n = min(args.n, int(1.9e9 // (hw * hw * cin * 2)))
@@ -33,12 +32,12 @@ for name, hw, cin, cout in shapes:
     for tag, flag, src in (("NHWC rows", 0, x), ("step-major A", 64, xb)):
         L.avs_debug_flags(flag)
         for _ in range(2):
-            ops.conv2d(src, w, 1, 1, 1, 0, y, w_layout=1)
+            ops.conv2d(src, w, 1, 1, 1, 0, y, w_layout=1, variant=2)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5):
-            ops.conv2d(src, w, 1, 1, 1, 0, y, w_layout=1)
+            ops.conv2d(src, w, 1, 1, 1, 0, y, w_layout=1, variant=2)
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / 5
@@ -47,4 +46,3 @@ for name, hw, cin, cout in shapes:
         line += f" | {tag} {us:8.1f} us {flops / us / 1e6:6.0f} TFLOP/s" + ("" if flag == 0 else (" same" if torch.equal(y, ref) else " DIFFERENT"))
     print(line, flush=True)
 L.avs_debug_flags(0)
-L.avs_tune_tall_tiles(0, 0, -1)

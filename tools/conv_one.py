@@ -9,13 +9,12 @@ from avsum_amd import ops, _abi
 n, hw, cin, cout, k = [int(v) for v in sys.argv[1:6]]
 if len(sys.argv) > 6:      # optional: debug flags (avs_debug_flags), tall mode
     _abi.lib().avs_debug_flags(int(sys.argv[6]))
-if len(sys.argv) > 7:
-    _abi.lib().avs_tune_tall_tiles(int(sys.argv[7]), 0, -1)
+variant = int(sys.argv[7]) if len(sys.argv) > 7 else 0   # avs_conv_desc.variant (1 = 128-row, 2 = 256-row tiles)
 dev = torch.device("cuda", 0)
 dt = torch.bfloat16
 x = torch.randn(n, hw, hw, cin, device=dev).to(dt)
 w = (torch.randn(cout, k * k * cin, device=dev) / (k * k * cin) ** 0.5).to(dt)
 y = torch.empty(n, hw, hw, cout, device=dev, dtype=dt)
 for _ in range(3):
-    ops.conv2d(x, w, k, k, 1, k // 2, y)
+    ops.conv2d(x, w, k, k, 1, k // 2, y, variant=variant)
 torch.cuda.synchronize()

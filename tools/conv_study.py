@@ -36,14 +36,13 @@ for name, n, hw, cin, cout, k, s in shapes:
         L.avs_debug_flags(flags)
         L.avs_tune_short_reduction_bytes(rowb)
         L.avs_tune_pipeline(pipe)
-        L.avs_tune_tall_tiles(tall, 0, -1)
         for _ in range(2):
-            ops.conv2d(x, w, k, k, s, k // 2, y)
+            ops.conv2d(x, w, k, k, s, k // 2, y, variant=tall)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5):
-            ops.conv2d(x, w, k, k, s, k // 2, y)
+            ops.conv2d(x, w, k, k, s, k // 2, y, variant=tall)
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / 5
@@ -51,5 +50,4 @@ for name, n, hw, cin, cout, k, s in shapes:
     print(line, flush=True)
 L.avs_debug_flags(0)
 L.avs_tune_pipeline(1)
-L.avs_tune_tall_tiles(0, 0, -1)
 L.avs_tune_short_reduction_bytes(2048)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel study: the convolution + per-tile statistics launch (the split form's first kernel) per ResNet-50 layer shape
-with the 128-row and the 256-row tiles (avs_tune_tall_tiles: 1 = never, 2 = whenever the variant exists), the latter
+with the 128-row and the 256-row tiles (avs_conv_desc.variant: AVS_TILE_128 / AVS_TILE_256, per call), the latter
 also with the weights stored reduction-step major (AVS_W_KSTEP32).
 Usage: python tools/tile_study.py [--n 4096]"""
 import argparse, os, sys
@@ -40,12 +40,11 @@ for name, hw, cin, cout, k, s in shapes:
     wk = ops.weights_kstep32(w)   # reduction-step major image (AVS_W_KSTEP32)
     ref_y = None
     for tag, tall, kstep in (("128-row", 1, 0), ("256-row", 2, 0), ("256-row w-kstep", 2, 1)):
-        L.avs_tune_tall_tiles(tall, 0, -1)
         wsel = wk if kstep else w
 
         def run():
             return ops.conv2d_raw(code, *geom, x, *xs, wsel, wrs, y, cout, bnstats=(ho * ho, gamma, beta, 1e-5),
-                                  w_layout=kstep)
+                                  w_layout=kstep, variant=tall)
         for _ in range(2):
             run()
         torch.cuda.synchronize()
@@ -61,4 +60,3 @@ for name, hw, cin, cout, k, s in shapes:
         same = "" if not kstep else (" same" if torch.equal(y, ref_y) else " DIFFERENT")
         line += f" | {tag} {us:8.1f} us {flops / us / 1e6:6.0f} TFLOP/s{same}"
     print(line, flush=True)
-L.avs_tune_tall_tiles(0, 0, -1)
