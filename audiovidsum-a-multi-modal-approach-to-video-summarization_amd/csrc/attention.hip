@@ -145,6 +145,240 @@ __global__ __launch_bounds__(64 * NW, 1) void flash_mhsa_kernel(const float* __r
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same fused core on the fp16 matrix cores, split precision (AVS_F16X2 operands): Q, K, V come in as fp16 hi | lo
+// runs (avs_f16x2_pack_f32 of the fp32 projections), every product is hi*hi + lo*hi + hi*lo on v_mfma_f32_32x32x16_f16
+// (2^-21 relative, fp32 accumulation), the probabilities are split once per tile in registers.  16x the matrix rate of
+// the fp32 MFMA: the [T, T] scores never exist AND the kernel beats the batched-GEMM path, so `auto` never
+// materialises them.  Layout as above (a query lives on a lane), with two differences:
+//   K tile   rows of f16x2 as they are ([key][D slots], pitch D * 4 + 16 bytes): lane (key, half) reads its 16-element
+//            step as two 16-byte LDS reads (hi run, lo run);
+//   V tile   TRANSPOSED planes Vt_hi / Vt_lo [d][32 key slots] (2-byte writes when staging, a lane per key so that a
+//            wave's writes are contiguous): the reduction index of O^T += V^T . P is the key.  Key slots are ordered
+//            the way the S^T accumulator holds keys - register e = 8 s + j of lane half h is key
+//            16 s + 4 h + (j & 3) + 8 (j >> 2) - so P needs no data movement, only the split.
+// One workgroup per CU (512 registers per wave: 128 accumulator + 128 Q fragment registers at D = 256).
+template <int D, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void flash_mhsa_h2_kernel(const char* __restrict__ q, const char* __restrict__ k,
+                                                               const char* __restrict__ v, long long ld, int T,
+                                                               float sqrt_d, float* __restrict__ ctx, long long ldo) {
+  constexpr int KPB = D * 4 + 16;    // K tile pitch (bytes)
+  constexpr int VPB = 32 * 2 + 16;   // V^T plane pitch (bytes): 32 key slots of fp16
+  constexpr int DT = D / 32;         // 32-wide d tiles of the output
+  constexpr int KS = D / 16;         // reduction steps of S^T
+  constexpr int OP = 33;             // output staging pitch
+  constexpr int NTH = 64 * NW;
+  constexpr int NCK = (32 * D * 4 / 16) / NTH;   // 16-byte K chunks per thread and tile
+  constexpr int NPV = (32 * D / 8) / NTH;        // (key, run) pairs of V per thread and tile
+  __shared__ __attribute__((aligned(16))) char ks[32 * KPB];
+  __shared__ __attribute__((aligned(16))) char vth[D * VPB];
+  __shared__ __attribute__((aligned(16))) char vtl[D * VPB];
+  __shared__ float os[NW][32 * OP];
+
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int lj = lane & 31, lh = lane >> 5;
+  const int h = blockIdx.y;
+  const long long boff = (long long)blockIdx.z * T;
+  const int q0 = blockIdx.x * (32 * NW) + wave * 32;
+  const int qrow = q0 + lj;
+  const bool q_ok = qrow < T;
+
+  // this lane's query row as MFMA B fragments: step s covers d = 16 s + 8 lh .. + 7 = run 2 s + lh (hi | lo)
+  uint4 qh[KS], ql[KS];
+  {
+    const char* qp = q + ((boff + (q_ok ? qrow : 0)) * ld + h * D) * 4;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const uint4* r = reinterpret_cast<const uint4*>(qp + (2 * s + lh) * 32);
+      qh[s] = q_ok ? r[0] : make_uint4(0u, 0u, 0u, 0u);
+      ql[s] = q_ok ? r[1] : make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+  f32x16 oacc[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[i][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // staging assignments: K as 16-byte chunks (row-major copy), V as (key = lane & 31, run) pairs
+  const int vkey = t & 31;
+  const int vslot = 16 * (vkey >> 4) + 8 * ((vkey >> 2) & 1) + (vkey & 3) + 4 * ((vkey >> 3) & 1);
+  uint4 kreg[NCK], vreg[NPV][2];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int c = 0; c < NCK; ++c) {
+      const int idx = t + NTH * c;
+      const int lrow = idx / (D / 4), ch = idx - lrow * (D / 4);
+      const bool ok = k0 + lrow < T;
+      kreg[c] = *reinterpret_cast<const uint4*>(k + ((boff + (ok ? k0 + lrow : 0)) * ld + h * D) * 4 + ch * 16);
+      if (!ok) kreg[c] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    const bool vok = k0 + vkey < T;
+#pragma unroll
+    for (int c = 0; c < NPV; ++c) {
+      const int run = (t >> 5) + (NTH / 32) * c;
+      const uint4* src = reinterpret_cast<const uint4*>(v + ((boff + (vok ? k0 + vkey : 0)) * ld + h * D + 8 * run) * 4);
+      vreg[c][0] = src[0];
+      vreg[c][1] = src[1];
+      if (!vok) vreg[c][0] = vreg[c][1] = make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int c = 0; c < NCK; ++c) {
+      const int idx = t + NTH * c;
+      const int lrow = idx / (D / 4), ch = idx - lrow * (D / 4);
+      *reinterpret_cast<uint4*>(ks + lrow * KPB + ch * 16) = kreg[c];
+    }
+#pragma unroll
+    for (int c = 0; c < NPV; ++c) {
+      const int run = (t >> 5) + (NTH / 32) * c;
+      const unsigned hw[4] = {vreg[c][0].x, vreg[c][0].y, vreg[c][0].z, vreg[c][0].w};
+      const unsigned lw[4] = {vreg[c][1].x, vreg[c][1].y, vreg[c][1].z, vreg[c][1].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int d0 = 8 * run + 2 * j;
+        *reinterpret_cast<unsigned short*>(vth + d0 * VPB + vslot * 2) = (unsigned short)hw[j];
+        *reinterpret_cast<unsigned short*>(vth + (d0 + 1) * VPB + vslot * 2) = (unsigned short)(hw[j] >> 16);
+        *reinterpret_cast<unsigned short*>(vtl + d0 * VPB + vslot * 2) = (unsigned short)lw[j];
+        *reinterpret_cast<unsigned short*>(vtl + (d0 + 1) * VPB + vslot * 2) = (unsigned short)(lw[j] >> 16);
+      }
+    }
+  };
+
+  gload(0);
+  for (int k0 = 0; k0 < T; k0 += 32) {
+    __syncthreads();   // the previous tile is no longer read
+    lstore();
+    __syncthreads();
+    if (k0 + 32 < T) gload(k0 + 32);   // the next tile's rows are in flight during this tile's matrix work
+
+    // S^T[key][query] = sum_d K[key][d] Q[query][d]
+    f32x16 sacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const uint4* kr = reinterpret_cast<const uint4*>(ks + lj * KPB + (2 * s + lh) * 32);
+      const avs_f16x8 kh = __builtin_bit_cast(avs_f16x8, kr[0]), kl = __builtin_bit_cast(avs_f16x8, kr[1]);
+      const avs_f16x8 bh = __builtin_bit_cast(avs_f16x8, qh[s]), bl = __builtin_bit_cast(avs_f16x8, ql[s]);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, bh, sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, bh, sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, bl, sacc, 0, 0, 0);
+      // (without a fence every few steps the scheduler hoists all K fragment reads of the tile and the kernel spills)
+      if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    // scale, mask the keys past T, online softmax per query (= per lane; the two lane halves hold different keys)
+    float mt = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      const float sv = key < T ? sacc[e] / sqrt_d : -INFINITY;
+      sacc[e] = sv;
+      mt = fmaxf(mt, sv);
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    const float corr = expf(m_run - m_new);
+    float ls = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float pe = expf(sacc[e] - m_new);
+      sacc[e] = pe;
+      ls += pe;
+    }
+    ls += __shfl_xor(ls, 32, 64);
+    l_run = l_run * corr + ls;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[i][e] *= corr;
+    // P as fp16 hi | lo B fragments: step s2 holds registers 8 s2 .. 8 s2 + 7 (the key slots of the V^T planes)
+    uint4 ph[2], pl[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const float pv[8] = {sacc[8 * s2], sacc[8 * s2 + 1], sacc[8 * s2 + 2], sacc[8 * s2 + 3],
+                           sacc[8 * s2 + 4], sacc[8 * s2 + 5], sacc[8 * s2 + 6], sacc[8 * s2 + 7]};
+      avs_f16x2_split8(pv, ph[s2], pl[s2]);
+    }
+    // O^T[d][query] += sum_key V[key][d] P[key][query]
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int off = (32 * i + lj) * VPB + (16 * s2 + 8 * lh) * 2;
+        const avs_f16x8 vh = __builtin_bit_cast(avs_f16x8, *reinterpret_cast<const uint4*>(vth + off));
+        const avs_f16x8 vl = __builtin_bit_cast(avs_f16x8, *reinterpret_cast<const uint4*>(vtl + off));
+        const avs_f16x8 bh = __builtin_bit_cast(avs_f16x8, ph[s2]), bl = __builtin_bit_cast(avs_f16x8, pl[s2]);
+        oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, bh, oacc[i], 0, 0, 0);
+        oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, bh, oacc[i], 0, 0, 0);
+        oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, bl, oacc[i], 0, 0, 0);
+        if (s2 == 1 && (i & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+      }
+  }
+
+  // normalise and store: O^T tile (d rows in registers, query on the lane) -> LDS [query][d] -> 128-byte rows
+  const float inv_l = 1.f / l_run;
+  float* osw = os[wave];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int dd = (e & 3) + 8 * (e >> 2) + 4 * lh;
+      osw[lj * OP + dd] = oacc[i][e] * inv_l;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int r = (lane >> 3) + 8 * it, c = (lane & 7) * 4;
+      if (q0 + r < T) {
+        float4 o4;
+        o4.x = osw[r * OP + c];
+        o4.y = osw[r * OP + c + 1];
+        o4.z = osw[r * OP + c + 2];
+        o4.w = osw[r * OP + c + 3];
+        *reinterpret_cast<float4*>(ctx + (boff + q0 + r) * ldo + h * D + i * 32 + c) = o4;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+extern "C" int avs_mhsa_flash_f16x2(const void* d_q, const void* d_k, const void* d_v, int64_t ld, int b, int t,
+                                    int heads, int head_dim, float* d_ctx, int64_t ldo, avs_stream_t stream) {
+  const char* who = "avs_mhsa_flash_f16x2";
+  AVS_REQUIRE(b > 0 && t >= 0 && heads > 0 && (head_dim == 64 || head_dim == 128 || head_dim == 256), AVS_E_SHAPE,
+              "%s: b=%d t=%d heads=%d head_dim=%d (head_dim must be 64, 128 or 256)", who, b, t, heads, head_dim);
+  AVS_REQUIRE(ld >= (int64_t)heads * head_dim && ldo >= (int64_t)heads * head_dim && ld % 8 == 0 && ldo % 4 == 0,
+              AVS_E_SHAPE, "%s: row strides too small, or not multiples of 8 slots (q, k, v) / 4 floats (ctx)", who);
+  if (t == 0) return AVS_OK;
+  AVS_REQUIRE(d_q && d_k && d_v && d_ctx, AVS_E_ARG, "%s: null pointer", who);
+  AVS_REQUIRE(((((uintptr_t)d_q) | ((uintptr_t)d_k) | ((uintptr_t)d_v)) & 31u) == 0 && avs_aligned16(d_ctx), AVS_E_ALIGN,
+              "%s: q, k, v must be 32-byte aligned (AVS_F16X2), ctx 16-byte aligned", who);
+  AVS_REQUIRE(b <= 65535 && heads <= 65535, AVS_E_SHAPE, "%s: grid too large", who);
+  // 64 queries (2 waves) per workgroup while that still leaves CUs idle, else 128
+  const bool small = avs_cdiv(t, 128) * heads * b < 256;
+  const int qpw = small ? 64 : 128;
+  dim3 grid((unsigned)avs_cdiv(t, qpw), (unsigned)heads, (unsigned)b);
+  const float sq = sqrtf((float)head_dim);
+#define AVS_FLASH_H2_LAUNCH(DD, NWV)                                                                                   \
+  hipLaunchKernelGGL((flash_mhsa_h2_kernel<DD, NWV>), grid, dim3(64 * NWV), 0, (hipStream_t)stream, (const char*)d_q,  \
+                     (const char*)d_k, (const char*)d_v, (long long)ld, t, sq, d_ctx, (long long)ldo)
+  if (head_dim == 64) {
+    if (small) AVS_FLASH_H2_LAUNCH(64, 2); else AVS_FLASH_H2_LAUNCH(64, 4);
+  } else if (head_dim == 128) {
+    if (small) AVS_FLASH_H2_LAUNCH(128, 2); else AVS_FLASH_H2_LAUNCH(128, 4);
+  } else {
+    if (small) AVS_FLASH_H2_LAUNCH(256, 2); else AVS_FLASH_H2_LAUNCH(256, 4);
+  }
+#undef AVS_FLASH_H2_LAUNCH
+  AVS_CHECK_LAUNCH(who);
+  return AVS_OK;
+}
+
 extern "C" int avs_mhsa_flash_f32(const float* d_q, const float* d_k, const float* d_v, int64_t ld, int b, int t,
                                   int heads, int head_dim, float* d_ctx, int64_t ldo, avs_stream_t stream) {
   AVS_REQUIRE(b > 0 && t >= 0 && heads > 0 && (head_dim == 64 || head_dim == 128 || head_dim == 256), AVS_E_SHAPE,

@@ -6,8 +6,9 @@ Same constructor, same sub-module names (query, key, value, out), batch-first
     Q, K projections          -> avs_gemm_nt                         attention.py:17-18
     V projection, TRANSPOSED  -> avs_gemm_nt with A = W_v, B = x     attention.py:19
                                  (V^T[e, t], so the second einsum is an NT GEMM too)
-    head dim 64 / 128 / 256:  -> avs_mhsa_flash_f32: QK^T, online softmax (one wave shuffle per tile) and PV
-                                 fused, the [T,T] scores never reach memory           attention.py:21-24
+    head dim 64 / 128 / 256:  -> avs_f16x2_pack_f32 + avs_mhsa_flash_f16x2: QK^T, online softmax (one wave shuffle
+                                 per tile) and PV fused on the fp16 matrix cores (hi*hi + lo*hi + hi*lo), the [T,T]
+                                 scores never reach memory (avs_mhsa_flash_f32 = the exact-fp32 form) attention.py:21-24
     other head dims:
     scores = Q.K^T / sqrt(d)  -> avs_gemm_nt, batch = heads          attention.py:21
     softmax over keys         -> avs_softmax_rows_f32 (wave shuffle)  attention.py:22
@@ -35,7 +36,10 @@ class MultiHeadSelfAttention(nn.Module):
         self.out = nn.Linear(embed_dim, embed_dim)
         self.num_heads = num_heads
         self.dim_head = embed_dim // num_heads
-        self.use_flash = "auto"  # True / False / "auto" (fused kernel needs head dim 64, 128 or 256)
+        # True / "f32" / False / "auto".  The fused kernel (head dim 64, 128 or 256) never materialises the [T,T] scores:
+        # True / "auto" = its split-precision form on the fp16 matrix cores (avs_mhsa_flash_f16x2: faster than the
+        # batched-GEMM path at every size measured), "f32" = the exact fp32 MFMA form, False = the batched-GEMM path
+        self.use_flash = "auto"
 
     def forward(self, x):
         if not x.is_cuda:
@@ -53,13 +57,11 @@ class MultiHeadSelfAttention(nn.Module):
         dev = x2.device
         q = ops.linear(x2, self.query.weight, self.query.bias)
         k = ops.linear(x2, self.key.weight, self.key.bias)
-        # "auto": the fused kernel when the [B,H,T,T] scores would be large (>= 1 GiB); for moderate T the
-        # batched-GEMM path keeps more of the chip busy (measured: 2.4 vs 2.7 ms at T = 5000, E = 1024, H = 4)
-        flash = self.use_flash if isinstance(self.use_flash, bool) else (4.0 * b * h * t * t >= 2 ** 30)
+        flash = self.use_flash is not False
         if d in (64, 128, 256) and flash:
-            # fused core: scores never materialised (avs_mhsa_flash_f32)
+            # fused core: scores never materialised
             v = ops.linear(x2, self.value.weight, self.value.bias)
-            ctx = ops.mhsa_flash(q, k, v, b, t, h)
+            ctx = ops.mhsa_flash(q, k, v, b, t, h, split=self.use_flash != "f32")
             return ops.linear(ctx, self.out.weight, self.out.bias).view(b, t, e)
         tp = (t + 3) // 4 * 4
         vt = torch.zeros((b, e, tp), dtype=torch.float32, device=dev)

@@ -800,8 +800,10 @@ def score_head(hid, w2, b2):
     return out
 
 
-def mhsa_flash(q, k, v, b, t, heads):
-    """q, k, v: fp32 [b*t, E] (projected); returns ctx [b*t, E].  Head dim E/heads must be 64, 128 or 256."""
+def mhsa_flash(q, k, v, b, t, heads, split=True):
+    """q, k, v: fp32 [b*t, E] (projected); returns ctx [b*t, E].  Head dim E/heads must be 64, 128 or 256.
+    split (default): the operands are packed to fp16 hi | lo runs and the products run on the fp16 matrix cores as
+    hi*hi + lo*hi + hi*lo (avs_mhsa_flash_f16x2); False: the exact fp32 MFMA kernel (avs_mhsa_flash_f32)."""
     for name, x in (("q", q), ("k", k), ("v", v)):
         _f32(x, name)
         _rowmajor2d(x, name)
@@ -809,6 +811,11 @@ def mhsa_flash(q, k, v, b, t, heads):
     ctx = torch.empty((b * t, e), dtype=torch.float32, device=q.device)
     if not (q.stride(0) == k.stride(0) == v.stride(0)):
         raise ValueError("q, k, v must share a row stride")
+    if split and e % 8 == 0 and q.is_contiguous() and k.is_contiguous() and v.is_contiguous():
+        qp, kp, vp = f16x2_pack(q), f16x2_pack(k), f16x2_pack(v)
+        check(lib().avs_mhsa_flash_f16x2(_p(qp), _p(kp), _p(vp), qp.stride(0), b, t, heads, e // heads, _p(ctx), e,
+                                         _stream()), "avs_mhsa_flash_f16x2")
+        return ctx
     check(lib().avs_mhsa_flash_f32(_p(q), _p(k), _p(v), q.stride(0), b, t, heads, e // heads, _p(ctx), e, _stream()),
           "avs_mhsa_flash_f32")
     return ctx

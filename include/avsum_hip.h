@@ -444,6 +444,12 @@ int avs_score_head_f32(const float* d_hid, int64_t rows, int d, int64_t ldh,
  * fp32 MFMA for both products, per-query online softmax folded with one wave shuffle.                      */
 int avs_mhsa_flash_f32(const float* d_q, const float* d_k, const float* d_v, int64_t ld, int b, int t,
                        int heads, int head_dim, float* d_ctx, int64_t ldo, avs_stream_t stream);
+/* The same fused core with AVS_F16X2 operands (d_q / d_k / d_v: the projections after avs_f16x2_pack_f32, row stride
+ * ld slots; d_ctx fp32): every product hi*hi + lo*hi + hi*lo on v_mfma_f32_32x32x16_f16 (2^-21 relative, fp32
+ * accumulation; the probabilities are split in registers), 16x the matrix rate of the fp32 MFMA - faster than the
+ * batched-GEMM path at every size measured, so the [T,T] scores are never materialised (models/attention.py:21-24). */
+int avs_mhsa_flash_f16x2(const void* d_q, const void* d_k, const void* d_v, int64_t ld, int b, int t, int heads,
+                         int head_dim, float* d_ctx, int64_t ldo, avs_stream_t stream);
 
 /* Row softmax in place: x[r, 0:n] for `rows` rows of stride ldx
  * (torch.softmax(dim=-1) at models/attention.py:22).                         */

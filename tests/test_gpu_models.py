@@ -163,13 +163,16 @@ def test_mhsa(dev, e, h, b, t):
     ref = osc.mhsa_forward(m.state_dict(), x, h)
     md = m.to(dev)
     with torch.no_grad():
-        md.use_flash = True   # fused kernel (head dims 64/128/256; silently the GEMM path otherwise)
-        got = md(x.to(dev)).cpu()
+        md.use_flash = True   # fused kernel, split precision on the fp16 matrix cores (head dims 64/128/256;
+        got = md(x.to(dev)).cpu()   # silently the GEMM path otherwise): the default ("auto")
+        md.use_flash = "f32"  # the fused kernel on the fp32 MFMA
+        got3 = md(x.to(dev)).cpu()
         md.use_flash = False  # the materialised-score path must agree too
         got2 = md(x.to(dev)).cpu()
     assert got.shape == ref.shape
     assert (got - ref).abs().max().item() < 1e-4
     assert (got2 - ref).abs().max().item() < 1e-4
+    assert (got3 - ref).abs().max().item() < 1e-4
 
 
 def _frames(n, seed, h=224, w=224):

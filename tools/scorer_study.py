@@ -33,8 +33,10 @@ with torch.no_grad():
         ms_s = timeit(lambda: scorer(v, a))
         mhsa.use_flash = False
         ms_m = timeit(lambda: mhsa(x))
-        mhsa.use_flash = True
+        mhsa.use_flash = "f32"
         ms_f = timeit(lambda: mhsa(x))
+        mhsa.use_flash = True
+        ms_h = timeit(lambda: mhsa(x))
         print(f"T={t:5d}  AVBiLSTMModel {ms_s:8.3f} ms ({t / ms_s:8.1f} k steps/s)   MHSA(1024,4) GEMM path {ms_m:8.3f} ms "
-              f"| fused {ms_f:8.3f} ms ({4.0 * t * t * 1024 * 1e-9 / ms_f:6.1f} TFLOP/s on the two T^2 products)",
-              flush=True)
+              f"| fused fp32 MFMA {ms_f:8.3f} ms | fused fp16 split {ms_h:8.3f} ms "
+              f"({4.0 * t * t * 1024 * 1e-9 / ms_h:6.1f} TFLOP/s on the two T^2 products, whole forward)", flush=True)
