@@ -200,6 +200,7 @@ __global__ __launch_bounds__(64 * NW, 1) void flash_mhsa_h2_kernel(const char* _
 #pragma unroll
     for (int e = 0; e < 16; ++e) oacc[i][e] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
+  const float inv_sqrt_d = 1.f / sqrt_d;   // (head dims are powers of four here: exact)
 
   // staging assignments: K as 16-byte chunks (row-major copy), V as (key = lane & 31, run) pairs
   const int vkey = t & 31;
@@ -247,12 +248,15 @@ __global__ __launch_bounds__(64 * NW, 1) void flash_mhsa_h2_kernel(const char* _
     }
   };
 
-  gload(0);
+  // D = 256 holds 128 accumulator + 128 Q fragment registers per lane: no room to keep the next tile's rows in flight
+  constexpr bool PREFETCH = D < 256;
+  if (PREFETCH) gload(0);
   for (int k0 = 0; k0 < T; k0 += 32) {
     __syncthreads();   // the previous tile is no longer read
+    if (!PREFETCH) gload(k0);
     lstore();
     __syncthreads();
-    if (k0 + 32 < T) gload(k0 + 32);   // the next tile's rows are in flight during this tile's matrix work
+    if (PREFETCH && k0 + 32 < T) gload(k0 + 32);   // the next tile's rows are in flight during this tile's matrix work
 
     // S^T[key][query] = sum_d K[key][d] Q[query][d]
     f32x16 sacc;
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(64 * NW, 1) void flash_mhsa_h2_kernel(const char* _
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-      const float sv = key < T ? sacc[e] / sqrt_d : -INFINITY;
+      const float sv = key < T ? sacc[e] * inv_sqrt_d : -INFINITY;
       sacc[e] = sv;
       mt = fmaxf(mt, sv);
     }
