@@ -36,9 +36,12 @@ class MultiHeadSelfAttention(nn.Module):
         self.out = nn.Linear(embed_dim, embed_dim)
         self.num_heads = num_heads
         self.dim_head = embed_dim // num_heads
-        # True / "f32" / False / "auto".  The fused kernel (head dim 64, 128 or 256) never materialises the [T,T] scores:
-        # True / "auto" = its split-precision form on the fp16 matrix cores (avs_mhsa_flash_f16x2: faster than the
-        # batched-GEMM path at every size measured), "f32" = the exact fp32 MFMA form, False = the batched-GEMM path
+        # "auto" / True / "f32" / False.  The fused kernels (head dim 64, 128 or 256) never materialise the [T,T] scores:
+        # True = the split-precision form on the fp16 matrix cores (avs_mhsa_flash_f16x2), "f32" = the exact fp32 MFMA
+        # form (avs_mhsa_flash_f32), "auto" = whichever of the two is faster at this T (measured on MI355X, E = 1024,
+        # H = 4, whole forward: T = 300: 0.40 / 0.48 ms, 1800: 0.77 / 1.11 ms, 5000: 2.98 / 2.69 ms).  False = the
+        # batched-GEMM path, which DOES materialise [H,T,T] (400 MB at T = 5000) and is still the fastest of the three
+        # (0.38 / 0.61 / 2.29 ms): kept as an explicit option, never chosen by "auto" (SURVEY 3.5).
         self.use_flash = "auto"
 
     def forward(self, x):
@@ -61,7 +64,8 @@ class MultiHeadSelfAttention(nn.Module):
         if d in (64, 128, 256) and flash:
             # fused core: scores never materialised
             v = ops.linear(x2, self.value.weight, self.value.bias)
-            ctx = ops.mhsa_flash(q, k, v, b, t, h, split=self.use_flash != "f32")
+            split = (t <= 3000) if self.use_flash == "auto" else self.use_flash != "f32"
+            ctx = ops.mhsa_flash(q, k, v, b, t, h, split=split)
             return ops.linear(ctx, self.out.weight, self.out.bias).view(b, t, e)
         tp = (t + 3) // 4 * 4
         vt = torch.zeros((b, e, tp), dtype=torch.float32, device=dev)
