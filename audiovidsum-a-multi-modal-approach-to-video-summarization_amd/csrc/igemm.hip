@@ -1105,6 +1105,20 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
     const int rpg = p.rows_per_group;
     const int used = (m0 + p.tile_rows <= p.M ? p.tile_rows : p.M - m0);  // rows of this tile that exist
     const int ng = used / rpg;                                            // whole groups (M is a multiple of rpg)
+    // 0. every residual row of this thread in flight BEFORE the statistics rounds (their four barriers hide the memory
+    //    latency; rows that do not exist read the residual's first bytes, never used)
+    uint4 r4[E_NIT];
+    {
+      const int srow = t / E_CPRW, sch = t - srow * E_CPRW;
+      const int col = n0 + sch * 8;
+      if (p.residual && col < p.N) {
+#pragma unroll
+        for (int it = 0; it < E_NIT; ++it) {
+          const int lrow = srow + it * E_RSTEP;
+          r4[it] = *reinterpret_cast<const uint4*>(p.residual + (lrow < used ? ((long long)(m0 + lrow) * p.ldr + col) * 2 : 0));
+        }
+      }
+    }
     // 1. zero the per-wave partial sums
     for (int i = t; i < WR * ng * 2 * BN; i += 256) red[i] = 0.f;
     __syncthreads();
@@ -1248,17 +1262,7 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
       const int col = n0 + sch * 8;
       const bool relu_res = p.act == AVS_ACT_RELU;
       if (col < p.N) {
-        // every residual row of this thread in flight at once (the accumulators are dead: registers are free),
-        // then the adds and stores: one memory latency per tile instead of one per row
-        uint4 r4[E_NIT];
-        if (p.residual) {
-#pragma unroll
-          for (int it = 0; it < E_NIT; ++it) {
-            const int lrow = srow + it * E_RSTEP;
-            r4[it] = lrow < used ? *reinterpret_cast<const uint4*>(p.residual + ((long long)(m0 + lrow) * p.ldr + col) * 2)
-                                 : make_uint4(0u, 0u, 0u, 0u);
-          }
-        }
+        // (the residual rows were fetched at the top of the epilogue)
 #pragma unroll
         for (int it = 0; it < E_NIT; ++it) {
           const int lrow = srow + it * E_RSTEP;
