@@ -157,6 +157,37 @@ class MelPlan:
         ops.clamp_topdb(db, gmax, top_db)
         return ops.linear(db, self.dct)
 
+    @staticmethod
+    def segment_table(bounds, device):
+        """bounds: STFT-frame boundaries [nseg + 1] of consecutive segments (host ints) -> the device tables of
+        avs_stft_mel_segmean_f32: blocks int32 [nblocks, 3] (first frame, frames <= 32, segment), first block of each
+        segment [nseg + 1], frames per segment [nseg]."""
+        blocks, seg_block, seg_frames = [], [0], []
+        for sgm, (a, b) in enumerate(zip(bounds[:-1], bounds[1:])):
+            a, b = int(a), int(b)
+            for f in range(a, b, 32):
+                blocks.append((f, min(32, b - f), sgm))
+            seg_block.append(len(blocks))
+            seg_frames.append(max(0, b - a))
+        mk = lambda v, shape: torch.tensor(v, dtype=torch.int32).reshape(shape).to(device)
+        return mk(blocks, (len(blocks), 3)), mk(seg_block, (len(seg_block),)), mk(seg_frames, (len(seg_frames),))
+
+    def segment_means(self, wave, table, out_log2=None, out_mfcc_db=None, top_db=80.0):
+        """Per segment (a shot's slice of the track) the time mean of the log2-mel rows (out_log2 [nseg, >= n_mels]) and
+        of the top_db-clamped dB-mel rows (out_mfcc_db; its DCT is the mean of the MFCC rows: the DCT and mfcc_proj are
+        linear) without the per-frame matrices (features/extractors.py:232-246 pool them over time): two passes over
+        the waveform - the track's maximum for the clamp, then the means - nothing per frame in HBM."""
+        t = wave.numel()
+        if t <= N_FFT // 2:
+            raise RuntimeError(f"Argument #4: Padding size should be less than the corresponding input dimension, "
+                               f"but got: padding ({N_FFT // 2}, {N_FFT // 2}) at dimension 1 of input [1, {t}]")
+        wave = wave.contiguous()
+        if wave.data_ptr() % 16:
+            wave = wave.clone()
+        args = (wave, self.window, self.cos_t, self.sin_t, self.fb, self.fb_lo, self.fb_hi)
+        gmax = ops.stft_mel_max(*args) if out_mfcc_db is not None else None
+        return ops.stft_mel_segmean(*args, *table, gmax=gmax, top_db=top_db, out_log2=out_log2, out_db=out_mfcc_db)
+
     def log2_mel_and_mfcc(self, wave, top_db=80.0):
         """Both features of one waveform from ONE pass over it (the spectrum is shared): ([frames, n_mels], [frames, n_mfcc])."""
         mel, db, _, gmax = self._fused(wave, log2=True, db=True)

@@ -184,17 +184,24 @@ extern "C" int avs_power_mel_f32(const float* d_spec, int64_t frames, int nbins,
 #define AVS_FUSED_RE_ROWS 204  // n = 0 .. 200 padded to a multiple of 4
 #define AVS_FUSED_IM_ROWS 200  // n = 1 .. 199 padded to a multiple of 4
 
+// SEG: a workgroup's frames come from a block table (first STFT frame, count <= 32, segment) instead of blockIdx * 32 and
+// nothing per frame is written: the block's per-mel SUMS over its frames (log2-mel, and the dB value clamped at
+// 10 log10(*max_in) - top_db) go to part_log2 / part_db [block, nmel]; segment_fold_kernel adds a segment's blocks in
+// block order and divides by its frame count - the time means of a shot (features/extractors.py:232-246 take means over
+// time of the per-frame matrices) without the [frames, nmel] matrices ever reaching HBM.  Deterministic.
+template <bool SEG>
 __global__ __launch_bounds__(256, 2) void stft_mel_fused_kernel(
     const float* __restrict__ x, long long t, long long frames, const double* __restrict__ window,
     const double* __restrict__ cos_t, const double* __restrict__ sin_t, const float* __restrict__ fb,
     const int* __restrict__ fb_lo, const int* __restrict__ fb_hi, int nmel, float* __restrict__ out_log2,
-    float* __restrict__ out_db, float* __restrict__ out_pow, float* __restrict__ gmax) {
+    float* __restrict__ out_db, float* __restrict__ out_pow, float* __restrict__ gmax, const int* __restrict__ blocks,
+    float* __restrict__ part_log2, float* __restrict__ part_db, const float* __restrict__ max_in, float top_db) {
   constexpr int SPAN = AVS_FUSED_FPB * AVS_FUSED_HOP + (AVS_FUSED_NFFT - AVS_FUSED_HOP);   // 6600 samples
   __shared__ __attribute__((aligned(16))) float span[SPAN];
   __shared__ double win[AVS_FUSED_NFFT];
   __shared__ float pw[AVS_FUSED_FPB][AVS_FUSED_BINS + 3];
   const int tid = threadIdx.x;
-  const long long f0 = (long long)blockIdx.x * AVS_FUSED_FPB;
+  const long long f0 = SEG ? (long long)blocks[3 * blockIdx.x] : (long long)blockIdx.x * AVS_FUSED_FPB;
   // ---- stage the span: padded position q = f0 * 200 + i is sample q - 200, reflected at both ends
   const long long q0 = f0 * AVS_FUSED_HOP - AVS_FUSED_NFFT / 2;
   for (int i = tid * 4; i < SPAN; i += 256 * 4) {
@@ -266,6 +273,24 @@ __global__ __launch_bounds__(256, 2) void stft_mel_fused_kernel(
   }
   __syncthreads();
   // ---- mel + log: a thread owns (frame, mel) pairs and sums its filter's non-zero bins in ascending order
+  if constexpr (SEG) {
+    // a thread owns a mel band and walks the block's frames in order: sums of log2(mel + 1e-6) and of the clamped dB
+    const int nf = blocks[3 * blockIdx.x + 1];
+    const float thr = part_db ? 10.f * log10f(*max_in) - top_db : 0.f;
+    for (int m = tid; m < nmel; m += 256) {
+      const int lo = fb_lo[m], hi = fb_hi[m];
+      float s_log = 0.f, s_db = 0.f;
+      for (int f = 0; f < nf; ++f) {
+        float a = 0.f;
+        for (int k = lo; k < hi; ++k) a += pw[f][k] * fb[(long long)k * nmel + m];
+        s_log += log2f(a + 1e-6f);
+        s_db += fmaxf(10.f * log10f(fmaxf(a, 1e-10f)), thr);
+      }
+      if (part_log2) part_log2[(long long)blockIdx.x * nmel + m] = s_log;
+      if (part_db) part_db[(long long)blockIdx.x * nmel + m] = s_db;
+    }
+    return;
+  }
   const int nf = (int)((frames - f0) < AVS_FUSED_FPB ? (frames - f0) : AVS_FUSED_FPB);
   float lmax = 0.f;
   for (int i = tid; i < nf * nmel; i += 256) {
@@ -275,14 +300,14 @@ __global__ __launch_bounds__(256, 2) void stft_mel_fused_kernel(
     for (int k = lo; k < hi; ++k) a += pw[f][k] * fb[(long long)k * nmel + m];
     const long long o = (f0 + f) * nmel + m;
     if (out_log2) out_log2[o] = log2f(a + 1e-6f);
-    if (out_db) {
+    if (gmax) {   // the dB feature (and / or only the track's maximum, which its top_db clamp needs)
       const float cl = fmaxf(a, 1e-10f);
       lmax = fmaxf(lmax, cl);
-      out_db[o] = 10.f * log10f(cl);
+      if (out_db) out_db[o] = 10.f * log10f(cl);
     }
     if (out_pow) out_pow[o] = a;
   }
-  if (out_db) {
+  if (gmax) {
     lmax = avs_wave_max(lmax);
     // positive floats order like their bit patterns: an integer max, order-independent
     if ((tid & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(gmax), __float_as_uint(lmax));
@@ -298,15 +323,69 @@ extern "C" int avs_stft_mel_fused_f32(const float* d_wave, int64_t t, const doub
               AVS_FUSED_NFFT / 2, (long long)t);
   AVS_REQUIRE(nmel > 0 && nmel <= 1024, AVS_E_SHAPE, "%s: nmel=%d", who, nmel);
   AVS_REQUIRE(d_wave && d_window && d_cos && d_sin && d_fb && d_fb_lo && d_fb_hi, AVS_E_ARG, "%s: null pointer", who);
-  AVS_REQUIRE(d_log2mel || d_db || d_power, AVS_E_ARG, "%s: no output requested", who);
+  AVS_REQUIRE(d_log2mel || d_db || d_power || d_max, AVS_E_ARG, "%s: no output requested", who);
   AVS_REQUIRE(!d_db || d_max, AVS_E_ARG, "%s: the dB output needs d_max", who);
   AVS_REQUIRE(avs_aligned16(d_wave), AVS_E_ALIGN, "%s: the waveform must be 16-byte aligned", who);
   const long long frames = 1 + t / AVS_FUSED_HOP;
   const long long blocks = avs_cdiv(frames, AVS_FUSED_FPB);
   AVS_REQUIRE(blocks < (1ll << 31), AVS_E_SHAPE, "%s: too many frames", who);
-  hipLaunchKernelGGL(stft_mel_fused_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_wave,
+  hipLaunchKernelGGL(stft_mel_fused_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_wave,
                      (long long)t, frames, d_window, d_cos, d_sin, d_fb, d_fb_lo, d_fb_hi, nmel, d_log2mel, d_db, d_power,
-                     d_max);
+                     d_max, (const int*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr, 0.f);
+  AVS_CHECK_LAUNCH(who);
+  return AVS_OK;
+}
+
+// out[s, m] = (sum of part[b, m] over the blocks b of segment s, in block order) / frames of s
+__global__ __launch_bounds__(256) void segment_fold_kernel(const float* __restrict__ part, const int* __restrict__ seg_block,
+                                                           const int* __restrict__ seg_frames, int nseg, int nmel,
+                                                           float* __restrict__ out, long long ldo) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)nseg * nmel;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int sgm = (int)(i / nmel), m = (int)(i - (long long)sgm * nmel);
+    float a = 0.f;
+    for (int b = seg_block[sgm]; b < seg_block[sgm + 1]; ++b) a += part[(long long)b * nmel + m];
+    out[sgm * ldo + m] = seg_frames[sgm] > 0 ? a / (float)seg_frames[sgm] : 0.f;
+  }
+}
+
+extern "C" int avs_stft_mel_segmean_f32(const float* d_wave, int64_t t, const double* d_window, const double* d_cos,
+                                        const double* d_sin, const float* d_fb, const int* d_fb_lo, const int* d_fb_hi,
+                                        int nmel, const int* d_blocks, int nblocks, const int* d_seg_block,
+                                        const int* d_seg_frames, int nseg, const float* d_max, float top_db,
+                                        float* d_mean_log2, int64_t ld_log2, float* d_mean_db, int64_t ld_db, void* d_ws,
+                                        int64_t ws_bytes, avs_stream_t stream) {
+  const char* who = "avs_stft_mel_segmean_f32";
+  AVS_REQUIRE(t > AVS_FUSED_NFFT / 2, AVS_E_SHAPE, "%s: reflect padding needs more than %d samples, got %lld", who,
+              AVS_FUSED_NFFT / 2, (long long)t);
+  AVS_REQUIRE(nmel > 0 && nmel <= 1024 && nblocks >= 0 && nseg >= 0, AVS_E_SHAPE, "%s: nmel=%d nblocks=%d nseg=%d", who,
+              nmel, nblocks, nseg);
+  if (nseg == 0) return AVS_OK;
+  AVS_REQUIRE(d_wave && d_window && d_cos && d_sin && d_fb && d_fb_lo && d_fb_hi && d_blocks && d_seg_block && d_seg_frames,
+              AVS_E_ARG, "%s: null pointer", who);
+  AVS_REQUIRE(d_mean_log2 || d_mean_db, AVS_E_ARG, "%s: no output requested", who);
+  AVS_REQUIRE(!d_mean_db || d_max, AVS_E_ARG, "%s: the dB mean needs the track's maximum mel power (d_max)", who);
+  AVS_REQUIRE((!d_mean_log2 || ld_log2 >= nmel) && (!d_mean_db || ld_db >= nmel), AVS_E_SHAPE, "%s: output rows too short", who);
+  AVS_REQUIRE(avs_aligned16(d_wave), AVS_E_ALIGN, "%s: the waveform must be 16-byte aligned", who);
+  const int64_t per = (int64_t)nblocks * nmel * 4;
+  const int64_t need = per * ((d_mean_log2 ? 1 : 0) + (d_mean_db ? 1 : 0));
+  AVS_REQUIRE(d_ws && ws_bytes >= need, AVS_E_WORKSPACE, "%s: workspace %lld < %lld bytes", who, (long long)ws_bytes,
+              (long long)need);
+  float* p_log2 = d_mean_log2 ? (float*)d_ws : nullptr;
+  float* p_db = d_mean_db ? (float*)((char*)d_ws + (d_mean_log2 ? per : 0)) : nullptr;
+  const long long frames = 1 + t / AVS_FUSED_HOP;
+  if (nblocks > 0)
+    hipLaunchKernelGGL(stft_mel_fused_kernel<true>, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, d_wave,
+                       (long long)t, frames, d_window, d_cos, d_sin, d_fb, d_fb_lo, d_fb_hi, nmel, (float*)nullptr,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, d_blocks, p_log2, p_db, d_max, top_db);
+  long long gx = avs_cdiv((long long)nseg * nmel, 256);
+  if (gx > 4096) gx = 4096;
+  if (d_mean_log2)
+    hipLaunchKernelGGL(segment_fold_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, p_log2, d_seg_block,
+                       d_seg_frames, nseg, nmel, d_mean_log2, (long long)ld_log2);
+  if (d_mean_db)
+    hipLaunchKernelGGL(segment_fold_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, p_db, d_seg_block,
+                       d_seg_frames, nseg, nmel, d_mean_db, (long long)ld_db);
   AVS_CHECK_LAUNCH(who);
   return AVS_OK;
 }

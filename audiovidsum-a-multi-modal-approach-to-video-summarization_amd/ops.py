@@ -14,7 +14,7 @@ from ._abi import (ACT_NONE, ACT_RELU, AVS_BF16, AVS_F16X2, AVS_F32, AVS_F32_SPL
 __all__ = [
     "ACT_NONE", "ACT_RELU", "linear", "gemm_nt_batched", "conv2d", "conv2d_raw", "conv_bnlocal_tile_rows", "conv1x1_bn", "conv1x1_gram_bn", "bn_gram_affine", "gram_supported", "frames_normalize", "stem_conv_bn_pool", "resize_bilinear",
     "bn_batch_stats", "bn_apply", "bn_maxpool", "pool2d", "global_avgpool", "segment_mean", "hsv_frame_diff", "reflect_pad", "stft_f64", "stft_mel_fused", "power_mel",
-    "clamp_topdb", "fill", "quantize", "resample", "lstm", "mha_batchaxis", "score_head", "mhsa_flash", "softmax_rows", "cdist", "dtw_path",
+    "clamp_topdb", "stft_mel_max", "stft_mel_segmean", "fill", "quantize", "resample", "lstm", "mha_batchaxis", "score_head", "mhsa_flash", "softmax_rows", "cdist", "dtw_path",
     "gather_scale", "dtype_code", "f16x2_pack", "f16x2_unpack", "bn_gram_affine_h2", "conv2d_affine",
 ]
 
@@ -730,6 +730,49 @@ def stft_mel_fused(wave, window, cos_t, sin_t, fb, fb_lo, fb_hi, log2=False, db=
         lib().avs_stft_mel_fused_f32(_p(wave), t, _p(window), _p(cos_t), _p(sin_t), _p(fb), _p(fb_lo), _p(fb_hi), nmel,
                                      _p(o_log2), _p(o_db), _p(o_pow), _p(gmax), _stream()), "avs_stft_mel_fused_f32"))
     return o_log2, o_db, o_pow, gmax
+
+
+def stft_mel_max(wave, window, cos_t, sin_t, fb, fb_lo, fb_hi):
+    """fp32 [1]: the largest clamped mel power of the track (what the MFCC's top_db clamp is relative to), from one
+    pass of the fused front end that writes nothing else."""
+    _dev(wave, window, cos_t, sin_t, fb)
+    _f32(wave, "wave")
+    gmax = torch.zeros(1, dtype=torch.float32, device=wave.device)
+    t = wave.numel()
+    _timed("audio", AVS_F32, 4.0 * t, lambda: check(
+        lib().avs_stft_mel_fused_f32(_p(wave), t, _p(window), _p(cos_t), _p(sin_t), _p(fb), _p(fb_lo), _p(fb_hi),
+                                     fb.shape[1], None, None, None, _p(gmax), _stream()), "avs_stft_mel_fused_f32"))
+    return gmax
+
+
+_segmean_ws = {}
+
+
+def stft_mel_segmean(wave, window, cos_t, sin_t, fb, fb_lo, fb_hi, blocks, seg_block, seg_frames, gmax=None,
+                     top_db=80.0, out_log2=None, out_db=None):
+    """Time means per segment of log2(mel + 1e-6) (out_log2 [nseg, >= nmel]) and of the top_db-clamped dB mel (out_db,
+    needs gmax from stft_mel_max) straight from the waveform (avs_stft_mel_segmean_f32): no per-frame matrix is written.
+    blocks int32 [nblocks, 3] = (first STFT frame, frames <= 32, segment); seg_block int32 [nseg + 1]; seg_frames
+    int32 [nseg] - all on the device (audio.MelPlan.segment_table builds them)."""
+    _dev(wave, blocks, seg_block, seg_frames, out_log2, out_db, gmax)
+    _f32(wave, "wave")
+    nmel = fb.shape[1]
+    nblocks, nseg = blocks.shape[0], seg_frames.numel()
+    need = nblocks * nmel * 4 * (int(out_log2 is not None) + int(out_db is not None))
+    key = _ws_key(wave.device)
+    ws = _segmean_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=wave.device)
+        _segmean_ws[key] = ws
+    t = wave.numel()
+    nbytes = 4.0 * t + 4.0 * nseg * nmel * (int(out_log2 is not None) + int(out_db is not None))
+    _timed("audio", AVS_F32, nbytes, lambda: check(
+        lib().avs_stft_mel_segmean_f32(_p(wave), t, _p(window), _p(cos_t), _p(sin_t), _p(fb), _p(fb_lo), _p(fb_hi), nmel,
+                                       _p(blocks), nblocks, _p(seg_block), _p(seg_frames), nseg, _p(gmax), float(top_db),
+                                       _p(out_log2), out_log2.stride(0) if out_log2 is not None else 0, _p(out_db),
+                                       out_db.stride(0) if out_db is not None else 0, _p(ws), ws.numel(), _stream()),
+        "avs_stft_mel_segmean_f32"))
+    return out_log2, out_db
 
 
 def clamp_topdb(x, gmax, top_db):

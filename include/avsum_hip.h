@@ -373,6 +373,19 @@ int avs_stft_f64(const float* d_xpad, int64_t xpad_len, int64_t frames, int hop,
 int avs_stft_mel_fused_f32(const float* d_wave, int64_t t, const double* d_window, const double* d_cos,
                            const double* d_sin, const float* d_fb, const int* d_fb_lo, const int* d_fb_hi, int nmel,
                            float* d_log2mel, float* d_db, float* d_power, float* d_max, avs_stream_t stream);
+/* The same front end reduced to TIME MEANS per segment (a shot's slice of the track): d_blocks int32 [nblocks, 3] =
+ * (first STFT frame, frames <= 32, segment) - every segment cut into runs of at most 32 frames, in order -,
+ * d_seg_block int32 [nseg + 1] = first block of each segment, d_seg_frames int32 [nseg] = its frame count.  Out:
+ * d_mean_log2 [nseg, ld_log2] = mean over the segment's frames of log2(mel + 1e-6), d_mean_db [nseg, ld_db] = mean of
+ * max(10 log10(max(mel, 1e-10)), 10 log10(*d_max) - top_db) (d_max: the track's largest clamped mel power, from an
+ * avs_stft_mel_fused_f32 call with only d_max requested) - by linearity the DCT / mfcc_proj of that mean IS the mean
+ * of the MFCC rows.  Nothing per frame reaches HBM (features/extractors.py:232-246 pool the per-frame matrices over
+ * time); d_ws: nblocks * nmel * 4 bytes per requested output; deterministic (block partial sums folded in order).  */
+int avs_stft_mel_segmean_f32(const float* d_wave, int64_t t, const double* d_window, const double* d_cos,
+                             const double* d_sin, const float* d_fb, const int* d_fb_lo, const int* d_fb_hi, int nmel,
+                             const int* d_blocks, int nblocks, const int* d_seg_block, const int* d_seg_frames, int nseg,
+                             const float* d_max, float top_db, float* d_mean_log2, int64_t ld_log2, float* d_mean_db,
+                             int64_t ld_db, void* d_ws, int64_t ws_bytes, avs_stream_t stream);
 
 /* Power spectrum -> mel filterbank -> log.  d_spec is [frames, 2*nbins]
  * (re | im per frame, from avs_gemm_nt against the windowed DFT basis);

@@ -458,6 +458,43 @@ def test_fused_front_end_matches_the_unfused_kernels(dev, t):
 
 
 # ----------------------------------------------------------------------------- scorer pieces
+def test_segment_means_without_the_frame_matrices(dev):
+    """avs_stft_mel_segmean_f32: per-shot time means of log2-mel and of the clamped dB mel (-> MFCC by linearity) against
+    the means of the full per-frame matrices of the fused kernel; ragged segments, an empty one, deterministic."""
+    from avsum_amd.audio import MelPlan
+    ops = _ops()
+    plan = MelPlan.get(16000, 128, 40, dev)
+    g = torch.Generator().manual_seed(12)
+    tt = 16000 * 7 + 123
+    time = torch.arange(tt) / 16000.0
+    wave = (0.5 * torch.sin(2 * np.pi * 440 * time) + 0.2 * torch.sin(2 * np.pi * 1234 * time)
+            + 0.05 * torch.randn(tt, generator=g)).to(dev)
+    frames = 1 + tt // 200
+    bounds = [0, 1, 34, 34, 100, 163, 400, frames]      # 1-frame, 33-frame, EMPTY, ... segments; all frames covered
+    table = plan.segment_table(bounds, dev)
+    nseg = len(bounds) - 1
+    outs = []
+    for _ in range(2):
+        m_log2 = torch.zeros((nseg, 130), device=dev)
+        m_db = torch.zeros((nseg, 128), device=dev)
+        plan.segment_means(wave, table, m_log2, m_db)
+        outs.append((m_log2.clone(), m_db.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    mel, mfcc = plan.log2_mel_and_mfcc(wave)
+    _, db, _, gmax = plan._fused(wave, db=True)
+    ops.clamp_topdb(db, gmax, 80.0)
+    for sgm, (a, b) in enumerate(zip(bounds[:-1], bounds[1:])):
+        if b == a:
+            assert outs[0][0][sgm].abs().max().item() == 0 and outs[0][1][sgm].abs().max().item() == 0
+            continue
+        assert (outs[0][0][sgm, :128] - mel[a:b].mean(0)).abs().max().item() < 2e-5
+        assert (outs[0][1][sgm] - db[a:b].mean(0)).abs().max().item() < 2e-4     # dB values reach -100
+        # the MFCC rows' mean = the DCT of the mean dB row
+        got_mfcc = ops.linear(outs[0][1][sgm:sgm + 1].contiguous(), plan.dct)
+        assert (got_mfcc[0] - mfcc[a:b].mean(0)).abs().max().item() < 1e-3
+    assert outs[0][0][:, 128:].abs().max().item() == 0      # the columns past n_mels are not touched
+
+
 def test_lstm_vs_oracle(dev):
     ops = _ops()
     from oracle import scorer as osc
