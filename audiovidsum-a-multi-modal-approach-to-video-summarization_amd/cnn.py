@@ -570,8 +570,11 @@ class InceptionV3Runner:
     """uint8 frames [N,299,299,3] -> fp32 [N,2048]; eval-mode BatchNorm folded into the convolutions."""
 
     def __init__(self, net, dtype=torch.float32, f32_split=False):
+        """f32_split: as ResNet50Runner (True = AVS_F32_SPLIT, "f16x2" = AVS_F16X2 storage and arithmetic)."""
         self.net, self.dtype = net, dtype
-        self.f32_split = bool(f32_split) and dtype == torch.float32
+        self.h2 = f32_split == "f16x2" and dtype == torch.float32
+        self.f32_split = "f16x2" if self.h2 else (bool(f32_split) and dtype == torch.float32)
+        self.ecode = ops.dtype_code(dtype, "f16x2") if self.h2 else ops.dtype_code(dtype)   # storage format
         self.pool_after_conv = True   # branch_pool: 1x1 convolution first, average pooling on its (narrow) output
         self._key = None
         self._w = None
@@ -582,7 +585,8 @@ class InceptionV3Runner:
             s = bn.weight.float() / torch.sqrt(bn.running_var.float() + bn.eps)
             wt = conv.weight.float() * s.view(-1, 1, 1, 1)
             bias = (bn.bias.float() - bn.running_mean.float() * s).contiguous()
-            w = _W(_stem_weight(wt, stem_px, self.dtype) if stem_px else _ohwi(wt, self.dtype))
+            rows = _stem_weight(wt, stem_px, self.dtype) if stem_px else _ohwi(wt, self.dtype)
+            w = _W(ops.f16x2_pack(rows) if self.h2 else rows)
         kh, kw = conv.kernel_size
         return {"w": w, "b": bias, "kh": kh, "kw": kw, "s": conv.stride[0], "ph": conv.padding[0],
                 "pw": conv.padding[1], "cout": conv.out_channels}
@@ -622,14 +626,14 @@ class InceptionV3Runner:
         z = torch.empty((n, h, ww, c["cout"]), dtype=self.dtype, device=x.device)
         wsel, layout = c["w"].conv_operand()
         ops.conv2d(x, wsel, 1, 1, 1, (0, 0), z, None, ops.ACT_NONE, split=self.f32_split, w_layout=layout)
-        return ops.pool2d(z, "avg", 3, 1, 1, out, c["b"], ops.ACT_RELU)
+        return ops.pool2d(z, "avg", 3, 1, 1, out, c["b"], ops.ACT_RELU, code=self.ecode)
 
     def _pool(self, x, mode, k, s, p, out=None):
         n, h, ww, c = x.shape
         ho, wo = (h + 2 * p - k) // s + 1, (ww + 2 * p - k) // s + 1
         if out is None:
             out = torch.empty((n, ho, wo, c), dtype=self.dtype, device=x.device)
-        return ops.pool2d(x, mode, k, s, p, out)
+        return ops.pool2d(x, mode, k, s, p, out, code=self.ecode)
 
     def _cat_buffer(self, x, channels, stride=1):
         n, h, ww, _ = x.shape
@@ -703,7 +707,7 @@ class InceptionV3Runner:
         # (x/255 - mean)/std (extractors.py:151-153) then transform_input; one spare zero
         # pixel on the right so the stem's 4-pixel runs stay inside the row.
         affine = INCEPTION_TRANSFORM if self.net.transform_input else None
-        x0 = ops.frames_normalize(frames_u8, dt, 255.0, RESNET_MEAN, RESNET_STD, 299, 300, 0, 0, affine)
+        x0 = ops.frames_normalize(frames_u8, dt, 255.0, RESNET_MEAN, RESNET_STD, 299, 300, 0, 0, affine, code=self.ecode)
         c = w["Conv2d_1a_3x3"]
         x = torch.empty((n, 149, 149, 32), dtype=dt, device=dev)
         wsel, layout = c["w"].conv_operand()
@@ -726,4 +730,4 @@ class InceptionV3Runner:
         x = self._block_d(w, "Mixed_7a", x)
         x = self._block_e(w, "Mixed_7b", x)
         x = self._block_e(w, "Mixed_7c", x)
-        return ops.global_avgpool(x, out)
+        return ops.global_avgpool(x, out, code=self.ecode)

@@ -704,7 +704,7 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
     // in tile order (bn_fold_kernel).  Deterministic: fixed orders, no atomics.
     // Output: every wave stages 32 of its rows at a time in LDS as fp32 (row-major) and reads them back as runs of 8
     // columns: residual added and ReLU applied in fp32, then ONE split into fp16 hi | lo and two 16-byte stores.
-    static_assert(EPI == EPI_PLAIN || EPI == EPI_STATS || EPI == EPI_BNLOCAL || EPI == EPI_AFFINE,
+    static_assert(EPI == EPI_PLAIN || EPI == EPI_STATS || EPI == EPI_BNLOCAL || EPI == EPI_AFFINE || EPI == EPI_BRELU,
                   "epilogue forms built for AVS_F16X2");
     static_assert((EPI != EPI_BNLOCAL && EPI != EPI_AFFINE) || WR == 4, "the BatchNorm forms run on the 256-row tiles");
     float* const fl = reinterpret_cast<float*>(lds);
@@ -748,9 +748,19 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
     constexpr int G = WCOLS / 8;            // runs of 8 columns per staged row
     constexpr int NU = (32 * G) / 64;       // runs per lane and half
     constexpr int RSTEP = 64 / G;           // staged rows between a lane's consecutive runs
-    constexpr bool NORM = EPI == EPI_BNLOCAL || EPI == EPI_AFFINE;
+    constexpr bool NORM = EPI == EPI_BNLOCAL || EPI == EPI_AFFINE || EPI == EPI_BRELU;
     float* const wreg = fl + wave * (32 * H2_P);
-    const bool relu = NORM && p.act == AVS_ACT_RELU;
+    const bool relu = NORM && (EPI == EPI_BRELU || p.act == AVS_ACT_RELU);
+    if constexpr (EPI == EPI_BRELU) {   // bias per column + ReLU (the folded-BatchNorm convolutions of Inception-v3)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int col = n0 + wc * WCOLS + nt * 32 + lr;
+        sc0[nt] = 1.f;
+        sf0[nt] = col < p.N ? bias[col] : 0.f;
+        sc1[nt] = sc2[nt] = 1.f;
+        sf1[nt] = sf2[nt] = 0.f;
+      }
+    }
     // a lane's runs: staged row rl0 + it * RSTEP of a half, columns 8 * grp .. + 7
     const int rl0 = lane / G, grp = lane % G;
     const int col8 = n0 + wc * WCOLS + grp * 8;
@@ -1440,6 +1450,8 @@ static void igemm_dispatch_epi4(int epi, dim3 grid, hipStream_t stream, const Ig
         hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_PLAIN, PIPE, WR, FK, 2>), grid, dim3(256), 0, stream, p);
       else if (epi == EPI_STATS)
         hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE, WR, FK, 2>), grid, dim3(256), 0, stream, p);
+      else if (epi == EPI_BRELU)
+        hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BRELU, PIPE, WR, FK, 2>), grid, dim3(256), 0, stream, p);
       else if constexpr (WR == 4) {
         if (epi == EPI_BNLOCAL)
           hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BNLOCAL, PIPE, WR, FK, 2>), grid, dim3(256), 0, stream, p);
@@ -1560,8 +1572,11 @@ static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream
   AVS_REQUIRE(dtype == AVS_F32 || dtype == AVS_BF16 || dtype == AVS_F32_ACC64 || dtype == AVS_F32_SPLIT ||
                   dtype == AVS_F16X2, AVS_E_ARG, "%s: bad dtype %d", who, dtype);
   if (dtype == AVS_F16X2) {
-    const bool fixed = p.alpha == 1.0f && p.bias_mode == AVS_BIAS_NONE && (p.act == AVS_ACT_NONE || p.tile_rows || p.affine);
-    AVS_REQUIRE(fixed, AVS_E_UNSUPPORTED, "%s: AVS_F16X2 takes no bias / scaling / activation outside the BatchNorm form", who);
+    const bool fixed = p.alpha == 1.0f &&
+                       ((p.bias_mode == AVS_BIAS_NONE && (p.act == AVS_ACT_NONE || p.tile_rows || p.affine)) ||
+                        (p.bias_mode == AVS_BIAS_COL && p.act == AVS_ACT_RELU && !p.stat_part && !p.tile_rows && !p.affine));
+    AVS_REQUIRE(fixed, AVS_E_UNSUPPORTED,
+                "%s: AVS_F16X2 takes alpha = 1 and either no bias / activation (or a BatchNorm form) or bias per column + ReLU", who);
     AVS_REQUIRE(p.N % 8 == 0 && p.ldc % 8 == 0 && (p.sC % 8) == 0, AVS_E_SHAPE,
                 "%s: AVS_F16X2 needs cout and the output strides in multiples of 8 slots", who);
     AVS_REQUIRE(plan_only || ((((uintptr_t)p.x) | ((uintptr_t)p.w) | ((uintptr_t)p.y)) & 31u) == 0, AVS_E_ALIGN,

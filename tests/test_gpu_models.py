@@ -699,6 +699,12 @@ def test_inception_v3_fp32(dev):
     lit = runner.forward(big).cpu()
     assert (lit - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
     assert (lit - got).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    # the same trunk in the f16x2 mode (fp16 hi | lo storage, three fp16 MFMAs per product, bias + ReLU in the epilogue,
+    # pooling and the channel-concat slices on f16x2 tensors): fp32-class agreement, deterministic
+    rh = InceptionV3Runner(net, torch.float32, f32_split="f16x2")
+    goth = rh.forward(big).cpu()
+    assert torch.equal(goth, rh.forward(big).cpu())
+    assert (goth - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
 
 
 def test_visual_extractor_api(dev):
