@@ -521,6 +521,11 @@ def main():
                     frames, offsets, base + "bf16, both trunks of VisualFeatureExtractor.forward (Inception-v3: eval "
                     "BatchNorm folded, 299x299 bilinear resize on the GPU)")
             del ext16, pipe16
+            run_sub("resnet50+inception3", FrameScoringPipeline(extractor, scorer, use_inception=True,
+                                                                chunk_frames=min(args.chunk, 8192), frames_per_group=1),
+                    frames, offsets, base + args.dtype + ", both trunks of VisualFeatureExtractor.forward in the headline "
+                    "arithmetic (Inception-v3: eval BatchNorm folded, bias + ReLU epilogue, 299x299 bilinear resize "
+                    "on the GPU)")
             run_sub("frames_per_group_4", FrameScoringPipeline(extractor, scorer, use_inception=False,
                                                                chunk_frames=args.chunk, frames_per_group=4),
                     frames, offsets, base + args.dtype + ", frames normalised in the reference's micro-batches of 4 "
