@@ -48,10 +48,21 @@ def _as_bgr_u8(frame):
 
 
 class VisualFeatureExtractor(nn.Module):
-    def __init__(self, dtype=torch.float32, bn_mode="batch", f32_split=False):
-        """dtype: torch.float32 (parity mode, fp32 MFMA) or torch.bfloat16 (throughput mode); f32_split (with fp32):
-        fp32 activations / weights, convolution products on the bf16 matrix cores as hi*hi + hi*lo + lo*hi."""
+    ARITHMETIC = {"f32": (torch.float32, False), "f16x2": (torch.float32, "f16x2"), "f32split": (torch.float32, True),
+                  "bf16": (torch.bfloat16, False)}
+
+    def __init__(self, dtype=torch.float32, bn_mode="batch", f32_split=False, arith=None):
+        """The arithmetic of the two trunks, by name (`arith`) or by its parts (`dtype`, `f32_split`):
+          "f32"       exact fp32 MFMA (the default: the most literal parity, 10 k frames/s on one MI355X);
+          "f16x2"     values stored as fp16 hi | lo runs, three fp16 MFMAs per product: fp32-class results (meets the
+                      accuracy bars) at 23.6 k frames/s - what bench.py times;  = (torch.float32, f32_split="f16x2");
+          "f32split"  fp32 storage, operands split to bf16 hi + lo in the loop;  = (torch.float32, f32_split=True);
+          "bf16"      bf16 storage and MFMA: the throughput mode (52 k frames/s), NOT parity-grade;  = (torch.bfloat16)."""
         super().__init__()
+        if arith is not None:
+            if arith not in self.ARITHMETIC:
+                raise ValueError(f"arith must be one of {sorted(self.ARITHMETIC)}")
+            dtype, f32_split = self.ARITHMETIC[arith]
         self.resnet = resnet50_trunk()      # nn.Sequential(*resnet50.children()[:-1]), extractors.py:25,29
         self.inception = Inception3()       # fc = Identity, avgpool adaptive, extractors.py:26,32-36
         self.inception.aux_logits = False   # extractors.py:36
@@ -199,8 +210,9 @@ def sample_shot_indices(start, end):
 
 
 class AVProcessor:
-    def __init__(self, dtype=torch.float32, bn_mode="batch", strict_reference=True):
-        self.visual_extractor = VisualFeatureExtractor(dtype, bn_mode)
+    def __init__(self, dtype=torch.float32, bn_mode="batch", strict_reference=True, arith=None):
+        """arith: the visual trunks' arithmetic by name (VisualFeatureExtractor: "f32" default, "f16x2", ...)."""
+        self.visual_extractor = VisualFeatureExtractor(dtype, bn_mode, arith=arith)
         self.audio_extractor = AudioFeatureExtractor(strict_reference=strict_reference)
         self.sr = self.audio_extractor.sr
 

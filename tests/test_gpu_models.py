@@ -719,6 +719,13 @@ def test_visual_extractor_api(dev):
     assert got.dtype == np.float32 and got.shape == (4096,)
     assert np.abs(got - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
     assert np.array_equal(ext([]), np.zeros(4096, np.float32))  # extractors.py:44-45
+    # the same call in the f16x2 arithmetic (selected by name), both trunks: fp32-class agreement
+    exth = VisualFeatureExtractor(arith="f16x2")
+    exth.load_state_dict(ext.state_dict())
+    goth = exth.to(dev)(frames)
+    assert goth.dtype == np.float32 and np.abs(goth - ref).max() < 5e-4 * max(1.0, np.abs(ref).max())
+    with pytest.raises(ValueError):
+        VisualFeatureExtractor(arith="fp8")
     p = ext._preprocess_frame(frames[0])
     assert p.shape == (1, 3, 224, 224) and torch.equal(p, ocnn.preprocess_frame(frames[0]))
     pi = ext._preprocess_inception(frames[0])
