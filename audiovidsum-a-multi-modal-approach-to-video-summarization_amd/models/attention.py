@@ -37,11 +37,10 @@ class MultiHeadSelfAttention(nn.Module):
         self.num_heads = num_heads
         self.dim_head = embed_dim // num_heads
         # "auto" / True / "f32" / False.  The fused kernels (head dim 64, 128 or 256) never materialise the [T,T] scores:
-        # True = the split-precision form on the fp16 matrix cores (avs_mhsa_flash_f16x2), "f32" = the exact fp32 MFMA
-        # form (avs_mhsa_flash_f32), "auto" = whichever of the two is faster at this T (measured on MI355X, E = 1024,
-        # H = 4, whole forward: T = 300: 0.40 / 0.48 ms, 1800: 0.77 / 1.11 ms, 5000: 2.98 / 2.69 ms).  False = the
-        # batched-GEMM path, which DOES materialise [H,T,T] (400 MB at T = 5000) and is still the fastest of the three
-        # (0.38 / 0.61 / 2.29 ms): kept as an explicit option, never chosen by "auto" (SURVEY 3.5).
+        # "auto" / True = the split-precision form on the fp16 matrix cores (avs_mhsa_flash_f16x2, 16-query tiles), "f32" =
+        # the exact fp32 MFMA form (avs_mhsa_flash_f32), False = the batched-GEMM path, which DOES materialise [H,T,T]
+        # (400 MB at T = 5000).  Measured on MI355X, E = 1024, H = 4, whole forward, T = 300 / 1800 / 5000: split fused
+        # 0.375 / 0.63 / 1.40 ms, fp32 fused 0.49 / 1.11 / 2.69 ms, batched GEMMs 0.376 / 0.60 / 2.30 ms.
         self.use_flash = "auto"
 
     def forward(self, x):
@@ -64,8 +63,7 @@ class MultiHeadSelfAttention(nn.Module):
         if d in (64, 128, 256) and flash:
             # fused core: scores never materialised
             v = ops.linear(x2, self.value.weight, self.value.bias)
-            split = (t <= 3000) if self.use_flash == "auto" else self.use_flash != "f32"
-            ctx = ops.mhsa_flash(q, k, v, b, t, h, split=split)
+            ctx = ops.mhsa_flash(q, k, v, b, t, h, split=self.use_flash != "f32")
             return ops.linear(ctx, self.out.weight, self.out.bias).view(b, t, e)
         tp = (t + 3) // 4 * 4
         vt = torch.zeros((b, e, tp), dtype=torch.float32, device=dev)

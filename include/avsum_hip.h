@@ -459,9 +459,10 @@ int avs_mhsa_flash_f32(const float* d_q, const float* d_k, const float* d_v, int
                        int heads, int head_dim, float* d_ctx, int64_t ldo, avs_stream_t stream);
 /* The same fused core with AVS_F16X2 operands (d_q / d_k / d_v: the projections after avs_f16x2_pack_f32, row stride
  * ld slots; d_ctx fp32): every product hi*hi + lo*hi + hi*lo on v_mfma_f32_32x32x16_f16 (2^-21 relative, fp32
- * accumulation; the probabilities are split in registers).  One wave per SIMD (128 accumulator + 128 Q fragment
- * registers per lane at head dim 256): latency-bound - faster than the fp32 form up to T ~ 3000 (0.77 vs 1.11 ms whole
- * forward at T = 1800, E = 1024, H = 4), slower beyond (2.98 vs 2.69 ms at T = 5000) (models/attention.py:21-24). */
+ * accumulation; the probabilities are split in registers), on 16-query tiles (v_mfma_f32_16x16x32_f16: 64
+ * accumulator + 64 Q-fragment registers per lane at head dim 256, two waves per SIMD).  Whole forward at E = 1024,
+ * H = 4, T = 5000: 1.40 ms against 2.69 ms for the fp32 form and 2.30 ms for the batched-GEMM path that materialises
+ * the 400 MB of scores (models/attention.py:21-24).                                                               */
 int avs_mhsa_flash_f16x2(const void* d_q, const void* d_k, const void* d_v, int64_t ld, int b, int t, int heads,
                          int head_dim, float* d_ctx, int64_t ldo, avs_stream_t stream);
 
