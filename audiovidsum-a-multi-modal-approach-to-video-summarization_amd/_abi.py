@@ -26,7 +26,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "avsum_hip.h")
 
 AVS_F32, AVS_BF16, AVS_F32_ACC64, AVS_F32_SPLIT, AVS_F16X2 = 0, 1, 2, 3, 4
 AVS_W_ROWS, AVS_W_KSTEP32 = 0, 1
-TILE_AUTO, TILE_128, TILE_256, STAGING_GENERIC = 0, 1, 2, 4      # avs_conv_desc.variant
+TILE_AUTO, TILE_128, TILE_256, TILE_224, STAGING_GENERIC = 0, 1, 2, 3, 4      # avs_conv_desc.variant
 LSTM_AUTO, LSTM_STREAM, LSTM_RESIDENT_20_8, LSTM_RESIDENT_16_8 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU = 0, 1
 BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2

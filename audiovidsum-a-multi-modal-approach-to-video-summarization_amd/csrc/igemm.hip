@@ -31,55 +31,10 @@
 // With SPATIAL = false (1x1 kernels without padding, linears, GEMMs) the
 // per-tap bounds tests compile away.
 #include "avs_internal.h"
+#include "igemm_params.h"
 #include <type_traits>
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
 __device__ __attribute__((aligned(16))) unsigned int avs_zero16[4];
-
-struct IgemmParams {
-  const char* x;
-  const char* w;
-  char* y;
-  const float* bias;
-  int M, N, K;
-  int HoWo, Wo, H, W, cin, KW;
-  int sh, sw, ph, pw;
-  long long x_img_stride, x_row_stride, x_px_stride;
-  long long ldb, ldc;
-  long long sA, sB, sC, sBias;
-  float alpha;
-  int act, bias_mode;
-  int tiles_n;
-  // EPI_STATS (fused BatchNorm batch statistics): every row tile writes, for each group it overlaps, its column sums
-  // and sums of squares of the fp32 accumulators to its OWN slot stat_part[tile][slot][sum | sumsq][N] (plain stores,
-  // no atomics); bn_fold_kernel adds a group's slots in tile order, so the statistics are reproducible bit for bit
-  float* stat_part;
-  int stat_slots;    // slots per row tile = groups a tile can overlap
-  int rows_per_group;
-  long long lin_stride;  // >= 0: output row m reads input row m at x + m*lin_stride (no (n,ho,wo) decode needed)
-  // EPI_BNLOCAL (whole BatchNorm in the epilogue): BatchNorm parameters, optional residual
-  const float* gamma;
-  const float* beta;
-  float eps;
-  const char* residual;
-  long long ldr;
-  int split;         // fp32 operands only: 1 = products on the bf16 matrix cores as hi*hi + hi*lo + lo*hi (AVS_F32_SPLIT)
-  int tall;          // 1: the 256-row tile variants (WR = 4)
-  int w_kstep;       // 1: w is stored reduction-step major (AVS_W_KSTEP32), [K / S][N][S], S = 32 bf16 / 16 fp32: the 64 bytes a B row needs
-                     //    in one step sit next to the neighbouring rows' (whole cache lines per DMA instruction)
-  int tile_rows;     // EPI_BNLOCAL: rows of the tile that are used (whole groups), also the pitch between tiles
-  // EPI_AFFINE (AVS_F16X2): y = act((conv * scale[g] + shift[g]) + residual (* res_scale[g] + res_shift[g])), the folded
-  // affines given per group of rows_per_group rows: gamma / beta point at scale / shift [groups, N]
-  int affine;
-  const float* res_scale;
-  const float* res_shift;
-  int variant;       // avs_conv_desc.variant: AVS_TILE_128 / AVS_TILE_256 (bits 0-1), AVS_STAGING_GENERIC (bit 2)
-#ifdef AVS_STUDY
-  int debug;  // ablation switches of the kernel-study build (tools/): 1 = skip output stores, 2 = skip A/B loads, ...
-#endif
-};
 
 // Ablation switches exist in the study build only (make study -> libavsum_hip_study.so); the shipped kernels carry none.
 #ifdef AVS_STUDY
@@ -133,29 +88,11 @@ __device__ __forceinline__ void avs_split_bf16(const float4& p0, const float4& p
 //   EPI_AFFINE AVS_F16X2, 1x1 convolutions on the 256-row tiles: a folded BatchNorm affine GIVEN per group of rows (computed
 //              beforehand from the input's Gram matrix, avs_bn_gram_affine_f16x2) + residual + ReLU: the one streaming
 //              pass of the expanding 1x1 layers whose groups are too large for a tile
-enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_ANY = 2, EPI_BRELU = 3, EPI_BNLOCAL = 5, EPI_AFFINE = 6 };
-constexpr int BNLOCAL_MAX_GROUPS = 6;  // groups per 256-row tile (rows_per_group >= 43)
-constexpr int STATS_MIN_GROUP_ROWS = 64;  // EPI_STATS: a wave's 64 rows then overlap at most two groups
 
 // PIPE: three operand buffers, the DMA of step s+2 is issued in step s; fragment reads are inline-asm
 // ds_read_b128 and the waits are hand-counted (s_waitcnt vmcnt(N) + raw s_barrier), because hipcc orders every
 // LDS read it can see behind ALL outstanding LDS-DMA (vmcnt(0)), which caps a plain-HIP loop at one step of
 // prefetch.  Order per step: wait for this step's DMA -> barrier -> issue step s+2 -> read fragments -> MFMA.
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-// Passes a fragment THROUGH an empty asm: every later use of it depends on this statement, so it cannot be scheduled
-// ahead of the (volatile) wait that precedes the statement.
-__device__ __forceinline__ void avs_pin(uint4& v) {
-  u32x4 r = __builtin_bit_cast(u32x4, v);
-  asm volatile("" : "+v"(r));
-  v = __builtin_bit_cast(uint4, r);
-}
-
-__device__ __forceinline__ uint4 avs_lds_read_b128(unsigned byte_addr) {
-  uint4 v;
-  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(byte_addr));
-  return v;
-}
-
 // WR: rows of waves.  2 = the 128 x BN tile (2 x 2 waves of 64 x BN/2); 4 = a 256 x BN tile (4 x 1 waves of 64 x BN):
 // twice the matrix work per barrier and 0.75 (BN = 128) instead of 1 fragment read per MFMA, for layers with many
 // rows whose cost is the loop itself (the N = 64 layers run 4 MFMAs per wave between barriers at WR = 2).
@@ -1612,6 +1549,8 @@ static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream
                      (long long)p.K * es > 128 && batch == 1;
     const long long tall_tiles = ((long long)p.M + 255) / 256 * p.tiles_n;
     const int tile_mode = p.variant & 3;   // AVS_TILE_AUTO: by rule; AVS_TILE_128: never; AVS_TILE_256: wherever it exists
+    AVS_REQUIRE(tile_mode != AVS_TILE_224 || p.tile_rows, AVS_E_UNSUPPORTED,
+                "%s: AVS_TILE_224 is a tile of the tile-local BatchNorm form (avs_conv2d_nhwc_bnlocal)", who);
     if (can && (tile_mode == AVS_TILE_256 || (tile_mode == AVS_TILE_AUTO && tall_tiles >= g_tall_min_tiles &&
                                               (narrow || (long long)p.K * es >= g_tall_min_k_bytes))))
       p.tall = 1;
@@ -1635,6 +1574,17 @@ static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream
       p.lin_stride = p.x_px_stride;
   }
   dim3 grid((unsigned)total, 1, (unsigned)batch);
+  if (p.tile_rows && dtype == AVS_F16X2) {
+    // a group of 193 .. 224 rows: the tile that fits it (local224.hip), unless the caller asks for the 256-row form
+    const bool fits = igemm_h2_local224_ok(p, dtype);
+    AVS_REQUIRE(fits || (p.variant & 3) != AVS_TILE_224, AVS_E_UNSUPPORTED,
+                "%s: AVS_TILE_224 takes AVS_F16X2, groups of 193..224 rows, cout in multiples of 128, cin in multiples of 16", who);
+    if (fits) {
+      igemm_h2_local224_launch(p, spatial, grid, stream);
+      AVS_CHECK_LAUNCH(who);
+      return AVS_OK;
+    }
+  }
   if (dtype == AVS_BF16) {
     if (narrow)
       igemm_dispatch<2, 64, false>(spatial, grid, stream, p);
@@ -1688,7 +1638,7 @@ static int conv_fill_params(const avs_conv_desc* d, const void* d_x, const void*
   AVS_REQUIRE(d->w_layout == AVS_W_ROWS || d->w_layout == AVS_W_KSTEP32, AVS_E_ARG, "%s: bad w_layout %d", who,
               d->w_layout);
   p.w_kstep = d->w_layout == AVS_W_KSTEP32 ? 1 : 0;
-  AVS_REQUIRE((d->variant & ~7) == 0 && (d->variant & 3) != 3, AVS_E_ARG, "%s: bad variant %d", who, d->variant);
+  AVS_REQUIRE((d->variant & ~7) == 0, AVS_E_ARG, "%s: bad variant %d", who, d->variant);
   p.variant = d->variant;
   AVS_REQUIRE(!p.w_kstep || (d->dtype != AVS_F32_ACC64 && p.K % (d->dtype == AVS_BF16 ? 32 : 16) == 0), AVS_E_UNSUPPORTED,
               "%s: the reduction-step-major weight layout needs a reduction that is a multiple of a 64-byte step (K = %d)",

@@ -112,11 +112,14 @@ typedef struct {
   int variant;              /* 0 = the library's own choice.  Per-call overrides of the tile / staging variant (what the
                              * tests and the kernel-study tools force; there is NO process-global tuning state):
                              * AVS_TILE_128 / AVS_TILE_256 (bits 0-1): 128-row or, wherever the variant exists, 256-row
-                             * output tiles; AVS_STAGING_GENERIC (bit 2): the general per-lane gather staging even where
+                             * output tiles; AVS_TILE_224 (avs_conv2d_nhwc_bnlocal, AVS_F16X2 only): the 224-row tile
+                             * whose waves split the columns, for groups of 193..224 rows - what AVS_TILE_AUTO picks
+                             * for such groups, AVS_TILE_256 keeps them on the 256-row tile;
+                             * AVS_STAGING_GENERIC (bit 2): the general per-lane gather staging even where
                              * the scalar tap walk applies.  Results do not depend on it beyond fp32 summation order. */
 } avs_conv_desc;
 enum { AVS_W_ROWS = 0, AVS_W_KSTEP32 = 1 };
-enum { AVS_TILE_AUTO = 0, AVS_TILE_128 = 1, AVS_TILE_256 = 2, AVS_STAGING_GENERIC = 4 };
+enum { AVS_TILE_AUTO = 0, AVS_TILE_128 = 1, AVS_TILE_256 = 2, AVS_TILE_224 = 3, AVS_STAGING_GENERIC = 4 };
 
 int avs_conv2d_nhwc(const avs_conv_desc* desc, const void* d_x, const void* d_w,
                     const float* d_bias, void* d_y, avs_stream_t stream);

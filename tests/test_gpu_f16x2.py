@@ -221,6 +221,9 @@ _LOCAL_CASES = [
     (8, 28, 256, 512, 1, 2, 1, False, False, 0.3),   # strided downsample to 14x14, no ReLU
     (10, 7, 512, 128, 1, 1, 1, True, True, 40.0),    # mean >> spread
     (12, 14, 64, 64, 3, 1, 1, False, True, 0.3),     # 43-row..: 196-row groups on the 64-wide tile, spatial
+    (5, 28, 256, 256, 3, 2, 1, False, True, 0.3),    # 3x3 / 2 down to 14x14: 196-row groups, strided taps with padding
+    (6, 10, 128, 128, 1, 1, 2, True, True, 0.3),     # two-frame groups of 200 rows
+    (6, 10, 64, 128, 3, 1, 2, True, False, 40.0),    # ... 3x3, mean >> spread, no ReLU
 ]
 
 
@@ -245,18 +248,34 @@ def test_conv_bnlocal_f16x2(dev, cfg):
     code = ops.dtype_code(torch.float32, "f16x2")
     assert ops.conv_bnlocal_tile_rows(code, *geom, *xs, wp.shape[1], cout, rpg) == 256 // rpg * rpg
     xd, wd = xp.to(dev), wp.to(dev)
-    outs = []
-    for _ in range(2):
-        y = torch.empty((frames, ho, ho, cout), device=dev)
-        ops.conv2d_raw(code, *geom, xd, *xs, wd, wd.stride(0), y, cout, act=ops.ACT_RELU if relu else ops.ACT_NONE,
-                       bnlocal=(rpg, gamma.to(dev), beta.to(dev), 1e-5, resp.to(dev) if with_res else None))
-        outs.append(y)
-    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
-    got = ops.f16x2_unpack(outs[0]).cpu().double().view(-1, cout)
     # normalised values: |scale| up to gamma / sqrt(var) amplifies the convolution's 1e-6 by the same factor
     amp = max(1.0, (1.0 / torch.sqrt(raw.reshape(-1, rpg, cout).var(1, unbiased=False) + 1e-5)).max().item() *
               raw.abs().max().item())
-    assert (got - ref).abs().max().item() <= TOL * amp
+    # groups of 193..224 rows have a tile of their own (224 rows, the waves split the columns: AVS_TILE_224, what the
+    # library picks for them); AVS_TILE_256 keeps them on the general 256-row tile.  Same convolution, another summation
+    # order of the statistics: both are held to the float64 bar
+    from avsum_amd import _abi
+    fits = 192 < rpg <= 224 and cout % 128 == 0
+    for variant in ((_abi.TILE_AUTO, _abi.TILE_224, _abi.TILE_256) if fits else (_abi.TILE_AUTO,)):
+        outs = []
+        for _ in range(2):
+            y = torch.empty((frames, ho, ho, cout), device=dev)
+            ops.conv2d_raw(code, *geom, xd, *xs, wd, wd.stride(0), y, cout, act=ops.ACT_RELU if relu else ops.ACT_NONE,
+                           bnlocal=(rpg, gamma.to(dev), beta.to(dev), 1e-5, resp.to(dev) if with_res else None),
+                           variant=variant)
+            outs.append(y)
+        assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
+        got = ops.f16x2_unpack(outs[0]).cpu().double().view(-1, cout)
+        assert (got - ref).abs().max().item() <= TOL * amp, variant
+        if variant == _abi.TILE_AUTO:
+            auto = outs[0]
+        elif variant == _abi.TILE_224:
+            assert torch.equal(auto.view(torch.int32), outs[0].view(torch.int32))   # the library's own choice
+    if not fits:
+        y = torch.empty((frames, ho, ho, cout), device=dev)
+        with pytest.raises(RuntimeError, match="AVS_TILE_224"):
+            ops.conv2d_raw(code, *geom, xd, *xs, wd, wd.stride(0), y, cout, act=ops.ACT_NONE,
+                           bnlocal=(rpg, gamma.to(dev), beta.to(dev), 1e-5, None), variant=_abi.TILE_224)
 
 
 def test_elementwise_f16x2(dev):

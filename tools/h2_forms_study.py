@@ -23,6 +23,8 @@ shapes = [  # name, hw, cin, cout, k, stride
     ("l3.conv1 1x1 1024->256", 14, 1024, 256, 1, 1),
     ("l3.conv2 3x3 256->256", 14, 256, 256, 3, 1),
     ("l3.conv3 1x1 256->1024", 14, 256, 1024, 1, 1),
+    ("l3.0.conv2 3x3/2 256->256", 28, 256, 256, 3, 2),
+    ("l3.0.ds 1x1/2 512->1024", 28, 512, 1024, 1, 2),
     ("l4.conv1 1x1 2048->512", 7, 2048, 512, 1, 1),
     ("l4.conv2 3x3 512->512", 7, 512, 512, 3, 1),
     ("l4.conv3 1x1 512->2048", 7, 512, 2048, 1, 1),
@@ -68,6 +70,13 @@ for name, hw, cin, cout, k, s in shapes:
                                                            bnlocal=(rpg, gamma, beta, 1e-5, None), w_layout=1)))
         line += show("local+res", timed(lambda: ops.conv2d_raw(code, *geom, x, *xs, w, wrs, y, cout, act=ops.ACT_RELU,
                                                                bnlocal=(rpg, gamma, beta, 1e-5, res), w_layout=1)))
+        if 192 < rpg <= 224 and cout % 128 == 0:   # the library's choice above is the 224-row tile: the 256-row one beside it
+            line += show("local/256", timed(lambda: ops.conv2d_raw(code, *geom, x, *xs, w, wrs, y, cout, act=ops.ACT_RELU,
+                                                                   bnlocal=(rpg, gamma, beta, 1e-5, None), w_layout=1,
+                                                                   variant=2)))
+            line += show("local+res/256", timed(lambda: ops.conv2d_raw(code, *geom, x, *xs, w, wrs, y, cout, act=ops.ACT_RELU,
+                                                                       bnlocal=(rpg, gamma, beta, 1e-5, res), w_layout=1,
+                                                                       variant=2)))
     if k == 1 and cin * 4 > 128:
         groups = n
         sc, sh = torch.rand(groups, cout, device=dev) + 0.5, torch.randn(groups, cout, device=dev)
