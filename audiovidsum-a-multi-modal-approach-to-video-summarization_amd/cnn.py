@@ -402,6 +402,25 @@ class ResNet50Runner:
                 ops.conv1x1_affine(x2d, blk["cd"].rows, gmax, sc[:, c1n:].contiguous(), sh[:, c1n:].contiguous(), idn, None,
                                    False, x_aff)
                 x_aff = None
+            elif (bi == 0 and self.h2 and "cat0" in w and self.bn_mode == "batch" and uniform and not s1 and not sd
+                  and self._gram_h2_ok(cin, planes * 4, 1, 1, gsz * hcur * hcur)):
+                # AVS_F16X2, first block: conv1 (64 -> 64) and the downsample (64 -> 256) read the same finished input, so
+                # ONE Gram matrix gives both BatchNorms' affines and each layer is one streaming pass (conv1 would
+                # otherwise take convolution + statistics + an apply pass over its output)
+                wcat, gcat, bcat, eps, c1n = w["cat0"]
+                gmax = gsz * hcur * hcur
+                sc, sf = ops.bn_gram_affine_h2(x.view(-1, cin), wcat, gmax, gcat, bcat, eps)
+                geom, xs, _ = self._nhwc_geom(n, hcur, cin, 1, 1, 0, planes)
+                t1 = torch.empty((n, hcur, hcur, planes), dtype=dt, device=dev)
+                wsel, layout = blk["c1"].conv_operand()
+                ops.conv2d_affine(self.code, n, hcur, hcur, cin, 1, 1, hcur, hcur, planes, x, *xs, wsel, wsel.stride(0), t1,
+                                  planes, gmax, sc[:, :c1n].contiguous(), sf[:, :c1n].contiguous(), None, True, None,
+                                  w_layout=layout)
+                idn = torch.empty((n * hcur * hcur, planes * 4), dtype=dt, device=dev)
+                wsel, layout = blk["cd"].conv_operand()
+                ops.conv2d_affine(self.code, n, hcur, hcur, cin, 1, 1, hcur, hcur, planes * 4, x, *xs, wsel, wsel.stride(0),
+                                  idn, planes * 4, gmax, sc[:, c1n:].contiguous(), sf[:, c1n:].contiguous(), None, False,
+                                  None, w_layout=layout)
             else:
                 geom, xs, _ = self._nhwc_geom(n, hcur, cin, 1, 1, 0, planes)
                 t1 = self._conv_bn(geom, xs, x, blk["c1"], blk["b1"], groups, local=s1)

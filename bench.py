@@ -306,7 +306,7 @@ def config2_leg(extractor, scorer, dev, steps, videos):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3],
                     help="BASELINE config of the headline: 1 = SumMe-shape batch per rank; 2 = the TVSum-shape "
