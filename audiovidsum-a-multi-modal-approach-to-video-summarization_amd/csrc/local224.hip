@@ -179,6 +179,35 @@ __global__ __launch_bounds__(256, 2) void igemm_h2_local224_kernel(IgemmParams p
     fb_off[hl] = (unsigned)((L_ROWS + brow) * L_CPRR + (chunk ^ ((brow >> 2) & (L_CPRR - 1)))) * 16u;
   }
 
+  // The residual rows of the first three blocks are fetched BEFORE the reduction (48 registers through the main loop),
+  // the next three when it ends: no memory latency is left in front of the first stores, and the rest land under them.
+  const int col = n0 + wave * 32 + lr;
+  const float inv_n = 1.f / (float)p.rows_per_group;
+  const int lim = used - 4 * lh;   // block-local row offsets below this one exist
+  // the residual runs of a block: staged row rl0 (+ 16) of the block, columns 8 * grp .. + 7 of the wave's 32
+  const int rl0 = lane >> 2, grp = lane & 3;
+  const int col8 = n0 + wave * 32 + grp * 8;
+  constexpr int DEPTH = 6;   // blocks of residual rows in flight
+  uint4 rhi[DEPTH][2], rlo[DEPTH][2];
+  auto res_fetch = [&](auto blk) {
+    constexpr int mt = decltype(blk)::value;
+    const long long row0 = (long long)m0 + mt * 32 + rl0;
+    const char* base = p.residual + (row0 * p.ldr + col8) * 4;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      // rows that do not exist read the residual's first run (never used): no divergent branch around the loads
+      const bool ok = mt * 32 + rl0 + 16 * it < used;
+      const uint4* rp = reinterpret_cast<const uint4*>(ok ? base + (long long)it * 16 * p.ldr * 4 : p.residual);
+      rhi[mt % DEPTH][it] = rp[0];
+      rlo[mt % DEPTH][it] = rp[1];
+    }
+  };
+  if (p.residual) {
+    res_fetch(std::integral_constant<int, 0>{});
+    res_fetch(std::integral_constant<int, 1>{});
+    res_fetch(std::integral_constant<int, 2>{});
+  }
+
   const int steps = p.K / L_STEP;
   stage(0);
   if (steps > 1) stage(1);
@@ -231,31 +260,10 @@ __global__ __launch_bounds__(256, 2) void igemm_h2_local224_kernel(IgemmParams p
   // ---- epilogue: the group's BatchNorm from this wave's own registers, then 32 rows at a time through LDS ----
   // A lane holds column lr of its wave's 32, rows (e & 3) + 8 * (e >> 2) + 4 * lh of every block; rows >= used are
   // exact zeros (their operand rows were never fetched).
-  const int col = n0 + wave * 32 + lr;
-  const float inv_n = 1.f / (float)p.rows_per_group;
-  const int lim = used - 4 * lh;   // block-local row offsets below this one exist
-  // the residual runs of a block: staged row rl0 (+ 16) of the block, columns 8 * grp .. + 7 of the wave's 32
-  const int rl0 = lane >> 2, grp = lane & 3;
-  const int col8 = n0 + wave * 32 + grp * 8;
-  constexpr int DEPTH = 3;   // blocks of residual rows in flight
-  uint4 rhi[DEPTH][2], rlo[DEPTH][2];
-  auto res_fetch = [&](auto blk) {
-    constexpr int mt = decltype(blk)::value;
-    const long long row0 = (long long)m0 + mt * 32 + rl0;
-    const char* base = p.residual + (row0 * p.ldr + col8) * 4;
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      // rows that do not exist read the residual's first run (never used): no divergent branch around the loads
-      const bool ok = mt * 32 + rl0 + 16 * it < used;
-      const uint4* rp = reinterpret_cast<const uint4*>(ok ? base + (long long)it * 16 * p.ldr * 4 : p.residual);
-      rhi[mt % DEPTH][it] = rp[0];
-      rlo[mt % DEPTH][it] = rp[1];
-    }
-  };
   if (p.residual) {
-    res_fetch(std::integral_constant<int, 0>{});
-    res_fetch(std::integral_constant<int, 1>{});
-    res_fetch(std::integral_constant<int, 2>{});
+    res_fetch(std::integral_constant<int, 3>{});
+    res_fetch(std::integral_constant<int, 4>{});
+    res_fetch(std::integral_constant<int, 5>{});
   }
   float s1 = 0.f;
 #pragma unroll
