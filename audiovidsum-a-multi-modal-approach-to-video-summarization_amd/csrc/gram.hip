@@ -8,10 +8,10 @@
 // rows - far too large for a tile) this turns "convolution + statistics, then an apply pass over the 4K-wide output"
 // into ONE streaming convolution pass with the affine in its epilogue (avs_conv2d_nhwc_affine): the wide output is
 // written once and never re-read.  One workgroup per group:
-//   1. rows come in as runs of 8 channels (32 bytes: fp16 hi | lo), a lane per ROW so that the transposed 2-byte LDS
-//      writes of a wave are contiguous; a = relu(x * in_scale + in_shift) in fp32 (XF), per-channel sums and sums of
-//      squares on the VALU, a split into fp16 hi | lo ONCE: stored back to HBM (the finished activation) and into
-//      the LDS tile [channel][64 rows] (the reduction index of a^T a is the row);  a^T a on the matrix cores as
+//   1. rows come in as runs of 8 channels (32 bytes: fp16 hi | lo), consecutive lanes taking consecutive runs of a row
+//      (whole cache lines per load / store instruction); a = relu(x * in_scale + in_shift) in fp32 (XF), a split into
+//      fp16 hi | lo ONCE: stored back to HBM (the finished activation) and, transposed, into the LDS tile
+//      [channel][64 rows] (the reduction index of a^T a is the row);  a^T a on the matrix cores as
 //      hi*hi + hi*lo + lo*hi (v_mfma_f32_32x32x16_f16, fp32 accumulators over the whole group);
 //   2. C in fp32 from the accumulators, scaled by a power of two so that its largest entry is <= 1, split into
 //      fp16 hi | lo images in LDS;
@@ -44,9 +44,10 @@ __global__ __launch_bounds__(256, 2) void bn_gram_affine_h2_kernel(GramH2Params 
   static_assert(K == 64 || K == 128, "input widths of the layer-1 / layer-2 expanding convolutions");
   constexpr int CPR = K / 8;              // runs of 8 channels per row
   constexpr int TR = 64;                  // rows per LDS tile = lanes of a wave
-  constexpr int NP = CPR / 4;             // runs per thread and tile: wave w takes runs w, w + 4, ...
+  constexpr int NP = CPR / 4;             // runs per thread and tile
+  constexpr int RPP = 256 / CPR;          // rows per pass of the 256 threads: thread t takes run t % CPR of row t / CPR
   constexpr int PT = TR * 2 + 16;         // bytes per channel row of a transposed tile plane (16-byte padding)
-  constexpr int PLANE = K * PT;           // one plane (hi or lo) of a tile
+  constexpr int PLANE = K * PT + CPR * 16;   // one plane (hi or lo) of a tile; the rows of run c are skewed by 16 c bytes
   constexpr int TILE_BYTES = 2 * PLANE;
   constexpr int KB = K / 32;              // 32-channel blocks per side
   constexpr int NBLK = (KB * KB) / 4;     // Gram blocks per wave: 1 (K = 64) or 4 (K = 128: one block row)
@@ -65,9 +66,8 @@ __global__ __launch_bounds__(256, 2) void bn_gram_affine_h2_kernel(GramH2Params 
   const int R = p.rows_per_group;
   const char* __restrict__ xg = p.x + g * R * p.lin_stride * 4;
 
-  // this thread's channel runs: c_i = wave + 4 i.  (Channel sums and sums of squares are NOT kept per thread - 16 NP
-  // registers each: the sums come from one more pair of MFMAs against a ones operand, the squares are the diagonal of
-  // a^T a.)
+  // (Channel sums and sums of squares are NOT kept per thread: the sums come from one more pair of MFMAs against a
+  // ones operand, the squares are the diagonal of a^T a.)
   if constexpr (XF) {
     for (int i = t; i < K; i += 256) {
       xaf[0][i] = p.in_scale[g * K + i];
@@ -76,13 +76,18 @@ __global__ __launch_bounds__(256, 2) void bn_gram_affine_h2_kernel(GramH2Params 
     __syncthreads();
   }
 
+  // Thread t takes run c = t % CPR (8 channels) of rows t / CPR + RPP i of a tile: a wave's loads and stores cover whole
+  // rows (full cache lines; with a lane per ROW every 128-byte line was requested by eight instructions, 16 bytes at a
+  // time).  The transposed 2-byte LDS writes of a wave then go to CPR different channel rows at once: the rows of run c
+  // are skewed by 16 c bytes, which spreads them over the banks.
+  const int c_run = t % CPR, r_loc = t / CPR;
   uint4 rh[NP], rl[NP];
   auto gload = [&](int tile) {
-    const int row = tile * TR + lane;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
+      const int row = tile * TR + r_loc + RPP * i;
       if (row < R) {
-        const uint4* src = reinterpret_cast<const uint4*>(xg + ((long long)row * p.lin_stride + 8 * (wave + 4 * i)) * 4);
+        const uint4* src = reinterpret_cast<const uint4*>(xg + ((long long)row * p.lin_stride + 8 * c_run) * 4);
         rh[i] = src[0];
         rl[i] = src[1];
       } else {
@@ -91,48 +96,52 @@ __global__ __launch_bounds__(256, 2) void bn_gram_affine_h2_kernel(GramH2Params 
       }
     }
   };
+  float xs[XF ? 8 : 1], xh[XF ? 8 : 1];   // this thread's 8 channels of the input affine
+  if constexpr (XF) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      xs[j] = xaf[0][8 * c_run + j];
+      xh[j] = xaf[1][8 * c_run + j];
+    }
+  }
   auto xform_store = [&](int buf, int tile) {
-    const int row = tile * TR + lane;
-    char* hiT = lds + buf * TILE_BYTES;
+    char* hiT = lds + buf * TILE_BYTES + (8 * c_run) * PT + c_run * 16;
     char* loT = hiT + PLANE;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
+      const int rt = r_loc + RPP * i;         // row inside the tile
+      const int row = tile * TR + rt;
       uint4 hi = rh[i], lo = rl[i];
       if (row < R) {
-        float v[8];
-        avs_f16x2_join8(hi, lo, v);
         if constexpr (XF) {
-          const int c8 = 8 * (wave + 4 * i);
-          const float4 s0 = *reinterpret_cast<const float4*>(&xaf[0][c8]), s1 = *reinterpret_cast<const float4*>(&xaf[0][c8 + 4]);
-          const float4 h0 = *reinterpret_cast<const float4*>(&xaf[1][c8]), h1 = *reinterpret_cast<const float4*>(&xaf[1][c8 + 4]);
-          const float xs[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-          const float xh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+          float v[8];
+          avs_f16x2_join8(hi, lo, v);
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = fmaxf(fmaf(v[j], xs[j], xh[j]), 0.f);
           avs_f16x2_split8(v, hi, lo);   // the statistics below are those of the STORED activation (hi + lo)
           if (p.a_out != nullptr) {
-            uint4* dst = reinterpret_cast<uint4*>(p.a_out + (((g * R + row) * p.lda) + 8 * (wave + 4 * i)) * 4);
+            uint4* dst = reinterpret_cast<uint4*>(p.a_out + (((g * R + row) * p.lda) + 8 * c_run) * 4);
             dst[0] = hi;
             dst[1] = lo;
           }
         }
       }
-      // transposed: channel 8 c + j, row `lane` (rows past the group are zeros)
+      // transposed: channel 8 c + j, row rt (rows past the group are zeros)
       const unsigned hw[4] = {hi.x, hi.y, hi.z, hi.w}, lw[4] = {lo.x, lo.y, lo.z, lo.w};
-      const int cbase = 8 * (wave + 4 * i);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        *reinterpret_cast<unsigned short*>(hiT + (cbase + 2 * j) * PT + lane * 2) = (unsigned short)hw[j];
-        *reinterpret_cast<unsigned short*>(hiT + (cbase + 2 * j + 1) * PT + lane * 2) = (unsigned short)(hw[j] >> 16);
-        *reinterpret_cast<unsigned short*>(loT + (cbase + 2 * j) * PT + lane * 2) = (unsigned short)lw[j];
-        *reinterpret_cast<unsigned short*>(loT + (cbase + 2 * j + 1) * PT + lane * 2) = (unsigned short)(lw[j] >> 16);
+        *reinterpret_cast<unsigned short*>(hiT + (2 * j) * PT + rt * 2) = (unsigned short)hw[j];
+        *reinterpret_cast<unsigned short*>(hiT + (2 * j + 1) * PT + rt * 2) = (unsigned short)(hw[j] >> 16);
+        *reinterpret_cast<unsigned short*>(loT + (2 * j) * PT + rt * 2) = (unsigned short)lw[j];
+        *reinterpret_cast<unsigned short*>(loT + (2 * j + 1) * PT + rt * 2) = (unsigned short)(lw[j] >> 16);
       }
     }
   };
   // 32 channels (block b) x 16 rows (step s) of a plane as an MFMA operand: lane (lr, lh) takes channel 32 b + lr of
   // rows 16 s + 8 lh .. + 7 = 16 contiguous bytes
   auto frag = [&](const char* plane, int b, int s) -> avs_f16x8 {
-    return __builtin_bit_cast(avs_f16x8, *reinterpret_cast<const uint4*>(plane + (32 * b + lr) * PT + (16 * s + 8 * lh) * 2));
+    const int ch = 32 * b + lr;
+    return __builtin_bit_cast(avs_f16x8, *reinterpret_cast<const uint4*>(plane + ch * PT + (ch >> 3) * 16 + (16 * s + 8 * lh) * 2));
   };
 
   f32x16 acc[NBLK], accs;   // accs: channel sums of block bi (rows of a^T . 1)

@@ -83,3 +83,16 @@ for name, hw, cin, cout, k, s in shapes:
         line += show("affine+res", timed(lambda: ops.conv2d_affine(code, n, hw, hw, cin, s, s, ho, ho, cout, x, *xs, w, wrs,
                                                                    y, cout, rpg, sc, sh, res, True, None, w_layout=1)))
     print(line, flush=True)
+
+# the Gram statistics pass of the expanding 1x1 layers (it is also the apply pass of the layer before: reads the raw
+# input, writes the finished one in place): GB/s over read + write
+for name, hw, k, nout in (("gram l1 (56x56, 64 -> 256)", 56, 64, 256), ("gram l2 (28x28, 128 -> 512)", 28, 128, 512)):
+    rows = n * hw * hw
+    x = ops.f16x2_pack(torch.randn(rows, k, device=dev) + 0.3)
+    w = ops.f16x2_pack(torch.randn(nout, k, device=dev) / k ** 0.5)
+    gamma, beta = torch.rand(nout, device=dev) + 0.5, torch.randn(nout, device=dev)
+    isc, ish = torch.rand(n, k, device=dev) + 0.5, torch.randn(n, k, device=dev) * 0.1
+    us = timed(lambda: ops.bn_gram_affine_h2(x, w, hw * hw, gamma, beta, 1e-5, (isc, ish), store_input=True))
+    us0 = timed(lambda: ops.bn_gram_affine_h2(x, w, hw * hw, gamma, beta, 1e-5))
+    print(f"{name:28s} | affine in, stored {us:8.1f} us ({2 * rows * k * 4 / us / 1e3:6.0f} GB/s) | finished in {us0:8.1f} us "
+          f"({rows * k * 4 / us0 / 1e3:6.0f} GB/s)", flush=True)
