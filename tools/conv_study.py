@@ -22,14 +22,17 @@ shapes = [  # name, n, hw, cin, cout, k, stride
     ("l3.conv1 1x1 1024->256", 1024, 14, 1024, 256, 1, 1),
     ("l4.conv1 1x1 2048->512", 1024, 7, 2048, 512, 1, 1),
 ]
-dt = torch.bfloat16
+H2 = "--f16x2" in sys.argv   # AVS_F16X2 operands (fp16 hi | lo runs) instead of bf16
+dt = torch.float32 if H2 else torch.bfloat16
 for name, n, hw, cin, cout, k, s in shapes:
     x = torch.randn(n, hw, hw, cin, device=dev).to(dt)
     w = (torch.randn(cout, k * k * cin, device=dev) / (k * k * cin) ** 0.5).to(dt)
+    if H2:
+        x, w = ops.f16x2_pack(x), ops.f16x2_pack(w)
     ho = hw // s
     y = torch.empty(n, ho, ho, cout, device=dev, dtype=dt)
     flops = 2.0 * n * ho * ho * cout * k * k * cin
-    byts = (x.numel() + y.numel() + w.numel()) * 2
+    byts = (x.numel() + y.numel() + w.numel()) * (4 if H2 else 2)
     line = f"{name:26s}"
     for tag, flags, rowb, pipe, tall in (("auto", 0, 2048, 1, 0), ("nostage", 8, 2048, 1, 0), ("noA", 16, 2048, 1, 0),
                                          ("noB", 32, 2048, 1, 0), ("noload", 2, 2048, 1, 0)):
@@ -37,12 +40,12 @@ for name, n, hw, cin, cout, k, s in shapes:
         L.avs_tune_short_reduction_bytes(rowb)
         L.avs_tune_pipeline(pipe)
         for _ in range(2):
-            ops.conv2d(x, w, k, k, s, k // 2, y, variant=tall)
+            ops.conv2d(x, w, k, k, s, k // 2, y, variant=tall, **({"split": "f16x2"} if H2 else {}))
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5):
-            ops.conv2d(x, w, k, k, s, k // 2, y, variant=tall)
+            ops.conv2d(x, w, k, k, s, k // 2, y, variant=tall, **({"split": "f16x2"} if H2 else {}))
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / 5
