@@ -45,7 +45,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARC
 MFMA_F32_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
 PMC_TRAFFIC_FILES = {"bf16": ("r02_pmc_traffic.json", "r01_e_pmc_traffic.json"),   # newest first, under profiles/
-                     "f16x2": ("r03_b_pmc_traffic.json", "r03_a_pmc_traffic.json")}
+                     "f16x2": ("r03_c_pmc_traffic.json", "r03_b_pmc_traffic.json", "r03_a_pmc_traffic.json")}
 
 T_START = time.perf_counter()
 
@@ -143,7 +143,7 @@ def roofline_from(prof, dtype, elapsed, traffic, split=False):
     peak = MFMA_BF16_PEAK_TFLOPS if dtype == torch.bfloat16 else (MFMA_BF16_PEAK_TFLOPS / 3.0 if split
                                                                    else MFMA_F32_PEAK_TFLOPS)
     seen = prof.seen.get(("conv", code), conv["launches"])
-    roofline = {"bound": "mfma", "kernel": "igemm_kernel (avs_conv2d_nhwc[_bnstats|_bnlocal])",
+    roofline = {"bound": "mfma", "kernel": "igemm_kernel + igemm_h2_local224_kernel (avs_conv2d_nhwc[_bnstats|_bnlocal|_affine])",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": traffic[0], "traffic_source": traffic[1],
                 "launches": seen, "timed_launches": conv["launches"],

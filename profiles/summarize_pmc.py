@@ -31,6 +31,14 @@ def load(path, counter):
                 sub = f"igemm_kernel<4,split2,bn={v.group(2)},spatial={v.group(3)},epi={v.group(5)}>"
                 agg[sub][0] += 1
                 agg[sub][1] += float(r["Counter_Value"])
+        # round 3: the AVS_F16X2 tile-local form of 193..224-row groups runs on its own tile (csrc/local224.hip); it is
+        # the same contraction behind the same entry point (avs_conv2d_nhwc_bnlocal) and counts into the same family
+        m2 = re.match(r"igemm_h2_local224_kernel<(\w+)", full)
+        if m2:
+            sub = f"igemm_h2_local224_kernel<spatial={m2.group(1)}>"
+            agg[sub][0] += 1
+            agg[sub][1] += float(r["Counter_Value"])
+            name = "igemm_kernel<4,split2>"
         agg[name][0] += 1
         agg[name][1] += float(r["Counter_Value"])
     return agg

@@ -30,6 +30,9 @@ def main():
             last = re.search(r", (\d+)>\(", full + "(")
             if m.group(1) == "4" and last and last.group(1) in ("1", "2"):
                 name = name[:-1] + f",split={last.group(1)}>"
+        m2 = re.match(r"igemm_h2_local224_kernel<(\w+)", full)
+        if m2:   # the 224-row tile-local form (AVS_F16X2): spatial or not
+            name = f"igemm_h2_local224_kernel<spatial={m2.group(1)}>"
         if not name.startswith(("igemm", "conv1x1", "bn_", "lstm", "stft", "frames_", "global_avg", "power_mel", "stem")):
             continue
         agg[name][r["Counter_Name"]] += float(r["Counter_Value"])
