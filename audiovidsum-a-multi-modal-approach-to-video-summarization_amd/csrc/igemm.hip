@@ -643,7 +643,7 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
     // columns: residual added and ReLU applied in fp32, then ONE split into fp16 hi | lo and two 16-byte stores.
     static_assert(EPI == EPI_PLAIN || EPI == EPI_STATS || EPI == EPI_BNLOCAL || EPI == EPI_AFFINE || EPI == EPI_BRELU,
                   "epilogue forms built for AVS_F16X2");
-    static_assert((EPI != EPI_BNLOCAL && EPI != EPI_AFFINE) || WR == 4, "the BatchNorm forms run on the 256-row tiles");
+    static_assert(EPI != EPI_BNLOCAL || WR == 4, "the tile-local BatchNorm form runs on the 256-row tiles");
     float* const fl = reinterpret_cast<float*>(lds);
     // masked sums over this lane's 32 rows of column tile nt: rows with lo <= roff < hi (roff = row inside the wave's
     // 64 rows minus 4 * lh); both lane halves return the column's total over the wave's rows
@@ -1363,6 +1363,7 @@ AVS_RULE g_tall_min_tiles = 2048;        // 256-row tiles by rule: at least this
 AVS_RULE g_tall_min_k_bytes = 1024;      // ... and, at BN = 128, a reduction long enough to be bound by the loop
 AVS_RULE g_pipe3 = 1;                    // the 3-buffer hand-counted pipeline for the 64-byte-row variants
 AVS_RULE g_bnlocal = 1;                  // 0: avs_conv2d_bnlocal_tile_rows declines every shape
+static constexpr int AVS_RULE_AFFINE_128_MAX_K = 128;   // the given-affine 1x1 form: 128-row tiles up to this reduction length
 #ifdef AVS_STUDY
 extern "C" void avs_tune_short_reduction_bytes(int bytes) { g_rowb_threshold_bytes = bytes; }
 extern "C" void avs_tune_tall_rule(int min_tiles, int min_k_bytes) {
@@ -1396,6 +1397,9 @@ static void igemm_dispatch_epi4(int epi, dim3 grid, hipStream_t stream, const Ig
           if (epi == EPI_AFFINE)
             hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_AFFINE, PIPE, WR, FK, 2>), grid, dim3(256), 0, stream, p);
         }
+      } else if constexpr (!SP && ROWB == 64 && PIPE && BN == 128) {   // AVS_TILE_128: the given-affine form on 128-row tiles
+        if (epi == EPI_AFFINE)
+          hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_AFFINE, PIPE, WR, FK, 2>), grid, dim3(256), 0, stream, p);
       }
       return;
     }
@@ -1555,7 +1559,15 @@ static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream
                                               (narrow || (long long)p.K * es >= g_tall_min_k_bytes))))
       p.tall = 1;
   }
-  if (p.tile_rows || p.affine) p.tall = 1;  // EPI_BNLOCAL (validated by bnlocal_plan): 256-row tiles at a pitch of tile_rows
+  // EPI_BNLOCAL (validated by bnlocal_plan): 256-row tiles at a pitch of tile_rows; EPI_AFFINE: 256-row tiles, or 128-row
+  // ones for wide outputs when the caller asks (AVS_TILE_128) or the reduction is short
+  // (short reductions, K <= 128: three 128-row workgroups per CU overlap their loops and their epilogue traffic better
+  //  than two 256-row ones - l2.conv3 +5 %, l1.conv3 +2 %, bit-identical outputs)
+  if (p.tile_rows) p.tall = 1;
+  if (p.affine) {
+    const int tile_mode = p.variant & 3;
+    p.tall = (!narrow && (tile_mode == AVS_TILE_128 || (tile_mode == AVS_TILE_AUTO && p.K <= AVS_RULE_AFFINE_128_MAX_K))) ? 0 : 1;
+  }
   const int tile_rows = p.tile_rows ? p.tile_rows : (p.tall ? 256 : 128);
   const long long tiles_m = ((long long)p.M + tile_rows - 1) / tile_rows;
   const long long total = tiles_m * p.tiles_n;

@@ -449,12 +449,12 @@ def bn_gram_affine_h2(x2d, wt, rows_per_group, gamma, beta, eps, in_affine=None,
 
 def conv2d_affine(dtype, n, h, w, cin, sh, sw, ho, wo, cout, x, x_img_stride, x_row_stride, x_px_stride, wt,
                   w_row_stride, y, y_px_stride, rows_per_group, scale, shift, residual=None, relu=True,
-                  res_affine=None, w_layout=0):
+                  res_affine=None, w_layout=0, variant=0):
     """1x1 convolution + a GIVEN per-group affine (+ residual, + its affine, + ReLU) in one streaming pass
     (avs_conv2d_nhwc_affine, AVS_F16X2).  scale / shift fp32 [groups, cout]; residual f16x2 [rows, cout]."""
     _dev(x, wt, y, scale, shift, residual)
     d = _abi.ConvDesc(dtype, n, h, w, cin, 1, 1, sh, sw, 0, 0, ho, wo, cout, x_img_stride, x_row_stride, x_px_stride,
-                      w_row_stride, y_px_stride, ACT_RELU if relu else ACT_NONE, 1.0, int(w_layout))
+                      w_row_stride, y_px_stride, ACT_RELU if relu else ACT_NONE, 1.0, int(w_layout), int(variant))
     rows = n * ho * wo
     groups = (rows + rows_per_group - 1) // rows_per_group
     for a in (scale, shift):

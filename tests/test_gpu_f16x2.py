@@ -456,14 +456,17 @@ def test_gram_statistics_and_affine_pass_f16x2(dev, rpg, k, n, xf, with_res, ra)
     relu = with_res or xf
     if relu:
         out_ref = torch.relu(out_ref)
+    # both weight layouts and both tiles (short reductions take the 128-row tile by rule, AVS_TILE_256 / AVS_TILE_128 force
+    # one): no statistics in this form, so every variant gives the same bits
+    from avsum_amd import _abi
     outs = []
-    for layout in (0, 1):
+    for layout, variant in ((0, _abi.TILE_AUTO), (1, _abi.TILE_AUTO), (1, _abi.TILE_256), (0, _abi.TILE_128)):
         y = torch.empty((rows, n), device=dev)
         wsel = ops.weights_kstep32(wd) if layout else wd
         ops.conv2d_affine(code, rows, 1, 1, k, 1, 1, 1, 1, n, xin, k, k, k, wsel, k, y, n, rpg, sc, sh,
                           resp.to(dev) if with_res else None, relu, (rsc.to(dev), rsh.to(dev)) if ra else None,
-                          w_layout=layout)
+                          w_layout=layout, variant=variant)
         outs.append(y)
-    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
+    assert all(torch.equal(outs[0].view(torch.int32), o.view(torch.int32)) for o in outs[1:])
     got = ops.f16x2_unpack(outs[0]).cpu().double()
     assert (got - out_ref).abs().max().item() <= TOL * max(1.0, out_ref.abs().max().item())

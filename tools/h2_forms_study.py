@@ -82,6 +82,10 @@ for name, hw, cin, cout, k, s in shapes:
         sc, sh = torch.rand(groups, cout, device=dev) + 0.5, torch.randn(groups, cout, device=dev)
         line += show("affine+res", timed(lambda: ops.conv2d_affine(code, n, hw, hw, cin, s, s, ho, ho, cout, x, *xs, w, wrs,
                                                                    y, cout, rpg, sc, sh, res, True, None, w_layout=1)))
+        if cout > 64:
+            line += show("affine+res/128", timed(lambda: ops.conv2d_affine(code, n, hw, hw, cin, s, s, ho, ho, cout, x, *xs, w,
+                                                                           wrs, y, cout, rpg, sc, sh, res, True, None,
+                                                                           w_layout=1, variant=1)))
     print(line, flush=True)
 
 # the Gram statistics pass of the expanding 1x1 layers (it is also the apply pass of the layer before: reads the raw
