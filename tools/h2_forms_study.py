@@ -65,6 +65,9 @@ for name, hw, cin, cout, k, s in shapes:
     if rpg >= 64:
         line += show("stats", timed(lambda: ops.conv2d_raw(code, *geom, x, *xs, w, wrs, y, cout,
                                                            bnstats=(rpg, gamma, beta, 1e-5), w_layout=1)))
+        if True:
+            line += show("stats/128", timed(lambda: ops.conv2d_raw(code, *geom, x, *xs, w, wrs, y, cout,
+                                                                   bnstats=(rpg, gamma, beta, 1e-5), w_layout=1, variant=1)))
     if ops.conv_bnlocal_tile_rows(code, *geom, *xs, wrs, cout, rpg) is not None:
         line += show("local", timed(lambda: ops.conv2d_raw(code, *geom, x, *xs, w, wrs, y, cout, act=ops.ACT_RELU,
                                                            bnlocal=(rpg, gamma, beta, 1e-5, None), w_layout=1)))
