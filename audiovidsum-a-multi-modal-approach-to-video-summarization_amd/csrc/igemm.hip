@@ -85,9 +85,10 @@ __device__ __forceinline__ void avs_split_bf16(const float4& p0, const float4& p
 // (A form in which tiles of larger groups exchanged statistics through float atomics and waited for each other inside
 //  one launch was built in round 1 and removed: results were not reproducible run to run and it only won for groups of
 //  two or three tiles, which the tile-local form covers.)
-//   EPI_AFFINE AVS_F16X2, 1x1 convolutions on the 256-row tiles: a folded BatchNorm affine GIVEN per group of rows (computed
-//              beforehand from the input's Gram matrix, avs_bn_gram_affine_f16x2) + residual + ReLU: the one streaming
-//              pass of the expanding 1x1 layers whose groups are too large for a tile
+//   EPI_AFFINE AVS_F16X2, 1x1 convolutions: a folded BatchNorm affine GIVEN per group of rows (computed beforehand from
+//              the input's Gram matrix, avs_bn_gram_affine_f16x2) + residual + ReLU: the one streaming pass of the
+//              expanding 1x1 layers whose groups are too large for a tile.  256-row tiles; 128-row tiles (three
+//              workgroups per CU) for wide outputs of reductions up to 128 channels
 
 // PIPE: three operand buffers, the DMA of step s+2 is issued in step s; fragment reads are inline-asm
 // ds_read_b128 and the waits are hand-counted (s_waitcnt vmcnt(N) + raw s_barrier), because hipcc orders every
