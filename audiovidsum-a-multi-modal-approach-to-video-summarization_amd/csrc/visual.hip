@@ -45,10 +45,28 @@ __global__ __launch_bounds__(256) void frames_normalize_kernel(const uint8_t* __
   }
 }
 
-// AVS_F16X2 image: a thread writes two pixels = one run of 8 slots (2 x (3 channels + a zero channel))
+// AVS_F16X2 image: a thread writes two pixels = one run of 8 slots (2 x (3 channels + a zero channel)).  The normalised
+// value of a byte is one of 3 x 256: every workgroup evaluates frames_normalize_kernel's expression (two IEEE divisions per
+// value) ONCE per (channel, byte) into an LDS table of fp16 hi | lo pairs - avs_f16x2_split8's arithmetic, bit for bit -
+// and a pixel is three table reads.
 __global__ __launch_bounds__(256) void frames_normalize_h2_kernel(const uint8_t* __restrict__ src, int n, int h, int w,
                                                                   NormParams np, uint4* __restrict__ out, int out_h,
                                                                   int out_w, int pad_t, int pad_l) {
+  __shared__ unsigned lut[3][256];   // bits 0-15: the hi half, bits 16-31: the lo half
+  for (int i = threadIdx.x; i < 3 * 256; i += blockDim.x) {
+    const int c = i >> 8;
+    float f = (float)(i & 255) / np.denom;
+    f = (f - np.mean[c]) / np.stdv[c];
+    if (np.has_affine) {
+      f = f * np.aff_a[c];
+      f = f + np.aff_b[c];
+    }
+    const float v8[8] = {f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    uint4 hi, lo;
+    avs_f16x2_split8(v8, hi, lo);
+    lut[c][i & 255] = (hi.x & 0xffffu) | (lo.x << 16);
+  }
+  __syncthreads();
   const int pw = out_w >> 1;
   const long long total = (long long)n * out_h * pw;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -58,28 +76,21 @@ __global__ __launch_bounds__(256) void frames_normalize_h2_kernel(const uint8_t*
     const int oy = (int)(t % out_h);
     const long long img = t / out_h;
     const int sy = oy - pad_t;
-    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    unsigned e[2][3] = {{0u, 0u, 0u}, {0u, 0u, 0u}};
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int sx = ox + q - pad_l;
       if ((unsigned)sy < (unsigned)h && (unsigned)sx < (unsigned)w) {
         const uint8_t* s = src + ((img * h + sy) * (long long)w + sx) * 3;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          float f = (float)s[c] / np.denom;
-          f = (f - np.mean[c]) / np.stdv[c];
-          if (np.has_affine) {
-            f = f * np.aff_a[c];
-            f = f + np.aff_b[c];
-          }
-          v[4 * q + c] = f;
-        }
+        for (int c = 0; c < 3; ++c) e[q][c] = lut[c][s[c]];
       }
     }
-    uint4 hi, lo;
-    avs_f16x2_split8(v, hi, lo);
-    out[2 * i] = hi;
-    out[2 * i + 1] = lo;
+    // halves in slot order: pixel 0 (c0 c1 | c2 0), pixel 1 (c0 c1 | c2 0)
+    out[2 * i] = make_uint4((e[0][0] & 0xffffu) | (e[0][1] << 16), e[0][2] & 0xffffu,
+                            (e[1][0] & 0xffffu) | (e[1][1] << 16), e[1][2] & 0xffffu);
+    out[2 * i + 1] = make_uint4((e[0][0] >> 16) | (e[0][1] & 0xffff0000u), e[0][2] >> 16,
+                                (e[1][0] >> 16) | (e[1][1] & 0xffff0000u), e[1][2] >> 16);
   }
 }
 
@@ -154,8 +165,8 @@ extern "C" int avs_frames_normalize_u8(int dtype, const uint8_t* d_src, int n, i
   np.has_affine = affine6 != nullptr;
   const long long total = (long long)n * out_h * out_w;
   const int grid = (int)(avs_cdiv(total, 256) < 16384 ? avs_cdiv(total, 256) : 16384);
-  if (dtype == AVS_F16X2)
-    hipLaunchKernelGGL(frames_normalize_h2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_src, n, h, w, np,
+  if (dtype == AVS_F16X2)   // (a thread writes two pixels; few enough workgroups that the table build does not matter)
+    hipLaunchKernelGGL(frames_normalize_h2_kernel, dim3(grid < 4096 ? grid : 4096), dim3(256), 0, (hipStream_t)stream, d_src, n, h, w, np,
                        (uint4*)d_out, out_h, out_w, pad_t, pad_l);
   else if (dtype == AVS_F32)
     hipLaunchKernelGGL(frames_normalize_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_src, n, h, w,

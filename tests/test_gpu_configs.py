@@ -179,6 +179,16 @@ def test_pinned_host_frames_are_uploaded_pass_by_pass(dev):
     assert got.is_cuda and torch.equal(got, want)
     pipe.host_lead_frames = 0                       # no lead pass: 8 | 8 | 7
     assert torch.equal(pipe.embed(host.pin_memory(), offsets), want)
+    # two uploads back to back with NO host synchronisation in between (the second call's staging buffers may be
+    # the blocks the first call's kernels still read; the stager orders its copy stream behind the compute stream)
+    host2 = torch.from_numpy(rng.integers(0, 256, (23, 224, 224, 3), dtype=np.uint8))
+    want2 = FrameScoringPipeline(ext, None, use_inception=False, chunk_frames=64).embed(host2.to(dev), offsets)
+    torch.cuda.synchronize()
+    p1, p2 = host.pin_memory(), host2.pin_memory()
+    g1 = pipe.embed(p1, offsets)
+    g2 = pipe.embed(p2, offsets)
+    g3 = pipe.embed(p1, offsets)
+    assert torch.equal(g1, want) and torch.equal(g2, want2) and torch.equal(g3, want)
     with pytest.raises(ValueError, match="pinned"):
         pipe.embed(host, offsets)
 
