@@ -106,10 +106,21 @@ __device__ __forceinline__ void avs_split_bf16(const float4& p0, const float4& p
 // 2 = AVS_F16X2 (operands ARE stored as fp16 hi + lo runs: the 16-byte chunks of a step alternate hi8 | lo8, so the
 // fragments need no arithmetic at all - three v_mfma_f32_32x32x16_f16 per 16 reduction elements - and the epilogue
 // splits each output once, where it is produced, instead of every consumer splitting it per tile and step)
+// TAP9 (AVS_F16X2, 3x3 / stride 1 / pad 1 on a dense NHWC input, 256-row tiles): for output pixel (y, x) and tap (dy, dx)
+// the input pixel is row m + (dy - 1) W + (dx - 1) of the SAME flat pixel array the outputs are rows of.  So a 16-channel
+// block of the tile's pixels (+ W + 1 rows of halo on either side: 384 buffer rows) is fetched ONCE - two buffers, a
+// block ahead - and the nine taps of the block are nine reduction steps that read their A fragments from it at shifted
+// rows; a tap that leaves the frame reads a row of zeros (per-lane tap masks; this also covers tiles that straddle
+// frames).  Only the weights of a (block, tap) are fetched per step (a ring of three).  L2 -> LDS traffic of the A
+// operand / 9: for the 64-column layers, which sit at the L2 -> LDS intake ceiling (~21 B / clk / CU) with the matrix
+// cores 37 % busy.  The reduction runs block-major / tap-minor: another (fixed) summation order than the tap-major walk.
 template <int ES, int BN, bool ACC64, bool SPATIAL, int ROWB, int EPI, bool PIPE, int WR = 2, bool FASTK = false,
-          int SPLIT = 0>
+          int SPLIT = 0, bool TAP9 = false>
 __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64 && ES == 2) ? 4 : 3) : 2) void igemm_kernel(
     IgemmParams p) {
+  static_assert(!TAP9 || (SPLIT == 2 && PIPE && WR == 4 && ROWB == 64 && FASTK && SPATIAL &&
+                          (EPI == EPI_STATS || EPI == EPI_BNLOCAL)),
+                "the nine-tap form: AVS_F16X2 convolution + statistics / tile-local BatchNorm on the pipelined 256-row tiles");
   static_assert(SPLIT == 0 || (ES == 4 && !ACC64), "the split arithmetic is for 4-byte operands");
   static_assert(WR == 2 || (WR == 4 && !ACC64 && (ES == 2 || SPLIT != 0)),
                 "256-row tiles are built for the bf16 variants and the fp32-split arithmetic");
@@ -140,7 +151,12 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
   // reads them back as runs of 8 columns; the statistics tables alias those regions (a barrier separates the uses)
   constexpr int H2_P = WCOLS + 8;                               // words per staged row
   constexpr int H2_SLOTS = SPLIT == 2 ? (4 * 32 * H2_P * 4) / 16 : 0;
-  constexpr int LDS_BASE = NBUF * BUF > CT_SLOTS + TAB_SLOTS ? NBUF * BUF : CT_SLOTS + TAB_SLOTS;
+  // TAP9: two A buffers of 384 rows (+ 4 rows of zeros) and a ring of three weight tiles
+  constexpr int T9_AROWS = 384;
+  constexpr int T9_ABUF = (T9_AROWS + 4) * CPRR;
+  constexpr int T9_BBUF = BN * CPRR;
+  constexpr int OPERAND_SLOTS = TAP9 ? 2 * T9_ABUF + 3 * T9_BBUF : NBUF * BUF;
+  constexpr int LDS_BASE = OPERAND_SLOTS > CT_SLOTS + TAB_SLOTS ? OPERAND_SLOTS : CT_SLOTS + TAB_SLOTS;
   constexpr int LDS_SLOTS = LDS_BASE > H2_SLOTS ? LDS_BASE : H2_SLOTS;
 
   __shared__ uint4 lds[LDS_SLOTS];
@@ -378,7 +394,157 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
   }
 
   const int steps = (p.K + BKE - 1) / BKE;
-  if constexpr (PIPE) {
+  if constexpr (TAP9) {
+    constexpr int T9_NA = T9_AROWS / RPP;   // DMA instructions per wave and A block (6)
+    const unsigned lds_base = (unsigned)(unsigned long long)((__attribute__((address_space(3))) char*)lds);
+    const int w1 = p.W + 1;
+    // buffer row a holds flat input row m0 - (W + 1) + a; the buffer window starts at the first row fetched
+    const long long mbase = m0 > w1 ? m0 - w1 : 0;
+    const __amdgpu_buffer_rsrc_t a9 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(x) + mbase * p.cin * 4, 0,
+                                                                         (int)BUF_OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b9 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(w) + (p.w_kstep ? (long long)n0 * 64 : (long long)n0 * p.ldb * 4), 0, (int)BUF_OOB, 0x00020000);
+    unsigned aoff9[T9_NA], boff9[NB];
+#pragma unroll
+    for (int i = 0; i < T9_NA; ++i) {
+      const long long m = (long long)m0 - w1 + rb + RPP * i;
+      aoff9[i] = (m >= 0 && m < p.M) ? (unsigned)((m - mbase) * p.cin * 4) + cq * 16 : BUF_OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      boff9[i] = n0 + rb + RPP * i >= p.N ? BUF_OOB
+                 : p.w_kstep              ? (unsigned)((rb + RPP * i) * 64) + (cq & 3) * 16
+                                          : (unsigned)((long long)(rb + RPP * i) * p.ldb * 4) + cq * 16;
+    // bit tp of vm[mt]: tap tp of this lane's row of block mt lies inside its frame
+    unsigned vm[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      unsigned mk = 0;
+      const int m = m0 + wr * 64 + mt * 32 + lr;
+      bool live = m < p.M;
+      if constexpr (EPI == EPI_BNLOCAL) live = live && wr * 64 + mt * 32 + lr < p.tile_rows;   // the tile's idle rows
+      if (live) {
+        const int pix = m % p.HoWo;
+        const int yy = pix / p.W, xx = pix - yy * p.W;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp)
+          if ((unsigned)(yy + tp / 3 - 1) < (unsigned)p.H && (unsigned)(xx + tp % 3 - 1) < (unsigned)p.W) mk |= 1u << tp;
+      }
+      vm[mt] = mk;
+    }
+    if (t < 32) lds[(t >> 4) * T9_ABUF + T9_AROWS * CPRR + (t & 15)] = make_uint4(0u, 0u, 0u, 0u);   // the rows of zeros
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    unsigned fb9[NT][2];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int hl = 0; hl < 2; ++hl) {
+        const int brow = nt * 32 + lr;
+        fb9[nt][hl] = (unsigned)(brow * CPRR + ((2 * lh + hl) ^ ((brow >> SH) & (CPRR - 1)))) * 16u;
+      }
+    const int nblk = p.cin / BKE;   // 16-channel blocks; step s = (block s / 9, tap s % 9)
+    auto stage_a = [&](int blk, int buf) {
+      uint4* abuf = lds + buf * T9_ABUF + wave * 64;
+#pragma unroll
+      for (int i = 0; i < T9_NA; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a9, (__attribute__((address_space(3))) void*)(abuf + 256 * i), 16,
+                                                 (int)aoff9[i], blk * ROWB, 0, 0);
+    };
+    int sb_blk = 0, sb_tap = 0, sb_slot = 0;   // the step the next stage_b call fetches, and its ring slot
+    auto stage_b = [&]() {
+      uint4* bbuf = lds + 2 * T9_ABUF + sb_slot * T9_BBUF + wave * 64;
+      const int kstep = sb_tap * nblk + sb_blk;   // reduction elements tap * cin + 16 * block .. + 15 of a filter row
+      const int kb = p.w_kstep ? kstep * (p.N * ROWB) : kstep * ROWB;
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(b9, (__attribute__((address_space(3))) void*)(bbuf + 256 * i), 16,
+                                                 (int)boff9[i], kb, 0, 0);
+      sb_slot = sb_slot == 2 ? 0 : sb_slot + 1;
+      if (++sb_tap == 9) {
+        sb_tap = 0;
+        ++sb_blk;
+      }
+    };
+    stage_a(0, 0);
+    stage_b();
+    if (steps > 1) stage_b();
+    const int abase = wr * 64 + lr + w1;   // buffer row of this lane's row of block 0 under the centre tap
+    int blk = 0, tap = 0, tdx = 0, slot = 0, sig = -w1;   // sig: the tap's row shift (dy - 1) W + (dx - 1)
+    for (int s = 0; s < steps; ++s) {
+      // loads return in order: this step's weights (issued two steps ago, AFTER any A block of that step) cover the A
+      // block; younger than them: the next step's weights and - when the step before was a block's first tap - an A block
+      if (s + 1 < steps) {
+        if (tap == 1 && blk + 1 < nblk)
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB + T9_NA) : "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      const unsigned abuf = lds_base + (unsigned)(blk & 1) * (T9_ABUF * 16u);
+      const unsigned bbase = lds_base + (unsigned)(2 * T9_ABUF + slot * T9_BBUF) * 16u;
+      uint4 fa[2][2], fb[2][NT];
+      unsigned aaddr[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int a = ((vm[mt] >> tap) & 1u) ? abase + mt * 32 + sig : T9_AROWS;   // outside the frame: the zero row
+        aaddr[mt] = abuf + (unsigned)a * ROWB + (unsigned)((2 * lh) ^ ((a >> SH) & (CPRR - 1))) * 16u;
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) fa[0][mt] = avs_lds_read_b128(aaddr[mt]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) fb[0][nt] = avs_lds_read_b128(bbase + fb9[nt][0]);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) fa[1][mt] = avs_lds_read_b128(aaddr[mt] ^ 16u);   // the lo chunk sits beside the hi one
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) fb[1][nt] = avs_lds_read_b128(bbase + fb9[nt][1]);
+      // the next A block goes out at a block's first tap (its buffer was last read in the step before: every wave is
+      // past this step's barrier), then the weights of step s + 2
+      if (tap == 0 && blk + 1 < nblk) stage_a(blk + 1, (blk + 1) & 1);
+      if (s + 2 < steps) stage_b();
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 + NT) : "memory");
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) avs_pin(fa[0][mt]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) avs_pin(fb[0][nt]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(avs_f16x8, fa[0][mt]),
+                                                               __builtin_bit_cast(avs_f16x8, fb[0][nt]), acc[mt][nt], 0, 0, 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) avs_pin(fa[1][mt]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) avs_pin(fb[1][nt]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(avs_f16x8, fa[1][mt]),
+                                                               __builtin_bit_cast(avs_f16x8, fb[0][nt]), acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(avs_f16x8, fa[0][mt]),
+                                                               __builtin_bit_cast(avs_f16x8, fb[1][nt]), acc[mt][nt], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      slot = slot == 2 ? 0 : slot + 1;
+      ++sig;   // next tap: one pixel to the right, or the next row's first
+      if (++tdx == 3) {
+        tdx = 0;
+        sig += p.W - 3;
+      }
+      if (++tap == 9) {
+        tap = 0;
+        ++blk;
+        sig = -w1;
+      }
+    }
+    __syncthreads();   // the epilogue's tables and staging regions alias the operand buffers
+  } else if constexpr (PIPE) {
     constexpr int NDMA = NA + NB;  // DMA instructions one stage() issues per wave
     const unsigned lds_base = (unsigned)(unsigned long long)((__attribute__((address_space(3))) char*)lds);
     // per-lane fragment byte offsets inside a buffer (ks = 0; ks = 1 flips bit 1 of the chunk)
@@ -1375,6 +1541,16 @@ extern "C" void avs_tune_pipeline(int enabled) { g_pipe3 = enabled; }
 extern "C" void avs_tune_bnlocal(int enabled) { g_bnlocal = enabled; }
 #endif
 
+// The shapes the nine-tap form takes (AVS_F16X2 convolution + statistics on the 256-row tiles): 3x3 / stride 1 / pad 1,
+// output = input geometry, a dense NHWC input at most 63 pixels wide (a tile's rows + W + 1 rows of halo on either side
+// fit the 384-row A buffer), the caller not forcing the 256-row tile's classic walk (AVS_TILE_256 keeps it).
+static bool igemm_tap9_ok(const IgemmParams& p) {
+  return (p.variant & 3) != AVS_TILE_256 && p.KW == 3 && p.K == 9 * p.cin && p.sh == 1 && p.sw == 1 && p.ph == 1 && p.pw == 1 &&
+         p.W <= 63 && p.HoWo == p.H * p.W && p.Wo == p.W && p.x_px_stride == p.cin &&
+         p.x_row_stride == (long long)p.W * p.cin && p.x_img_stride == (long long)p.HoWo * p.cin && p.cin % 16 == 0 &&
+         (long long)(384 + 64) * p.cin * 4 < (1ll << 31);
+}
+
 template <int ES, int BN, bool ACC64, bool SP, int ROWB, bool PIPE, int WR, bool FK>
 static void igemm_dispatch_epi4(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p) {
   if constexpr (ES == 2 && WR == 4) {
@@ -1387,13 +1563,28 @@ static void igemm_dispatch_epi4(int epi, dim3 grid, hipStream_t stream, const Ig
     if (p.split == 2) {         // AVS_F16X2: operands stored as fp16 hi | lo runs, three fp16 MFMAs per product
       if (epi == EPI_PLAIN)
         hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_PLAIN, PIPE, WR, FK, 2>), grid, dim3(256), 0, stream, p);
-      else if (epi == EPI_STATS)
+      else if (epi == EPI_STATS) {
+        if constexpr (SP && ROWB == 64 && PIPE && WR == 4 && FK) {
+          if (igemm_tap9_ok(p)) {   // 3x3 / 1 / pad 1 on a dense input: one A fetch per channel block serves all nine taps
+            hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE, WR, FK, 2, true>), grid, dim3(256), 0,
+                               stream, p);
+            return;
+          }
+        }
         hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE, WR, FK, 2>), grid, dim3(256), 0, stream, p);
-      else if (epi == EPI_BRELU)
+      } else if (epi == EPI_BRELU)
         hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BRELU, PIPE, WR, FK, 2>), grid, dim3(256), 0, stream, p);
       else if constexpr (WR == 4) {
-        if (epi == EPI_BNLOCAL)
+        if (epi == EPI_BNLOCAL) {
+          if constexpr (SP && ROWB == 64 && PIPE && FK) {
+            if (igemm_tap9_ok(p)) {
+              hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BNLOCAL, PIPE, WR, FK, 2, true>), grid, dim3(256), 0,
+                                 stream, p);
+              return;
+            }
+          }
           hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BNLOCAL, PIPE, WR, FK, 2>), grid, dim3(256), 0, stream, p);
+        }
         if constexpr (!SP && ROWB == 64 && PIPE) {   // (the launcher only sends 1x1 shapes on the pipelined 256-row tiles here)
           if (epi == EPI_AFFINE)
             hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_AFFINE, PIPE, WR, FK, 2>), grid, dim3(256), 0, stream, p);
