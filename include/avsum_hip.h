@@ -114,7 +114,8 @@ typedef struct {
                              * AVS_TILE_128 / AVS_TILE_256 (bits 0-1): 128-row or, wherever the variant exists, 256-row
                              * output tiles; AVS_TILE_224 (avs_conv2d_nhwc_bnlocal, AVS_F16X2 only): the 224-row tile
                              * whose waves split the columns, for groups of 193..224 rows - what AVS_TILE_AUTO picks
-                             * for such groups, AVS_TILE_256 keeps them on the 256-row tile;
+                             * for such groups, AVS_TILE_256 keeps them on the 256-row tile (and keeps the AVS_F16X2
+                             * 3x3 / stride-1 layers on the tap-major walk instead of the nine-tap form);
                              * AVS_STAGING_GENERIC (bit 2): the general per-lane gather staging even where
                              * the scalar tap walk applies.  Results do not depend on it beyond fp32 summation order. */
 } avs_conv_desc;
