@@ -118,9 +118,9 @@ template <int ES, int BN, bool ACC64, bool SPATIAL, int ROWB, int EPI, bool PIPE
           int SPLIT = 0, bool TAP9 = false>
 __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64 && ES == 2) ? 4 : 3) : 2) void igemm_kernel(
     IgemmParams p) {
-  static_assert(!TAP9 || (SPLIT == 2 && PIPE && WR == 4 && ROWB == 64 && FASTK && SPATIAL &&
-                          (EPI == EPI_STATS || EPI == EPI_BNLOCAL)),
-                "the nine-tap form: AVS_F16X2 convolution + statistics / tile-local BatchNorm on the pipelined 256-row tiles");
+  static_assert(!TAP9 || (((SPLIT == 2 && ES == 4) || (SPLIT == 0 && ES == 2)) && PIPE && WR == 4 && ROWB == 64 && FASTK &&
+                          SPATIAL && (EPI == EPI_STATS || EPI == EPI_BNLOCAL)),
+                "the nine-tap form: AVS_F16X2 / bf16 convolution + statistics / tile-local BatchNorm on the pipelined 256-row tiles");
   static_assert(SPLIT == 0 || (ES == 4 && !ACC64), "the split arithmetic is for 4-byte operands");
   static_assert(WR == 2 || (WR == 4 && !ACC64 && (ES == 2 || SPLIT != 0)),
                 "256-row tiles are built for the bf16 variants and the fp32-split arithmetic");
@@ -400,21 +400,21 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
     const int w1 = p.W + 1;
     // buffer row a holds flat input row m0 - (W + 1) + a; the buffer window starts at the first row fetched
     const long long mbase = m0 > w1 ? m0 - w1 : 0;
-    const __amdgpu_buffer_rsrc_t a9 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(x) + mbase * p.cin * 4, 0,
+    const __amdgpu_buffer_rsrc_t a9 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(x) + mbase * p.cin * ES, 0,
                                                                          (int)BUF_OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t b9 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(w) + (p.w_kstep ? (long long)n0 * 64 : (long long)n0 * p.ldb * 4), 0, (int)BUF_OOB, 0x00020000);
+        const_cast<char*>(w) + (p.w_kstep ? (long long)n0 * 64 : (long long)n0 * p.ldb * ES), 0, (int)BUF_OOB, 0x00020000);
     unsigned aoff9[T9_NA], boff9[NB];
 #pragma unroll
     for (int i = 0; i < T9_NA; ++i) {
       const long long m = (long long)m0 - w1 + rb + RPP * i;
-      aoff9[i] = (m >= 0 && m < p.M) ? (unsigned)((m - mbase) * p.cin * 4) + cq * 16 : BUF_OOB;
+      aoff9[i] = (m >= 0 && m < p.M) ? (unsigned)((m - mbase) * p.cin * ES) + cq * 16 : BUF_OOB;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i)
       boff9[i] = n0 + rb + RPP * i >= p.N ? BUF_OOB
                  : p.w_kstep              ? (unsigned)((rb + RPP * i) * 64) + (cq & 3) * 16
-                                          : (unsigned)((long long)(rb + RPP * i) * p.ldb * 4) + cq * 16;
+                                          : (unsigned)((long long)(rb + RPP * i) * p.ldb * ES) + cq * 16;
     // bit tp of vm[mt]: tap tp of this lane's row of block mt lies inside its frame
     unsigned vm[2];
 #pragma unroll
@@ -440,7 +440,9 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
 #pragma unroll
       for (int hl = 0; hl < 2; ++hl) {
         const int brow = nt * 32 + lr;
-        fb9[nt][hl] = (unsigned)(brow * CPRR + ((2 * lh + hl) ^ ((brow >> SH) & (CPRR - 1)))) * 16u;
+        // sub-step hl: AVS_F16X2 = the hi / lo chunk of this lane half's 8 elements; bf16 = its chunk of 16-element half hl
+        const int chunk = SPLIT == 2 ? 2 * lh + hl : 2 * hl + lh;
+        fb9[nt][hl] = (unsigned)(brow * CPRR + (chunk ^ ((brow >> SH) & (CPRR - 1)))) * 16u;
       }
     const int nblk = p.cin / BKE;   // 16-channel blocks; step s = (block s / 9, tap s % 9)
     auto stage_a = [&](int blk, int buf) {
@@ -489,14 +491,15 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         const int a = ((vm[mt] >> tap) & 1u) ? abase + mt * 32 + sig : T9_AROWS;   // outside the frame: the zero row
-        aaddr[mt] = abuf + (unsigned)a * ROWB + (unsigned)((2 * lh) ^ ((a >> SH) & (CPRR - 1))) * 16u;
+        aaddr[mt] = abuf + (unsigned)a * ROWB + (unsigned)((SPLIT == 2 ? 2 * lh : lh) ^ ((a >> SH) & (CPRR - 1))) * 16u;
       }
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) fa[0][mt] = avs_lds_read_b128(aaddr[mt]);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) fb[0][nt] = avs_lds_read_b128(bbase + fb9[nt][0]);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) fa[1][mt] = avs_lds_read_b128(aaddr[mt] ^ 16u);   // the lo chunk sits beside the hi one
+      // (the second sub-step's chunk index differs in one bit: the lo chunk beside the hi one / the other 32-byte half)
+      for (int mt = 0; mt < 2; ++mt) fa[1][mt] = avs_lds_read_b128(aaddr[mt] ^ (SPLIT == 2 ? 16u : 32u));
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) fb[1][nt] = avs_lds_read_b128(bbase + fb9[nt][1]);
       // the next A block goes out at a block's first tap (its buffer was last read in the step before: every wave is
@@ -513,8 +516,12 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(avs_f16x8, fa[0][mt]),
-                                                               __builtin_bit_cast(avs_f16x8, fb[0][nt]), acc[mt][nt], 0, 0, 0);
+          if constexpr (SPLIT == 2)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(avs_f16x8, fa[0][mt]),
+                                                                 __builtin_bit_cast(avs_f16x8, fb[0][nt]), acc[mt][nt], 0, 0, 0);
+          else
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[0][mt]),
+                                                                  __builtin_bit_cast(bf16x8, fb[0][nt]), acc[mt][nt], 0, 0, 0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) avs_pin(fa[1][mt]);
@@ -525,10 +532,15 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(avs_f16x8, fa[1][mt]),
-                                                               __builtin_bit_cast(avs_f16x8, fb[0][nt]), acc[mt][nt], 0, 0, 0);
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(avs_f16x8, fa[0][mt]),
-                                                               __builtin_bit_cast(avs_f16x8, fb[1][nt]), acc[mt][nt], 0, 0, 0);
+          if constexpr (SPLIT == 2) {
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(avs_f16x8, fa[1][mt]),
+                                                                 __builtin_bit_cast(avs_f16x8, fb[0][nt]), acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(avs_f16x8, fa[0][mt]),
+                                                                 __builtin_bit_cast(avs_f16x8, fb[1][nt]), acc[mt][nt], 0, 0, 0);
+          } else {
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[1][mt]),
+                                                                  __builtin_bit_cast(bf16x8, fb[1][nt]), acc[mt][nt], 0, 0, 0);
+          }
         }
       __builtin_amdgcn_sched_barrier(0);
       slot = slot == 2 ? 0 : slot + 1;
@@ -1544,16 +1556,25 @@ extern "C" void avs_tune_bnlocal(int enabled) { g_bnlocal = enabled; }
 // The shapes the nine-tap form takes (AVS_F16X2 convolution + statistics on the 256-row tiles): 3x3 / stride 1 / pad 1,
 // output = input geometry, a dense NHWC input at most 63 pixels wide (a tile's rows + W + 1 rows of halo on either side
 // fit the 384-row A buffer), the caller not forcing the 256-row tile's classic walk (AVS_TILE_256 keeps it).
-static bool igemm_tap9_ok(const IgemmParams& p) {
+static bool igemm_tap9_ok(const IgemmParams& p, int es) {
   return (p.variant & 3) != AVS_TILE_256 && p.KW == 3 && p.K == 9 * p.cin && p.sh == 1 && p.sw == 1 && p.ph == 1 && p.pw == 1 &&
          p.W <= 63 && p.HoWo == p.H * p.W && p.Wo == p.W && p.x_px_stride == p.cin &&
-         p.x_row_stride == (long long)p.W * p.cin && p.x_img_stride == (long long)p.HoWo * p.cin && p.cin % 16 == 0 &&
-         (long long)(384 + 64) * p.cin * 4 < (1ll << 31);
+         p.x_row_stride == (long long)p.W * p.cin && p.x_img_stride == (long long)p.HoWo * p.cin && p.cin % (64 / es) == 0 &&
+         (long long)(384 + 64) * p.cin * es < (1ll << 31);
 }
 
 template <int ES, int BN, bool ACC64, bool SP, int ROWB, bool PIPE, int WR, bool FK>
 static void igemm_dispatch_epi4(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p) {
   if constexpr (ES == 2 && WR == 4) {
+    if constexpr (SP && ROWB == 64 && PIPE && FK) {   // bf16 3x3 / 1 layers: the nine-tap form
+      if ((epi == EPI_BNLOCAL || epi == EPI_STATS) && igemm_tap9_ok(p, ES)) {
+        if (epi == EPI_BNLOCAL)
+          hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BNLOCAL, PIPE, WR, FK, 0, true>), grid, dim3(256), 0, stream, p);
+        else
+          hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE, WR, FK, 0, true>), grid, dim3(256), 0, stream, p);
+        return;
+      }
+    }
     if (epi == EPI_BNLOCAL) {
       hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BNLOCAL, PIPE, WR, FK>), grid, dim3(256), 0, stream, p);
       return;
@@ -1565,7 +1586,7 @@ static void igemm_dispatch_epi4(int epi, dim3 grid, hipStream_t stream, const Ig
         hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_PLAIN, PIPE, WR, FK, 2>), grid, dim3(256), 0, stream, p);
       else if (epi == EPI_STATS) {
         if constexpr (SP && ROWB == 64 && PIPE && WR == 4 && FK) {
-          if (igemm_tap9_ok(p)) {   // 3x3 / 1 / pad 1 on a dense input: one A fetch per channel block serves all nine taps
+          if (igemm_tap9_ok(p, ES)) {   // 3x3 / 1 / pad 1 on a dense input: one A fetch per channel block serves all nine taps
             hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE, WR, FK, 2, true>), grid, dim3(256), 0,
                                stream, p);
             return;
@@ -1577,7 +1598,7 @@ static void igemm_dispatch_epi4(int epi, dim3 grid, hipStream_t stream, const Ig
       else if constexpr (WR == 4) {
         if (epi == EPI_BNLOCAL) {
           if constexpr (SP && ROWB == 64 && PIPE && FK) {
-            if (igemm_tap9_ok(p)) {
+            if (igemm_tap9_ok(p, ES)) {
               hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BNLOCAL, PIPE, WR, FK, 2, true>), grid, dim3(256), 0,
                                  stream, p);
               return;
