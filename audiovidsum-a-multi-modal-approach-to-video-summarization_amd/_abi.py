@@ -107,6 +107,7 @@ _SIGNATURES = {
     "avs_mhsa_flash_f32": (c_int, [P, P, P, c_int64, c_int, c_int, c_int, c_int, P, c_int64, P]),
     "avs_mhsa_flash_f16x2": (c_int, [P, P, P, c_int64, c_int, c_int, c_int, c_int, P, c_int64, P]),
     "avs_softmax_rows_f32": (c_int, [P, c_int64, c_int, c_int64, P]),
+    "avs_softmax_bwd_rows_f32": (c_int, [P, P, c_int64, c_int, c_int64, c_float, P]),
     "avs_transpose_f32": (c_int, [P, c_int, c_int, c_int64, P, c_int64, P]),
     "avs_colsum_f32": (c_int, [P, c_int64, c_int, c_int64, P, P, P]),
     "avs_relu_dropout_bwd_f32": (c_int, [P, P, P, c_int64, P, P]),

@@ -150,6 +150,8 @@ class ResNet50Runner:
         self._w = None
         self._plans = {}     # (n, group frames) -> per layer: does it take the tile-local form
 
+    block_hook = None   # study hook: callable(block index, block output) -> block output
+
     # weights in kernel layout, rebuilt when the parameters change / move
     def _prepare(self):
         key = tuple((p.data_ptr(), p._version) for p in self.trunk.parameters()) + (self.dtype,)
@@ -456,6 +458,8 @@ class ResNet50Runner:
             x = self._conv_bn(geom, xs, t2, blk["c3"], blk["b3"], groups, residual=idn, relu=True, local=s3,
                               in_affine=aff2, res_affine=affd)
             del t2, idn
+            if self.block_hook is not None:   # study tools only (tools/h3_storage_study.py): a block output's storage format
+                x = self.block_hook(bi, x)
             hcur = hout
         return ops.global_avgpool(x, out, code=self.ecode)
 

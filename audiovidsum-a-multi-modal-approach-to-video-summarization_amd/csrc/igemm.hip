@@ -2010,7 +2010,7 @@ static int bnlocal_plan(const avs_conv_desc* d, int64_t rpg, IgemmParams& p, con
   const long long per_tile = 256 / rpg;
   const bool h2 = d->dtype == AVS_F16X2;
   const int es = h2 ? 4 : 2;
-  const bool ok = g_bnlocal && g_pipe3 && (d->dtype == AVS_BF16 || h2) && p.N % bn == 0 && p.M % rpg == 0 && rpg <= 256 &&
+  const bool ok = (g_bnlocal != 0) && (g_pipe3 != 0) && (d->dtype == AVS_BF16 || h2) && p.N % bn == 0 && p.M % rpg == 0 && rpg <= 256 &&
                   per_tile * rpg * 4 >= 256 * 3 && per_tile <= BNLOCAL_MAX_GROUPS && (long long)p.K * es > 128 &&
                   d->alpha == 1.0f && (p.ldc * es) % (h2 ? 32 : 16) == 0;
   AVS_REQUIRE(ok, AVS_E_UNSUPPORTED,

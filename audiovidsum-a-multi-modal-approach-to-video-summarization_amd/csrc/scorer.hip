@@ -388,3 +388,34 @@ extern "C" int avs_softmax_rows_f32(float* d_x, int64_t rows, int n, int64_t ldx
   AVS_CHECK_LAUNCH("avs_softmax_rows_f32");
   return AVS_OK;
 }
+
+// Backward of the row softmax, in place on the upstream gradient: ds[r, j] = alpha * p[r, j] * (dp[r, j] - sum_k p[r, k]
+// dp[r, k]) - the gradient with respect to the UNSCALED scores q.k of softmax(alpha * q.k) (models/attention.py:21-22).
+// One 256-thread block per row; the dot product by wave shuffle, the four waves added in a fixed order.
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __restrict__ p, float* __restrict__ dp,
+                                                               int n, long long ld, float alpha) {
+  __shared__ float red[4];
+  const float* prow = p + (long long)blockIdx.x * ld;
+  float* drow = dp + (long long)blockIdx.x * ld;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s = fmaf(prow[i], drow[i], s);
+  s = avs_wave_sum(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  s = (red[0] + red[1]) + (red[2] + red[3]);
+  for (int i = threadIdx.x; i < n; i += 256) drow[i] = alpha * prow[i] * (drow[i] - s);
+}
+
+extern "C" int avs_softmax_bwd_rows_f32(const float* d_p, float* d_dp, int64_t rows, int n, int64_t ld, float alpha,
+                                        avs_stream_t stream) {
+  AVS_REQUIRE(rows >= 0 && n > 0 && ld >= n, AVS_E_SHAPE, "avs_softmax_bwd_rows_f32: rows=%lld n=%d ld=%lld",
+              (long long)rows, n, (long long)ld);
+  if (rows == 0) return AVS_OK;
+  AVS_REQUIRE(d_p && d_dp, AVS_E_ARG, "avs_softmax_bwd_rows_f32: null pointer");
+  AVS_REQUIRE(rows < (1ll << 31), AVS_E_SHAPE, "avs_softmax_bwd_rows_f32: too many rows");
+  hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, d_p, d_dp, n,
+                     (long long)ld, alpha);
+  AVS_CHECK_LAUNCH("avs_softmax_bwd_rows_f32");
+  return AVS_OK;
+}

@@ -17,6 +17,13 @@ Same constructor, same sub-module names (query, key, value, out), batch-first
 
 The key axis is padded to a multiple of 4 columns (16-byte rows) with zeros;
 the softmax only touches the real T columns.
+
+Autograd (the reference class is an ordinary autograd module, attention.py:5-25; nothing in the reference trains it,
+SURVEY Q11): with gradients enabled ``forward`` goes through ``_MHSAFunction`` - the same forward kernels, and a
+backward made of C-ABI calls: the probabilities are RECOMPUTED per batch element (avs_gemm_nt + avs_softmax_rows_f32),
+dP = dctx.V^T, dS = alpha P (dP - rowsum(P dP)) (avs_softmax_bwd_rows_f32), dQ = dS.K, dK = dS^T.Q, dV = P^T.dctx as
+NT GEMMs on transposed copies (avs_transpose_f32), the projection gradients as in the scorer's backward
+(ops.grad_weight / grad_input / colsum).  The backward materialises [H, T, T] (it is a training path: T is a clip).
 """
 import math
 
@@ -46,8 +53,13 @@ class MultiHeadSelfAttention(nn.Module):
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("MultiHeadSelfAttention runs on the MI355X HIP path only: move inputs with .cuda()")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and x.requires_grad:
-            raise NotImplementedError("MultiHeadSelfAttention HIP path: autograd is not implemented yet")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return _MHSAFunction.apply(self, x, self.query.weight, self.query.bias, self.key.weight, self.key.bias,
+                                       self.value.weight, self.value.bias, self.out.weight, self.out.bias)
+        return self._forward(x)[0]
+
+    def _forward(self, x, keep=False):
+        """-> (out [B,T,E], (x2, q, k, ctx) when ``keep``)."""
         b, t, e = x.shape
         h, d = self.num_heads, self.dim_head
         if h * d != e:
@@ -64,7 +76,7 @@ class MultiHeadSelfAttention(nn.Module):
             # fused core: scores never materialised
             v = ops.linear(x2, self.value.weight, self.value.bias)
             ctx = ops.mhsa_flash(q, k, v, b, t, h, split=self.use_flash != "f32")
-            return ops.linear(ctx, self.out.weight, self.out.bias).view(b, t, e)
+            return ops.linear(ctx, self.out.weight, self.out.bias).view(b, t, e), ((x2, q, k, ctx) if keep else None)
         tp = (t + 3) // 4 * 4
         vt = torch.zeros((b, e, tp), dtype=torch.float32, device=dev)
         # V^T[b] [E, T] = W_v [E,E] . x[b] [T,E]^T + bias per row
@@ -81,4 +93,71 @@ class MultiHeadSelfAttention(nn.Module):
             ops.gemm_nt_batched(f32, t, d, tp, scores, 0, tp, t * tp, vt, bi * e * tp, tp, d * tp, ctx, bi * t * e, e, d,
                                 None, BIAS_NONE, 0, 1.0, ops.ACT_NONE, h)
         out = ops.linear(ctx, self.out.weight, self.out.bias)
-        return out.view(b, t, e)
+        return out.view(b, t, e), ((x2, q, k, ctx) if keep else None)
+
+
+class _MHSAFunction(torch.autograd.Function):
+    """forward = MultiHeadSelfAttention._forward; backward = C-ABI calls only (module docstring)."""
+
+    @staticmethod
+    def forward(ctx, mod, x, wq, bq, wk, bk, wv, bv, wo, bo):
+        out, (x2, q, k, att) = mod._forward(x.detach(), keep=True)
+        ctx.mod_dims = (x.shape, mod.num_heads, mod.dim_head, x.dtype)
+        ctx.save_for_backward(x2, q, k, att, wq, wk, wv, bv, wo)
+        return out.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, q, k, att, wq, wk, wv, bv, wo = ctx.saved_tensors
+        (b, t, e), h, d, xdtype = ctx.mod_dims
+        dev = x2.device
+        f32 = ops.dtype_code(torch.float32)
+        alpha = 1.0 / math.sqrt(d)
+        tp = (t + 3) // 4 * 4
+        dout2 = dout.reshape(b * t, e).float().contiguous()
+        v = ops.linear(x2, wv, bv)
+        g_wo = ops.grad_weight(dout2, att)
+        g_bo = ops.colsum(dout2)
+        datt = ops.grad_input(dout2, wo)                              # [B*T, E], heads side by side
+        dq = torch.empty((b * t, e), dtype=torch.float32, device=dev)
+        dk = torch.empty_like(dq)
+        dv = torch.empty_like(dq)
+        for bi in range(b):
+            o = bi * t * e
+            # P = softmax(alpha Q K^T), recomputed                                    attention.py:21-22
+            prob = torch.zeros((h, t, tp), dtype=torch.float32, device=dev)
+            ops.gemm_nt_batched(f32, t, t, d, q, o, e, d, k, o, e, d, prob, 0, tp, t * tp, None, BIAS_NONE, 0, alpha,
+                                ops.ACT_NONE, h)
+            ops.softmax_rows(prob, h * t, t, tp)
+            # dP = dctx . V^T                                                          attention.py:23
+            dp = torch.zeros((h, t, tp), dtype=torch.float32, device=dev)
+            ops.gemm_nt_batched(f32, t, t, d, datt, o, e, d, v, o, e, d, dp, 0, tp, t * tp, None, BIAS_NONE, 0, 1.0,
+                                ops.ACT_NONE, h)
+            # transposed copies [E, T] of this batch element's dctx, K, Q (pad columns zero) and P^T per head
+            dattT = torch.zeros((e, tp), dtype=torch.float32, device=dev)
+            kT = torch.zeros((e, tp), dtype=torch.float32, device=dev)
+            qT = torch.zeros((e, tp), dtype=torch.float32, device=dev)
+            ops.transpose_into(datt, o, t, e, e, dattT, 0, tp)
+            ops.transpose_into(k, o, t, e, e, kT, 0, tp)
+            ops.transpose_into(q, o, t, e, e, qT, 0, tp)
+            probT = torch.zeros((h, t, tp), dtype=torch.float32, device=dev)
+            for hh in range(h):
+                ops.transpose_into(prob, hh * t * tp, t, t, tp, probT, hh * t * tp, tp)
+            # dV[h] = P[h]^T . dctx[h]
+            ops.gemm_nt_batched(f32, t, d, tp, probT, 0, tp, t * tp, dattT, 0, tp, d * tp, dv, o, e, d, None, BIAS_NONE,
+                                0, 1.0, ops.ACT_NONE, h)
+            # dS = alpha P (dP - rowsum(P dP)), in place on dP
+            ops.softmax_bwd_rows(prob, dp, h * t, t, tp, alpha)
+            # dQ[h] = dS[h] . K[h];  dK[h] = dS[h]^T . Q[h]                            attention.py:21
+            ops.gemm_nt_batched(f32, t, d, tp, dp, 0, tp, t * tp, kT, 0, tp, d * tp, dq, o, e, d, None, BIAS_NONE, 0,
+                                1.0, ops.ACT_NONE, h)
+            for hh in range(h):   # probT's storage is free again: dS^T
+                ops.transpose_into(dp, hh * t * tp, t, t, tp, probT, hh * t * tp, tp)
+            ops.gemm_nt_batched(f32, t, d, tp, probT, 0, tp, t * tp, qT, 0, tp, d * tp, dk, o, e, d, None, BIAS_NONE, 0,
+                                1.0, ops.ACT_NONE, h)
+        need = ctx.needs_input_grad
+        dx = None
+        if need[1]:
+            dx = (ops.grad_input(dq, wq) + ops.grad_input(dk, wk) + ops.grad_input(dv, wv)).view(b, t, e).to(xdtype)
+        return (None, dx, ops.grad_weight(dq, x2), ops.colsum(dq), ops.grad_weight(dk, x2), ops.colsum(dk),
+                ops.grad_weight(dv, x2), ops.colsum(dv), g_wo, g_bo)

@@ -870,6 +870,21 @@ def softmax_rows(x, rows, n, ldx):
     return x
 
 
+def softmax_bwd_rows(p, dp, rows, n, ld, alpha):
+    """dp <- alpha * p * (dp - rowsum(p * dp)), in place: the softmax backward w.r.t. the unscaled scores."""
+    _f32(p, "p")
+    _f32(dp, "dp")
+    check(lib().avs_softmax_bwd_rows_f32(_p(p), _p(dp), rows, n, ld, float(alpha), _stream()),
+          "avs_softmax_bwd_rows_f32")
+    return dp
+
+
+def transpose_into(src, src_off, rows, cols, ld_src, dst, dst_off, ld_dst):
+    """dst[c, r] = src[r, c] on raw element offsets (pad columns of dst are left as they are)."""
+    check(lib().avs_transpose_f32(_p(src, src_off), rows, cols, ld_src, _p(dst, dst_off), ld_dst, _stream()),
+          "avs_transpose_f32")
+
+
 # --------------------------------------------------------------------------- scorer backward
 def transpose_padded(x2d, pad=4):
     """[rows, cols] fp32 -> [cols, rows_p] with rows_p = rows rounded up to `pad`, the tail columns zero."""

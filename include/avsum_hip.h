@@ -474,6 +474,11 @@ int avs_mhsa_flash_f16x2(const void* d_q, const void* d_k, const void* d_v, int6
  * (torch.softmax(dim=-1) at models/attention.py:22).                         */
 int avs_softmax_rows_f32(float* d_x, int64_t rows, int n, int64_t ldx,
                          avs_stream_t stream);
+/* Backward of that softmax, in place on the upstream gradient: dp[r, j] <- alpha * p[r, j] * (dp[r, j] -
+ * sum_k p[r, k] dp[r, k]), the gradient with respect to the unscaled scores of softmax(alpha * q.k^T)
+ * (autograd through models/attention.py:21-22; the reference class is an ordinary autograd module).       */
+int avs_softmax_bwd_rows_f32(const float* d_p, float* d_dp, int64_t rows, int n, int64_t ld, float alpha,
+                             avs_stream_t stream);
 
 /* ---- scorer backward (K22; scripts/train_av_model.py:86-96) ------------------ */
 /* The dense parts of the backward reuse avs_gemm_nt on transposed copies (dX = dY.W uses W^T as the [N,K]

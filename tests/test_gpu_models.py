@@ -175,6 +175,49 @@ def test_mhsa(dev, e, h, b, t):
     assert (got3 - ref).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("e,h,b,t,flash", [(512, 8, 2, 77, True), (1024, 4, 1, 300, True), (64, 4, 3, 5, True),
+                                           (256, 4, 1, 129, "f32"), (96, 4, 2, 31, False), (512, 4, 1, 1, True)])
+def test_mhsa_backward(dev, e, h, b, t, flash):
+    """Autograd through MultiHeadSelfAttention (reference: an ordinary autograd module, models/attention.py:5-25):
+    the gradients of the input and of all 8 parameters against torch autograd through the oracle's forward (pinned to
+    the reference class in tests/test_oracle_pins.py), <= 1e-4 relative to each tensor's largest entry."""
+    from avsum_amd.models.attention import MultiHeadSelfAttention
+    from oracle import scorer as osc
+    torch.manual_seed(13)
+    m = MultiHeadSelfAttention(e, h)
+    x = torch.randn(b, t, e, generator=torch.Generator().manual_seed(t + e))
+    gout = torch.randn(b, t, e, generator=torch.Generator().manual_seed(3))
+    sd = {k_: v_.detach().clone().requires_grad_(True) for k_, v_ in m.state_dict().items()}
+    xr = x.clone().requires_grad_(True)
+    ref = osc.mhsa_forward(sd, xr, h)
+    ref.backward(gout)
+    md = m.to(dev)
+    md.use_flash = flash
+    xd = x.to(dev).requires_grad_(True)
+    got = md(xd)
+    assert got.requires_grad and (got.detach().cpu() - ref.detach()).abs().max().item() < 1e-4
+    got.backward(gout.to(dev))
+
+    def close(a, r, name):
+        err = (a.cpu() - r).abs().max().item()
+        # (key.bias: its gradient is analytically zero - the softmax is invariant to a shift of all keys' scores - and
+        #  both sides hold rounding noise of ~1e-7 there: hence the absolute floor of 1e-6)
+        assert err <= 1e-4 * max(r.abs().max().item(), 1e-2), (name, err, r.abs().max().item())
+
+    close(xd.grad, xr.grad, "x")
+    for name, prm in md.named_parameters():
+        close(prm.grad, sd[name].grad, name)
+    # parameters frozen: the input gradient alone; input without grad: the parameter gradients alone
+    for prm in md.parameters():
+        prm.grad = None
+        prm.requires_grad_(False)
+    xd2 = x.to(dev).requires_grad_(True)
+    md(xd2).backward(gout.to(dev))
+    close(xd2.grad, xr.grad, "x (frozen parameters)")
+    with torch.no_grad():
+        assert not md(x.to(dev)).requires_grad
+
+
 def _frames(n, seed, h=224, w=224):
     return np.random.default_rng(seed).integers(0, 256, (n, h, w, 3), dtype=np.uint8)
 
