@@ -27,6 +27,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "avsum_hip.h")
 AVS_F32, AVS_BF16, AVS_F32_ACC64, AVS_F32_SPLIT, AVS_F16X2 = 0, 1, 2, 3, 4
 AVS_W_ROWS, AVS_W_KSTEP32 = 0, 1
 TILE_AUTO, TILE_128, TILE_256, TILE_224, STAGING_GENERIC = 0, 1, 2, 3, 4      # avs_conv_desc.variant
+X_F16P8, Y_F16P8, RES_F16P8 = 1, 2, 4                                         # avs_conv_desc.formats
 LSTM_AUTO, LSTM_STREAM, LSTM_RESIDENT_20_8, LSTM_RESIDENT_16_8 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU = 0, 1
 BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
@@ -46,7 +47,7 @@ class ConvDesc(ctypes.Structure):
         ("ho", c_int), ("wo", c_int), ("cout", c_int),
         ("x_img_stride", c_int64), ("x_row_stride", c_int64), ("x_px_stride", c_int64),
         ("w_row_stride", c_int64), ("y_px_stride", c_int64),
-        ("act", c_int), ("alpha", c_float), ("w_layout", c_int), ("variant", c_int),
+        ("act", c_int), ("alpha", c_float), ("w_layout", c_int), ("variant", c_int), ("formats", c_int),
     ]
 
 
@@ -57,6 +58,8 @@ _SIGNATURES = {
     "avs_device_info": (c_int, [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int64), c_char_p, c_int]),
     "avs_f16x2_pack_f32": (c_int, [P, P, c_int64, P]),
     "avs_f16x2_unpack_f32": (c_int, [P, P, c_int64, P]),
+    "avs_f16p8_pack_f32": (c_int, [P, P, c_int64, P]),
+    "avs_f16p8_unpack_f32": (c_int, [P, P, c_int64, P]),
     "avs_conv2d_nhwc": (c_int, [POINTER(ConvDesc), P, P, P, P, P]),
     "avs_conv2d_bnstats_workspace_bytes": (c_int64, [POINTER(ConvDesc), c_int64]),
     "avs_conv2d_nhwc_bnstats": (c_int, [POINTER(ConvDesc), P, P, P, c_int64, P, P, c_float, P, P, P, c_int64, P]),
@@ -155,8 +158,8 @@ def lib():
         fn = getattr(handle, name)
         fn.restype = res
         fn.argtypes = args
-    if handle.avs_abi_version() != 2:
-        raise AvsError(f"ABI version mismatch: library reports {handle.avs_abi_version()}, binding expects 2")
+    if handle.avs_abi_version() != 3:
+        raise AvsError(f"ABI version mismatch: library reports {handle.avs_abi_version()}, binding expects 3")
     if STUDY and os.environ.get("AVS_TUNE_CONVBN_NARROW") is not None:
         handle.avs_tune_convbn_narrow(int(os.environ["AVS_TUNE_CONVBN_NARROW"]))
     if STUDY and os.environ.get("AVS_TUNE_PIPELINE") is not None:  # kernel-study override of the library default

@@ -146,6 +146,10 @@ class ResNet50Runner:
         self.defer_res_apply = True  # the downsample's BatchNorm applied inside conv3's residual add (layer 2's first block)
         self.gram_finish_min_k = 128  # >= this many input channels: the Gram kernel stores the finished input in place, so
                                       # the convolution pass (N / 128 column slabs) does not transform it per slab
+        self.stats_1x1_variant = 0   # tile override of the 1x1 convolution + statistics form (study: _abi.TILE_128 / TILE_256)
+        self.p8_blocks = (0, 1, 3, 4, 5) if self.h2 else ()   # AVS_F16X2: the outputs of these bottlenecks (the inner
+                                     # blocks of layers 1-2, whose consumers are the next block's conv1 and residual add - both
+                                     # HBM-bound) are stored as AVS_F16P8: fp16 hi + 8-bit remainder, 3 instead of 4 bytes
         self._key = None
         self._w = None
         self._plans = {}     # (n, group frames) -> per layer: does it take the tile-local form
@@ -244,14 +248,16 @@ class ResNet50Runner:
                 and cout >= 2 * cin and gmax >= self.fuse_min_rows)
 
     def _conv_bn(self, geom, xs, x, wt, bnp, groups, residual=None, relu=True, local=False, algo_k=None, pool=None,
-                 defer=False, in_affine=None, res_affine=None):
+                 defer=False, in_affine=None, res_affine=None, out_p8=False):
         """One convolution + BatchNorm (+ residual, + ReLU) -> NHWC activation; picks the form (class docstring).
         pool = (k, s, p): a max pooling follows (the stem) - on the split form it is fused with the BatchNorm apply
         (avs_bn_maxpool_nhwc: the normalised full-resolution map is never written).
         defer: return (raw convolution, (scale, shift)) WITHOUT applying the BatchNorm - the next layer's two-pass
         kernel applies it while staging its input (in_affine), so this layer needs no apply pass (bf16, equal groups).
         res_affine: the residual is a deferred (raw) downsample output; its BatchNorm rides in this layer's residual add
-        (one-pass 1x1 form only)."""
+        (one-pass 1x1 form only).
+        out_p8: the output as an AVS_F16P8 tensor (ops.P8; the one-pass 1x1 form only - the caller has checked that the
+        layer takes it); x / residual may be P8 tensors where the forms that read them take that format."""
         n, ho, wo, cout = geom[0], geom[10], geom[11], geom[12]
         cin, kh, sh = geom[3], geom[4], geom[6]
         dev, dt = x.device, self.dtype
@@ -263,6 +269,8 @@ class ResNet50Runner:
 
         def conv(**kw):
             wsel, layout = wt.conv_operand()
+            if kh == 1 and "bnstats" in kw and self.stats_1x1_variant:
+                kw["variant"] = self.stats_1x1_variant
             return ops.conv2d_raw(dcode, *geom, x, *xs, wsel, wsel.stride(0), y, cout, algo_k=algo_k,
                                   algo_in_elems=x.numel() if algo_k is not None else None, w_layout=layout, **kw)
 
@@ -304,9 +312,13 @@ class ResNet50Runner:
             x2d = x.view(-1, cin)
             sc, sf = ops.bn_gram_affine_h2(x2d, wt.rows, gmax, gamma, beta, eps, in_affine, store_input=in_affine is not None)
             wsel, layout = wt.conv_operand()
+            if out_p8:
+                y = ops.P8.empty((n, ho, wo, cout), dev)
             ops.conv2d_affine(dcode, n, geom[1], geom[2], cin, sh, geom[7], ho, wo, cout, x, *xs, wsel, wsel.stride(0), y, cout,
                               gmax, sc, sf, residual, relu, res_affine, w_layout=layout)
             return y
+        if out_p8 or isinstance(residual, ops.P8):
+            raise RuntimeError("an AVS_F16P8 output / residual belongs to the one-pass 1x1 form")
         if in_affine is not None or (fast and bf16 and self._twopass_ok(cin, cout, kh, sh, gmax)):
             # statistics from the input's Gram matrix + ONE streaming pass where the shape allows it (the expanding
             # 1x1 layers of layers 1-2), else the two-pass kernel
@@ -323,6 +335,8 @@ class ResNet50Runner:
             # statistics from the convolution's epilogue: per-tile partial sums of the fp32 accumulators, folded in
             # tile order (E[x^2]-E[x]^2: fine for bf16 activations); None = groups too small for that form
             affine = conv(bnstats=(gmax, gamma, beta, eps))
+        if affine is None and isinstance(x, ops.P8):
+            raise RuntimeError("an AVS_F16P8 input belongs to the convolution + statistics form")
         if affine is None:
             # fp32 parity mode / ragged groups / tiny groups (the fused form declined before launching anything):
             # plain convolution, then the shifted statistics pass over the stored output
@@ -453,10 +467,14 @@ class ResNet50Runner:
                     idn, affd = idn
                 idn = idn.view(-1, planes * 4)
             else:
-                idn = x.view(-1, cin)
+                idn = x if isinstance(x, ops.P8) else x.view(-1, cin)
             geom, xs, _ = self._nhwc_geom(n, hout, planes, 1, 1, 0, planes * 4)
+            # 3-byte storage of this block's output: conv3 is the one-pass form here and so is the next block's (same
+            # layer), whose conv1 is the convolution + statistics form on dense rows
+            p8 = (bi in self.p8_blocks and self.bn_mode == "batch" and uniform and not s3 and self.block_hook is None
+                  and (aff2 is not None or self._gram_h2_ok(planes, planes * 4, 1, 1, gmax3)) and (planes * 4) % 32 == 0)
             x = self._conv_bn(geom, xs, t2, blk["c3"], blk["b3"], groups, residual=idn, relu=True, local=s3,
-                              in_affine=aff2, res_affine=affd)
+                              in_affine=aff2, res_affine=affd, out_p8=p8)
             del t2, idn
             if self.block_hook is not None:   # study tools only (tools/h3_storage_study.py): a block output's storage format
                 x = self.block_hook(bi, x)

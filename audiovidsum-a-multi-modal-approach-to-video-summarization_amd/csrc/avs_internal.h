@@ -103,6 +103,64 @@ __device__ __forceinline__ void avs_f16x2_join8(const uint4& hi, const uint4& lo
     v[2 * j + 1] = hb + lb;
   }
 }
+// ---- AVS_F16P8: fp16 hi + an 8-BIT remainder, 3 bytes per value (the wide block outputs of ResNet layers 1-2, which
+// run at the HBM roofline of their dataflow: bytes per stored value are the lever there).  x ~ hi + (u - 128) * step(hi),
+// hi = fp16(x), step(hi) = 2^(frexp_exp(hi) - 19) = ulp(hi) / 256 for a normal hi, u = round((x - hi) / step) + 128
+// clamped to 1..255: 19-20 significant bits (tools/h3_storage_study.py: the scores do not move).  Every aligned run of
+// 16 channels is 48 bytes: the 8 hi halves of channels 0-7, the 8 hi halves of channels 8-15, the 16 remainder bytes.
+__device__ __forceinline__ float avs_ubyte(unsigned w, int k) { return (float)((w >> (8 * k)) & 0xffu); }   // v_cvt_f32_ubyteK
+__device__ __forceinline__ float avs_f16p8_lo(float hf, float uf) {
+  // (u - 128) * 2^(e - 19): one fma + one ldexp (exact: a small integer times a power of two)
+  return ldexpf(fmaf(uf, 1.9073486328125e-06f, -2.44140625e-04f), __builtin_amdgcn_frexp_expf(hf));
+}
+// 8 fp32 -> the 16 bytes of hi halves and the 8 remainder bytes
+__device__ __forceinline__ void avs_f16p8_split8(const float (&v)[8], uint4& hi, uint2& rem) {
+  unsigned h[4], r[2] = {0u, 0u};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a = fminf(fmaxf(v[2 * j], -AVS_F16_MAX), AVS_F16_MAX);
+    const float b = fminf(fmaxf(v[2 * j + 1], -AVS_F16_MAX), AVS_F16_MAX);
+    h[j] = avs_pack_f16x2(a, b);
+    float ha, hb;
+    avs_unpack_f16x2(h[j], ha, hb);
+    // u in 1..255, i.e. |u - 128| <= 127 < half an ulp of hi in steps: fp16(decoded value) == hi always, so a stored
+    // value has ONE representation and AVS_F16X2 holds it with the same hi (a remainder within half a step of +-half
+    // an ulp - a near-tie of the fp16 rounding - is stored one step short: 2^-18 relative at worst)
+    const float qa = fmaxf(rintf(ldexpf(a - ha, 19 - __builtin_amdgcn_frexp_expf(ha))) + 128.f, 1.f);
+    const float qb = fmaxf(rintf(ldexpf(b - hb, 19 - __builtin_amdgcn_frexp_expf(hb))) + 128.f, 1.f);
+    // (v_cvt_pk_u8_f32 saturates at 255)
+    r[j >> 1] = __builtin_amdgcn_cvt_pk_u8_f32(qa, 2 * (j & 1), r[j >> 1]);
+    r[j >> 1] = __builtin_amdgcn_cvt_pk_u8_f32(qb, 2 * (j & 1) + 1, r[j >> 1]);
+  }
+  hi = make_uint4(h[0], h[1], h[2], h[3]);
+  rem = make_uint2(r[0], r[1]);
+}
+__device__ __forceinline__ void avs_f16p8_join8(const uint4& hi, const uint2& rem, float (&v)[8]) {
+  const unsigned h[4] = {hi.x, hi.y, hi.z, hi.w}, r[2] = {rem.x, rem.y};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float ha, hb;
+    avs_unpack_f16x2(h[j], ha, hb);
+    const float ua = (j & 1) ? avs_ubyte(r[j >> 1], 2) : avs_ubyte(r[j >> 1], 0);
+    const float ub = (j & 1) ? avs_ubyte(r[j >> 1], 3) : avs_ubyte(r[j >> 1], 1);
+    v[2 * j] = ha + avs_f16p8_lo(ha, ua);
+    v[2 * j + 1] = hb + avs_f16p8_lo(hb, ub);
+  }
+}
+// the fp16 lo halves (the matrix cores' second operand) of 8 values from their hi halves and remainder bytes
+__device__ __forceinline__ uint4 avs_f16p8_lo8(const uint4& hi, const uint2& rem) {
+  const unsigned h[4] = {hi.x, hi.y, hi.z, hi.w}, r[2] = {rem.x, rem.y};
+  unsigned l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float ha, hb;
+    avs_unpack_f16x2(h[j], ha, hb);
+    const float ua = (j & 1) ? avs_ubyte(r[j >> 1], 2) : avs_ubyte(r[j >> 1], 0);
+    const float ub = (j & 1) ? avs_ubyte(r[j >> 1], 3) : avs_ubyte(r[j >> 1], 1);
+    l[j] = avs_pack_f16x2(avs_f16p8_lo(ha, ua), avs_f16p8_lo(hb, ub));
+  }
+  return make_uint4(l[0], l[1], l[2], l[3]);
+}
 // element type tag of the elementwise kernels: ONE slot (4 bytes); only whole runs of 8 are ever loaded or stored
 struct avs_h2_tag { unsigned bits; };
 

@@ -114,10 +114,22 @@ __device__ __forceinline__ void avs_split_bf16(const float4& p0, const float4& p
 // frames).  Only the weights of a (block, tap) are fetched per step (a ring of three).  L2 -> LDS traffic of the A
 // operand / 9: for the 64-column layers, which sit at the L2 -> LDS intake ceiling (~21 B / clk / CU) with the matrix
 // cores 37 % busy.  The reduction runs block-major / tap-minor: another (fixed) summation order than the tap-major walk.
+// AP8 (AVS_F16X2 convolution + statistics, 1x1 on dense rows, 256-row tiles: conv1 of the ResNet bottlenecks in layers
+// 1-2): the input is an AVS_F16P8 tensor (fp16 hi + 8-bit remainder, 48 bytes per 16 channels).  The LDS-DMA staging is
+// the AVS_F16X2 one with other source offsets: of the four 16-byte slots of an LDS row, slot "hi 0-7" takes the block's
+// first 16 bytes, slot "hi 8-15" its second, slot "lo 0-7" the 16 remainder bytes and slot "lo 8-15" nothing (an
+// out-of-range lane), and a step advances the source by 48 instead of 64 bytes: 3 instead of 4 bytes per input value from
+// HBM, the same LDS image for the hi fragments.  A lane reads its 8 remainder bytes with one ds_read_b64 and rebuilds the
+// fp16 lo fragment in registers (5 VALU operations per value, behind the hi*hi MFMAs of the step).  (A first version
+// fetched the A fragments straight into registers - a wave owns its 64 rows for all columns on these tiles, nothing is
+// shared - with buffer_load_dwordx4 + dwordx2 per lane: 19 - 25 % SLOWER than the AVS_F16X2 path, 16-byte pieces of 32
+// rows per instruction; removed.)
 template <int ES, int BN, bool ACC64, bool SPATIAL, int ROWB, int EPI, bool PIPE, int WR = 2, bool FASTK = false,
-          int SPLIT = 0, bool TAP9 = false>
+          int SPLIT = 0, bool TAP9 = false, bool AP8 = false>
 __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64 && ES == 2) ? 4 : 3) : 2) void igemm_kernel(
     IgemmParams p) {
+  static_assert(!AP8 || (SPLIT == 2 && ES == 4 && PIPE && ROWB == 64 && FASTK && !SPATIAL && !TAP9 && EPI == EPI_STATS),
+                "AVS_F16P8 input: the AVS_F16X2 1x1 convolution + statistics on the pipelined tiles");
   static_assert(!TAP9 || (((SPLIT == 2 && ES == 4) || (SPLIT == 0 && ES == 2)) && PIPE && WR == 4 && ROWB == 64 && FASTK &&
                           SPATIAL && (EPI == EPI_STATS || EPI == EPI_BNLOCAL)),
                 "the nine-tap form: AVS_F16X2 / bf16 convolution + statistics / tile-local BatchNorm on the pipelined 256-row tiles");
@@ -260,7 +272,7 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
       n_first = m0 / p.HoWo;
       a_origin = (long long)n_first * p.x_img_stride - (long long)p.ph * p.x_row_stride - (long long)p.pw * p.x_px_stride;
     }
-    a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(x) + a_origin * ES, 0, (int)BUF_OOB, 0x00020000);
+    a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(x) + a_origin * (AP8 ? 3 : ES), 0, (int)BUF_OOB, 0x00020000);
     b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(w) + (p.w_kstep ? (long long)n0 * 64 : (long long)n0 * p.ldb * ES), 0, (int)BUF_OOB, 0x00020000);
 #pragma unroll
@@ -271,7 +283,12 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
         if (rb + RPP * i >= p.tile_rows) m = p.M;
       }
       if (a_base[i] != nullptr && m < p.M) {
-        if (p.lin_stride >= 0) {
+        if (AP8) {
+          // AVS_F16P8 rows: slot "hi 0-7" <- bytes 0-15 of the 48-byte block, "lo 0-7" <- the remainder bytes (32-47),
+          // "hi 8-15" <- bytes 16-31, "lo 8-15" <- nothing
+          mk = ~0u;
+          off = cq == 3 ? BUF_OOB : (unsigned)((long long)(m - m0) * p.lin_stride * 3) + (cq == 0 ? 0u : cq == 1 ? 32u : 16u);
+        } else if (p.lin_stride >= 0) {
           mk = ~0u;
           off = AVS_DEBUG_BIT(p, 64) ? (unsigned)((m - m0) * ROWB) + cq * 16
                                      : (unsigned)((long long)(m - m0) * p.lin_stride * ES) + cq * 16;
@@ -322,7 +339,7 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
       f_kb += p.w_kstep ? p.N * ROWB : BKE * ES;   // (ROWB / 64 pieces of N x 64 bytes per step)
       // next step (scalar): the same tap's next channel block, or the next tap
       f_ci0 += BKE;
-      f_koff += AVS_DEBUG_BIT(p, 64) ? p.M * ROWB : BKE * ES;
+      f_koff += AP8 ? 48 : (AVS_DEBUG_BIT(p, 64) ? p.M * ROWB : BKE * ES);
       if (f_ci0 == p.cin) {
         f_ci0 = 0;
         ++f_tap;
@@ -588,10 +605,21 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
       __builtin_amdgcn_s_barrier();
       const unsigned bbase = lds_base + (unsigned)cur * (BUF * 16u);
       uint4 fa[KS][2], fb[KS][NT];
+      uint2 frem[AP8 ? 2 : 1];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) fa[ks][mt] = avs_lds_read_b128(bbase + fa_off[mt][ks]);
+        for (int mt = 0; mt < 2; ++mt) {
+          if constexpr (AP8) {
+            // sub-step 1 of an AVS_F16P8 row: this lane half's 8 remainder bytes (the slot "lo 0-7" holds all 16)
+            if (ks == 1) {
+              const int row = wr * 64 + mt * 32 + lr;
+              frem[mt] = avs_lds_read_b64(bbase + (unsigned)(row * CPRR + (1 ^ ((row >> SH) & (CPRR - 1)))) * 16u + 8u * lh);
+              continue;
+            }
+          }
+          fa[ks][mt] = avs_lds_read_b128(bbase + fa_off[mt][ks]);
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) fb[ks][nt] = avs_lds_read_b128(bbase + fb_off[nt][ks]);
       }
@@ -623,11 +651,19 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
                                                                    __builtin_bit_cast(avs_f16x8, fb[kp][nt]),
                                                                    acc[mt][nt], 0, 0, 0);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if constexpr (AP8) {   // the fp16 lo fragments from the hi fragments and the remainder bytes
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt) avs_pin(fa[kp + 1][mt]);
+            for (int mt = 0; mt < 2; ++mt) {
+              avs_pin2(frem[mt]);
+              fa[kp + 1][mt] = avs_f16p8_lo8(fa[kp][mt], frem[mt]);
+            }
+          } else {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) avs_pin(fa[kp + 1][mt]);
+          }
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) avs_pin(fb[kp + 1][nt]);
-          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (!AP8) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -882,6 +918,11 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
     const int col8 = n0 + wc * WCOLS + grp * 8;
     const int row_lim = (EPI == EPI_BNLOCAL ? m0 + used : p.M);   // rows at or past this one do not exist
     const bool col_ok = col8 < p.N;
+    // AVS_F16P8 (output / residual of the given-affine form): byte offset of this lane's run of 8 columns inside a row -
+    // 48 bytes per 16 columns: hi halves of columns 0-7 | of columns 8-15 | the 16 remainder bytes - and from its hi
+    // halves to its remainder bytes
+    const int p8_hi = (col8 >> 4) * 48 + ((col8 >> 3) & 1) * 16;
+    const int p8_rem = 32 - ((col8 >> 3) & 1) * 8;
     // the residual rows of a half are in flight before that half is staged: one memory latency per half instead of one
     // per run.  Rows / columns that do not exist read the residual's first run (never used): no divergent branch
     // around the loads (and hipcc 7.2 crashes in machine copy propagation on a zero-filling else branch).
@@ -890,6 +931,19 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
       constexpr int mt = decltype(half)::value;
       if constexpr (NORM) {
         const long long row0 = (long long)m0 + wr * 64 + mt * 32 + rl0;
+        if (EPI == EPI_AFFINE && p.res_p8) {   // AVS_F16P8 residual: 16 bytes of hi halves + 8 remainder bytes per run
+          const char* base = p.residual + row0 * p.ldr * 3 + p8_hi;
+          const long long step = (long long)RSTEP * p.ldr * 3;
+#pragma unroll
+          for (int it = 0; it < NU; ++it) {
+            const bool ok = col_ok && row0 + it * RSTEP < row_lim;
+            const char* rp = ok ? base + it * step : p.residual + p8_hi;
+            rhi[mt][it] = *reinterpret_cast<const uint4*>(rp);
+            const uint2 q = *reinterpret_cast<const uint2*>(rp + p8_rem);
+            rlo[mt][it] = make_uint4(q.x, q.y, 0u, 0u);
+          }
+          return;
+        }
         const char* base = p.residual + (row0 * p.ldr + col8) * 4;
         const long long step = (long long)RSTEP * p.ldr * 4;
 #pragma unroll
@@ -1103,7 +1157,10 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
             //  residual run to floats right behind the loads and the 128-column tiles spill)
             avs_pin(rhi[mt][it]);
             avs_pin(rlo[mt][it]);
-            avs_f16x2_join8(rhi[mt][it], rlo[mt][it], rv);
+            if (EPI == EPI_AFFINE && p.res_p8)
+              avs_f16p8_join8(rhi[mt][it], make_uint2(rlo[mt][it].x, rlo[mt][it].y), rv);
+            else
+              avs_f16x2_join8(rhi[mt][it], rlo[mt][it], rv);
             if constexpr (EPI == EPI_AFFINE) {
               if (p.res_scale) {   // the residual is a raw convolution output: its BatchNorm rides in the add
                 const long long gq = (row / p.rows_per_group) * p.N + col8;
@@ -1124,6 +1181,15 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
           }
+        }
+        if (EPI == EPI_AFFINE && p.y_p8) {   // AVS_F16P8 output: 3 bytes per value
+          uint4 hi;
+          uint2 rem;
+          avs_f16p8_split8(v, hi, rem);
+          char* dst = y + (row * p.ldc) * 3 + p8_hi;
+          *reinterpret_cast<uint4*>(dst) = hi;
+          *reinterpret_cast<uint2*>(dst + p8_rem) = rem;
+          continue;
         }
         uint4 hi, lo;
         avs_f16x2_split8(v, hi, lo);
@@ -1592,6 +1658,13 @@ static void igemm_dispatch_epi4(int epi, dim3 grid, hipStream_t stream, const Ig
             return;
           }
         }
+        if constexpr (!SP && ROWB == 64 && PIPE && FK) {
+          if (p.x_p8) {   // AVS_F16P8 input (validated by igemm_launch): A fragments fetched into registers
+            hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE, WR, FK, 2, false, true>), grid, dim3(256), 0,
+                               stream, p);
+            return;
+          }
+        }
         hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE, WR, FK, 2>), grid, dim3(256), 0, stream, p);
       } else if (epi == EPI_BRELU)
         hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BRELU, PIPE, WR, FK, 2>), grid, dim3(256), 0, stream, p);
@@ -1777,6 +1850,21 @@ static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream
   // (short reductions, K <= 128: three 128-row workgroups per CU overlap their loops and their epilogue traffic better
   //  than two 256-row ones - l2.conv3 +5 %, l1.conv3 +2 %, bit-identical outputs)
   if (p.tile_rows) p.tall = 1;
+  // AVS_F16P8 operands: the input of the 1x1 convolution + statistics form on the 256-row tiles (A fragments in registers),
+  // the output / residual of the given-affine form
+  AVS_REQUIRE(!(p.y_p8 || p.res_p8) || (p.affine && p.N % 16 == 0 && p.ldc % 16 == 0 && p.ldr % 16 == 0), AVS_E_UNSUPPORTED,
+              "%s: an AVS_F16P8 output / residual is taken by avs_conv2d_nhwc_affine (cout and row strides in multiples of 16)", who);
+  if (p.x_p8) {
+    AVS_REQUIRE(p.stat_part && !p.tile_rows && !p.affine && batch == 1 && g_pipe3 && !(p.variant & AVS_STAGING_GENERIC) &&
+                    (p.tall || (long long)p.K * 4 <= g_rowb_threshold_bytes) &&   // (64-byte reduction steps)
+                    p.KW == 1 && p.K == p.cin && p.K % 32 == 0 && p.K >= 64 &&
+                    p.sh == 1 && p.sw == 1 && p.ph == 0 && p.pw == 0 && p.x_row_stride == (long long)p.Wo * p.x_px_stride &&
+                    p.x_img_stride == (long long)p.HoWo * p.x_px_stride && p.x_px_stride % 16 == 0 &&
+                    256 * p.x_px_stride * 3 + (long long)p.K * 3 < (1ll << 31),
+                AVS_E_UNSUPPORTED,
+                "%s: an AVS_F16P8 input is taken by avs_conv2d_nhwc_bnstats for 1x1 / stride-1 convolutions on dense rows, "
+                "cin a multiple of 32 (>= 64), the input row stride a multiple of 16", who);
+  }
   if (p.affine) {
     const int tile_mode = p.variant & 3;
     p.tall = (!narrow && (tile_mode == AVS_TILE_128 || (tile_mode == AVS_TILE_AUTO && p.K <= AVS_RULE_AFFINE_128_MAX_K))) ? 0 : 1;
@@ -1865,6 +1953,11 @@ static int conv_fill_params(const avs_conv_desc* d, const void* d_x, const void*
   p.w_kstep = d->w_layout == AVS_W_KSTEP32 ? 1 : 0;
   AVS_REQUIRE((d->variant & ~7) == 0, AVS_E_ARG, "%s: bad variant %d", who, d->variant);
   p.variant = d->variant;
+  AVS_REQUIRE((d->formats & ~(AVS_X_F16P8 | AVS_Y_F16P8 | AVS_RES_F16P8)) == 0, AVS_E_ARG, "%s: bad formats %d", who, d->formats);
+  AVS_REQUIRE(d->formats == 0 || d->dtype == AVS_F16X2, AVS_E_UNSUPPORTED, "%s: AVS_F16P8 operands belong to the AVS_F16X2 forms", who);
+  p.x_p8 = (d->formats & AVS_X_F16P8) ? 1 : 0;
+  p.y_p8 = (d->formats & AVS_Y_F16P8) ? 1 : 0;
+  p.res_p8 = (d->formats & AVS_RES_F16P8) ? 1 : 0;
   AVS_REQUIRE(!p.w_kstep || (d->dtype != AVS_F32_ACC64 && p.K % (d->dtype == AVS_BF16 ? 32 : 16) == 0), AVS_E_UNSUPPORTED,
               "%s: the reduction-step-major weight layout needs a reduction that is a multiple of a 64-byte step (K = %d)",
               who, p.K);

@@ -44,6 +44,9 @@ struct IgemmParams {
   const float* res_scale;
   const float* res_shift;
   int variant;       // avs_conv_desc.variant: AVS_TILE_128 / AVS_TILE_256 (bits 0-1), AVS_STAGING_GENERIC (bit 2)
+  // AVS_F16P8 operands of the AVS_F16X2 1x1 forms (avs_conv_desc.formats): the input of the convolution + statistics
+  // form (fetched into registers, the lo halves rebuilt there), the output / the residual of the given-affine form
+  int x_p8, y_p8, res_p8;
 #ifdef AVS_STUDY
   int debug;  // ablation switches of the kernel-study build (tools/): 1 = skip output stores, 2 = skip A/B loads, ...
 #endif
@@ -54,6 +57,7 @@ constexpr int BNLOCAL_MAX_GROUPS = 6;  // groups per 256-row tile (rows_per_grou
 constexpr int STATS_MIN_GROUP_ROWS = 64;  // EPI_STATS: a wave's 64 rows then overlap at most two groups
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // Passes a fragment THROUGH an empty asm: every later use of it depends on this statement, so it cannot be scheduled
 // ahead of the (volatile) wait that precedes the statement.
 __device__ __forceinline__ void avs_pin(uint4& v) {
@@ -62,6 +66,16 @@ __device__ __forceinline__ void avs_pin(uint4& v) {
   v = __builtin_bit_cast(uint4, r);
 }
 
+__device__ __forceinline__ void avs_pin2(uint2& v) {
+  u32x2 r = __builtin_bit_cast(u32x2, v);
+  asm volatile("" : "+v"(r));
+  v = __builtin_bit_cast(uint2, r);
+}
+__device__ __forceinline__ uint2 avs_lds_read_b64(unsigned byte_addr) {
+  uint2 v;
+  asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(byte_addr));
+  return v;
+}
 __device__ __forceinline__ uint4 avs_lds_read_b128(unsigned byte_addr) {
   uint4 v;
   asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(byte_addr));

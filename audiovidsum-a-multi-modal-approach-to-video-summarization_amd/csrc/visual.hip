@@ -143,6 +143,54 @@ extern "C" int avs_f16x2_unpack_f32(const void* d_src, float* d_dst, int64_t n, 
   return AVS_OK;
 }
 
+// fp32 <-> AVS_F16P8 (fp16 hi + 8-bit remainder: 48 bytes per 16 values; tests and tools)
+__global__ __launch_bounds__(256) void f16p8_pack_kernel(const float* __restrict__ src, char* __restrict__ dst, long long runs) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < runs; i += (long long)gridDim.x * blockDim.x) {
+    const float4 a = *reinterpret_cast<const float4*>(src + 8 * i), b = *reinterpret_cast<const float4*>(src + 8 * i + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint4 hi;
+    uint2 rem;
+    avs_f16p8_split8(v, hi, rem);
+    char* blk = dst + (i >> 1) * 48;
+    *reinterpret_cast<uint4*>(blk + (i & 1) * 16) = hi;
+    *reinterpret_cast<uint2*>(blk + 32 + (i & 1) * 8) = rem;
+  }
+}
+__global__ __launch_bounds__(256) void f16p8_unpack_kernel(const char* __restrict__ src, float* __restrict__ dst, long long runs) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < runs; i += (long long)gridDim.x * blockDim.x) {
+    const char* blk = src + (i >> 1) * 48;
+    float v[8];
+    avs_f16p8_join8(*reinterpret_cast<const uint4*>(blk + (i & 1) * 16), *reinterpret_cast<const uint2*>(blk + 32 + (i & 1) * 8), v);
+    *reinterpret_cast<float4*>(dst + 8 * i) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(dst + 8 * i + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+}
+
+extern "C" int avs_f16p8_pack_f32(const float* d_src, void* d_dst, int64_t n, avs_stream_t stream) {
+  AVS_REQUIRE(n >= 0 && n % 16 == 0, AVS_E_SHAPE, "avs_f16p8_pack_f32: n = %lld must be a multiple of 16", (long long)n);
+  if (n == 0) return AVS_OK;
+  AVS_REQUIRE(d_src && d_dst, AVS_E_ARG, "avs_f16p8_pack_f32: null pointer");
+  AVS_REQUIRE(avs_aligned16(d_src) && avs_aligned16(d_dst), AVS_E_ALIGN, "avs_f16p8_pack_f32: operands must be 16-byte aligned");
+  long long gx = avs_cdiv(n / 8, 256);
+  if (gx > 16384) gx = 16384;
+  hipLaunchKernelGGL(f16p8_pack_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, d_src, (char*)d_dst, n / 8);
+  AVS_CHECK_LAUNCH("avs_f16p8_pack_f32");
+  return AVS_OK;
+}
+
+extern "C" int avs_f16p8_unpack_f32(const void* d_src, float* d_dst, int64_t n, avs_stream_t stream) {
+  AVS_REQUIRE(n >= 0 && n % 16 == 0, AVS_E_SHAPE, "avs_f16p8_unpack_f32: n = %lld must be a multiple of 16", (long long)n);
+  if (n == 0) return AVS_OK;
+  AVS_REQUIRE(d_src && d_dst, AVS_E_ARG, "avs_f16p8_unpack_f32: null pointer");
+  AVS_REQUIRE(avs_aligned16(d_src) && avs_aligned16(d_dst), AVS_E_ALIGN, "avs_f16p8_unpack_f32: operands must be 16-byte aligned");
+  long long gx = avs_cdiv(n / 8, 256);
+  if (gx > 16384) gx = 16384;
+  hipLaunchKernelGGL(f16p8_unpack_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, (const char*)d_src, d_dst,
+                     n / 8);
+  AVS_CHECK_LAUNCH("avs_f16p8_unpack_f32");
+  return AVS_OK;
+}
+
 extern "C" int avs_frames_normalize_u8(int dtype, const uint8_t* d_src, int n, int h, int w, float denom,
                                        const float* mean3, const float* std3, const float* affine6, void* d_out,
                                        int out_h, int out_w, int pad_t, int pad_l, avs_stream_t stream) {

@@ -126,6 +126,46 @@ def f16x2_unpack(x):
     return out
 
 
+class P8:
+    """An AVS_F16P8 activation (fp16 hi + 8-bit remainder, 3 bytes per value; include/avsum_hip.h): ``data`` is the
+    uint8 image [rows, 3 * c], ``shape`` the logical NHWC shape.  Written by conv2d_affine(out_p8=...), read by it as a
+    residual and by conv2d_raw(bnstats=...) as the input (the wide block outputs of ResNet layers 1-2)."""
+
+    def __init__(self, data, shape):
+        self.data, self.shape = data, tuple(shape)
+
+    @property
+    def device(self):
+        return self.data.device
+
+    @classmethod
+    def empty(cls, shape, device):
+        rows = 1
+        for e in shape[:-1]:
+            rows *= e
+        if shape[-1] % 16:
+            raise ValueError("AVS_F16P8 needs a channel count that is a multiple of 16")
+        return cls(torch.empty((rows, 3 * shape[-1]), dtype=torch.uint8, device=device), shape)
+
+
+def f16p8_pack(x):
+    """fp32 [..., c] (contiguous, c a multiple of 16) -> P8 of the same logical shape."""
+    _dev(x)
+    _f32(x, "x")
+    if not x.is_contiguous() or x.shape[-1] % 16:
+        raise ValueError("f16p8_pack: contiguous fp32 tensor whose innermost extent is a multiple of 16")
+    out = P8.empty(x.shape, x.device)
+    check(lib().avs_f16p8_pack_f32(_p(x), _p(out.data), x.numel(), _stream()), "avs_f16p8_pack_f32")
+    return out
+
+
+def f16p8_unpack(t):
+    """The fp32 values of a P8 tensor."""
+    out = torch.empty(t.shape, dtype=torch.float32, device=t.device)
+    check(lib().avs_f16p8_unpack_f32(_p(t.data), _p(out), out.numel(), _stream()), "avs_f16p8_unpack_f32")
+    return out
+
+
 def _dev(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -226,15 +266,20 @@ def conv2d_raw(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x, x_i
     w_layout: _abi.AVS_W_ROWS (wt[cout, K]) or AVS_W_KSTEP32 (the image weights_kstep32() makes).
     variant: avs_conv_desc.variant (_abi.TILE_128 / TILE_256 | STAGING_GENERIC): a per-call override of the tile /
     staging choice, for tests and the study tools (the library has no global tuning state)."""
+    formats = 0
+    if isinstance(x, P8):   # AVS_F16P8 input: the 1x1 convolution + statistics form only (the library checks the shape)
+        if bnstats is None:
+            raise ValueError("an AVS_F16P8 input is taken by the convolution + statistics form (bnstats=...)")
+        x, formats = x.data, _abi.X_F16P8
     _dev(x, wt, y, bias)
     d = _abi.ConvDesc(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x_img_stride, x_row_stride,
-                      x_px_stride, w_row_stride, y_px_stride, act, float(alpha), int(w_layout), int(variant))
+                      x_px_stride, w_row_stride, y_px_stride, act, float(alpha), int(w_layout), int(variant), formats)
     flops = 2.0 * n * ho * wo * cout * (algo_k if algo_k is not None else kh * kw * cin)
     # algorithmic HBM bytes: the input map read once (the pixels a strided 1x1 skips are not needed), the output
     # written once (+ the residual read once); weights are negligible and L2-resident
     es = 2 if dtype == AVS_BF16 else 4
     touched = algo_in_elems if algo_in_elems is not None else n * (ho * wo if (kh == 1 and kw == 1) else h * w) * cin
-    cbytes = float(es) * (touched + n * ho * wo * cout)
+    cbytes = (3.0 if formats else float(es)) * touched + float(es) * n * ho * wo * cout
     if bnlocal is not None:
         rpg, gamma, beta, eps, residual = bnlocal
         _dev(gamma, beta, residual)
@@ -263,6 +308,8 @@ def conv2d_raw(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x, x_i
     groups = (rows + rpg - 1) // rpg
     need = lib().avs_conv2d_bnstats_workspace_bytes(ctypes.byref(d), int(rpg))
     if need == _abi.E_UNSUPPORTED:
+        if formats:
+            check(int(need), "avs_conv2d_bnstats_workspace_bytes")   # no other form reads an AVS_F16P8 input
         return None
     if need < 0:
         check(int(need), "avs_conv2d_bnstats_workspace_bytes")
@@ -452,26 +499,38 @@ def conv2d_affine(dtype, n, h, w, cin, sh, sw, ho, wo, cout, x, x_img_stride, x_
                   res_affine=None, w_layout=0, variant=0):
     """1x1 convolution + a GIVEN per-group affine (+ residual, + its affine, + ReLU) in one streaming pass
     (avs_conv2d_nhwc_affine, AVS_F16X2).  scale / shift fp32 [groups, cout]; residual f16x2 [rows, cout]."""
+    formats = 0
+    yout = y
+    if isinstance(y, P8):          # AVS_F16P8 output / residual: 3 bytes per value (strides stay in elements)
+        if y.shape[-1] != cout or y_px_stride != cout:
+            raise ValueError("an AVS_F16P8 output is dense [rows, cout]")
+        y, formats = y.data, formats | _abi.Y_F16P8
+    res_p8 = isinstance(residual, P8)
+    if res_p8:
+        if residual.shape[-1] != cout or residual.data.shape[0] != n * ho * wo:
+            raise ValueError("an AVS_F16P8 residual is dense [rows, cout]")
+        residual, formats = residual.data, formats | _abi.RES_F16P8
     _dev(x, wt, y, scale, shift, residual)
     d = _abi.ConvDesc(dtype, n, h, w, cin, 1, 1, sh, sw, 0, 0, ho, wo, cout, x_img_stride, x_row_stride, x_px_stride,
-                      w_row_stride, y_px_stride, ACT_RELU if relu else ACT_NONE, 1.0, int(w_layout), int(variant))
+                      w_row_stride, y_px_stride, ACT_RELU if relu else ACT_NONE, 1.0, int(w_layout), int(variant), formats)
     rows = n * ho * wo
     groups = (rows + rows_per_group - 1) // rows_per_group
     for a in (scale, shift):
         if a.dtype != torch.float32 or a.shape != (groups, cout) or not a.is_contiguous():
             raise ValueError("scale / shift must be contiguous fp32 [groups, cout]")
     rsc, rsh = res_affine if res_affine is not None else (None, None)
-    if residual is not None:
+    if residual is not None and not res_p8:
         _rowmajor2d(residual, "residual")
         if residual.shape != (rows, cout):
             raise ValueError("residual must be [rows, cout]")
+    ldr = 0 if residual is None else (cout if res_p8 else residual.stride(0))
     flops = 2.0 * rows * cout * cin
-    nbytes = 4.0 * (rows * cin + rows * cout * (2 if residual is not None else 1))
+    nbytes = (4.0 * rows * cin + (3.0 if formats & _abi.Y_F16P8 else 4.0) * rows * cout
+              + (0.0 if residual is None else (3.0 if res_p8 else 4.0) * rows * cout))
     _timed("conv", dtype, flops, lambda: check(
         lib().avs_conv2d_nhwc_affine(ctypes.byref(d), _p(x), _p(wt), _p(y), int(rows_per_group), _p(scale), _p(shift),
-                                     _p(residual), residual.stride(0) if residual is not None else 0, _p(rsc), _p(rsh),
-                                     _stream()), "avs_conv2d_nhwc_affine"), nbytes)
-    return y
+                                     _p(residual), ldr, _p(rsc), _p(rsh), _stream()), "avs_conv2d_nhwc_affine"), nbytes)
+    return yout
 
 
 def weights_kstep32(wt):

@@ -340,6 +340,8 @@ def main():
                          "small passes, nothing at 12288 frames)")
     ap.add_argument("--bn-local", default="on", choices=["on", "off"],
                     help="tuning: one-launch tile-local convolution + BatchNorm on the layers that take it")
+    ap.add_argument("--p8", default="on", choices=["on", "off"],
+                    help="tuning (f16x2): the inner block outputs of ResNet layers 1-2 stored as AVS_F16P8 (3 bytes per value)")
     ap.add_argument("--fuse", default=None, help="tuning: min_rows,ratio_num,ratio_den of the one-kernel conv+BN")
     args = ap.parse_args()
 
@@ -392,6 +394,8 @@ def main():
                   {k: v.clone() for k, v in extractor.inception.state_dict().items()} if use_inception else None)
     runner = extractor._resnet_runner
     runner.bn_local = args.bn_local == "on"
+    if args.p8 == "off":
+        runner.p8_blocks = ()
     if args.fuse is not None:
         runner.fuse_min_rows, runner.fuse_ratio_num, runner.fuse_ratio_den = [int(v) for v in args.fuse.split(",")]
     extractor = extractor.to(dev)

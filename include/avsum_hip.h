@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define AVS_ABI_VERSION 2
+#define AVS_ABI_VERSION 3
 
 enum {
   AVS_OK = 0,
@@ -80,6 +80,17 @@ int avs_device_info(int dev, int* cu_count, int* clock_khz, int64_t* hbm_bytes,
 int avs_f16x2_pack_f32(const float* d_src, void* d_dst, int64_t n, avs_stream_t stream);
 int avs_f16x2_unpack_f32(const void* d_src, float* d_dst, int64_t n, avs_stream_t stream);
 
+/* AVS_F16P8: a value as fp16 hi + an 8-BIT remainder, 3 bytes: x ~ hi + (u - 128) * step(hi), hi = fp16(x),
+ * step(hi) = ulp(hi) / 256 (2^(frexp exponent of hi - 19)), u = round((x - hi) / step) + 128 clamped to 1..255:
+ * 19-20 significant bits.  Every run of 16 values is 48 bytes: the hi halves of values 0-7, of values 8-15, the 16
+ * remainder bytes.  The storage format of the wide block outputs of ResNet layers 1-2 in the AVS_F16X2 trunk
+ * (features/extractors.py:29,65), which run at the HBM roofline of their dataflow: written by avs_conv2d_nhwc_affine
+ * (AVS_Y_F16P8), read as its residual (AVS_RES_F16P8) and as the input of avs_conv2d_nhwc_bnstats (AVS_X_F16P8), where
+ * the fp16 lo halves the matrix cores take are rebuilt in registers.  fp32 [n] <-> AVS_F16P8 [n], n a multiple of 16,
+ * both sides 16-byte aligned (tests, tools).                                                                      */
+int avs_f16p8_pack_f32(const float* d_src, void* d_dst, int64_t n, avs_stream_t stream);
+int avs_f16p8_unpack_f32(const void* d_src, float* d_dst, int64_t n, avs_stream_t stream);
+
 /* ---- dense contraction (K3, K6, K16-K20 of SURVEY §2.3) ------------------ */
 
 /* Implicit-GEMM 2-D convolution on NHWC activations, weights [cout][kh][kw][cin]:
@@ -118,8 +129,14 @@ typedef struct {
                              * 3x3 / stride-1 layers on the tap-major walk instead of the nine-tap form);
                              * AVS_STAGING_GENERIC (bit 2): the general per-lane gather staging even where
                              * the scalar tap walk applies.  Results do not depend on it beyond fp32 summation order. */
+  int formats;              /* 0, or AVS_F16P8 operands of the AVS_F16X2 1x1 forms (bits): AVS_X_F16P8 - the INPUT of
+                             * avs_conv2d_nhwc_bnstats (1x1 / stride 1 on dense rows, cin a multiple of 32, >= 64);
+                             * AVS_Y_F16P8 / AVS_RES_F16P8 - the OUTPUT / the RESIDUAL of avs_conv2d_nhwc_affine (cout and
+                             * the row strides multiples of 16).  Strides stay in elements; a row of c elements is 3 c
+                             * bytes.  Other combinations: AVS_E_UNSUPPORTED.                                           */
 } avs_conv_desc;
 enum { AVS_W_ROWS = 0, AVS_W_KSTEP32 = 1 };
+enum { AVS_X_F16P8 = 1, AVS_Y_F16P8 = 2, AVS_RES_F16P8 = 4 };
 enum { AVS_TILE_AUTO = 0, AVS_TILE_128 = 1, AVS_TILE_256 = 2, AVS_TILE_224 = 3, AVS_STAGING_GENERIC = 4 };
 
 int avs_conv2d_nhwc(const avs_conv_desc* desc, const void* d_x, const void* d_w,

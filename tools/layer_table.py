@@ -20,7 +20,13 @@ ap.add_argument("--gf", type=int, default=1)
 ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32split", "f32", "f16x2"])
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--set", action="append", default=[], help="runner attribute override, e.g. --set gram_finish_min_k=64")
+ap.add_argument("--p8", default="on", choices=["on", "off"], help="f16x2: AVS_F16P8 storage of the inner block outputs of layers 1-2")
+ap.add_argument("--short", type=int, default=0,
+                help="study build (AVS_STUDY_LIB=1): reductions of at most this many bytes per row take 64-byte steps (rule: 2048)")
 args = ap.parse_args()
+if args.short:
+    from avsum_amd import _abi
+    _abi.lib().avs_tune_short_reduction_bytes(args.short)
 dev = torch.device("cuda", 0)
 dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 es = 2 if dt == torch.bfloat16 else 4
@@ -34,6 +40,8 @@ if runner is None:
 for kv in args.set:
     k, v = kv.split("=")
     setattr(runner, k, type(getattr(runner, k))(int(v)))
+if args.p8 == "off":
+    runner.p8_blocks = ()
 frames = torch.randint(0, 256, (args.n, 224, 224, 3), dtype=torch.uint8, device=dev)
 gf = torch.arange(0, args.n + 1, args.gf, dtype=torch.int64)
 
