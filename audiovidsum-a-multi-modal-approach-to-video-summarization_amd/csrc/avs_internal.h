@@ -103,15 +103,24 @@ __device__ __forceinline__ void avs_f16x2_join8(const uint4& hi, const uint4& lo
     v[2 * j + 1] = hb + lb;
   }
 }
-// ---- AVS_F16P8: fp16 hi + an 8-BIT remainder, 3 bytes per value (the wide block outputs of ResNet layers 1-2, which
-// run at the HBM roofline of their dataflow: bytes per stored value are the lever there).  x ~ hi + (u - 128) * step(hi),
-// hi = fp16(x), step(hi) = 2^(frexp_exp(hi) - 19) = ulp(hi) / 256 for a normal hi, u = round((x - hi) / step) + 128
-// clamped to 1..255: 19-20 significant bits (tools/h3_storage_study.py: the scores do not move).  Every aligned run of
-// 16 channels is 48 bytes: the 8 hi halves of channels 0-7, the 8 hi halves of channels 8-15, the 16 remainder bytes.
-__device__ __forceinline__ float avs_ubyte(unsigned w, int k) { return (float)((w >> (8 * k)) & 0xffu); }   // v_cvt_f32_ubyteK
-__device__ __forceinline__ float avs_f16p8_lo(float hf, float uf) {
-  // (u - 128) * 2^(e - 19): one fma + one ldexp (exact: a small integer times a power of two)
-  return ldexpf(fmaf(uf, 1.9073486328125e-06f, -2.44140625e-04f), __builtin_amdgcn_frexp_expf(hf));
+// ---- AVS_F16P8: fp16 hi + an 8-BIT remainder, 3 bytes per value (the inner block outputs of ResNet layers 1-2).
+// x ~ hi + (u - 128) * step(hi), hi = fp16(x), step(hi) = ulp(max(|hi|, 2^-6)) / 256 = 2^(max(E, -6) - 18) with E the
+// exponent of hi (a step of 2^-24 - the fp16 grid - below 2^-6), u = round((x - hi) / step) + 128 clamped to 1..255
+// (u = 128 when hi = 0): 19-20 significant bits, the absolute floor of AVS_F16X2 (tools/h3_storage_study.py: the scores
+// do not move).  Every remainder (u - 128) * step IS an fp16 number - exactly the lo half AVS_F16X2 holds for the same
+// value - and is rebuilt with packed fp16 arithmetic: 3 VALU operations per value.  Every aligned run of 16 channels is
+// 48 bytes: the 8 hi halves of channels 0-7, the 8 hi halves of channels 8-15, the 16 remainder bytes.
+typedef unsigned short avs_u16x2 __attribute__((ext_vector_type(2)));
+// the fp16 lo halves of two values from their hi halves (one dword) and their remainder bytes k, k + 1 of `rem`
+__device__ __forceinline__ unsigned avs_f16p8_lo2(unsigned hi2, unsigned rem, int k) {
+  // 2^max(E, -6) of each half (the exponent field alone; denormals and zero count as 2^-6), times 2^-18 (an fp16 denormal)
+  const avs_u16x2 floor6 = {0x2400, 0x2400};
+  const avs_u16x2 hp = __builtin_elementwise_max(__builtin_bit_cast(avs_u16x2, hi2 & 0x7C007C00u), floor6);
+  const avs_f16x2v step = __builtin_bit_cast(avs_f16x2v, hp) * __builtin_bit_cast(avs_f16x2v, 0x00400040u);
+  // 0x6400 | u = 1024 + u as fp16; minus 1152 = u - 128, exactly
+  const unsigned q = __builtin_amdgcn_perm(rem, 0x64646464u, k == 0 ? 0x00050004u : 0x00070006u);
+  const avs_f16x2v qh = __builtin_bit_cast(avs_f16x2v, q) + __builtin_bit_cast(avs_f16x2v, 0xE480E480u);
+  return __builtin_bit_cast(unsigned, qh * step);
 }
 // 8 fp32 -> the 16 bytes of hi halves and the 8 remainder bytes
 __device__ __forceinline__ void avs_f16p8_split8(const float (&v)[8], uint4& hi, uint2& rem) {
@@ -123,11 +132,13 @@ __device__ __forceinline__ void avs_f16p8_split8(const float (&v)[8], uint4& hi,
     h[j] = avs_pack_f16x2(a, b);
     float ha, hb;
     avs_unpack_f16x2(h[j], ha, hb);
+    // frexp's exponent is E + 1 (0 for hi = 0, where the remainder rounds to zero whatever the step)
+    const int ea = max(__builtin_amdgcn_frexp_expf(ha), -5), eb = max(__builtin_amdgcn_frexp_expf(hb), -5);
     // u in 1..255, i.e. |u - 128| <= 127 < half an ulp of hi in steps: fp16(decoded value) == hi always, so a stored
-    // value has ONE representation and AVS_F16X2 holds it with the same hi (a remainder within half a step of +-half
-    // an ulp - a near-tie of the fp16 rounding - is stored one step short: 2^-18 relative at worst)
-    const float qa = fmaxf(rintf(ldexpf(a - ha, 19 - __builtin_amdgcn_frexp_expf(ha))) + 128.f, 1.f);
-    const float qb = fmaxf(rintf(ldexpf(b - hb, 19 - __builtin_amdgcn_frexp_expf(hb))) + 128.f, 1.f);
+    // value has ONE representation and AVS_F16X2 holds it with the same hi and lo (a remainder within half a step of
+    // +-half an ulp - a near-tie of the fp16 rounding - is stored one step short: 2^-18 relative at worst)
+    const float qa = fmaxf(rintf(ldexpf(a - ha, 19 - ea)) + 128.f, 1.f);
+    const float qb = fmaxf(rintf(ldexpf(b - hb, 19 - eb)) + 128.f, 1.f);
     // (v_cvt_pk_u8_f32 saturates at 255)
     r[j >> 1] = __builtin_amdgcn_cvt_pk_u8_f32(qa, 2 * (j & 1), r[j >> 1]);
     r[j >> 1] = __builtin_amdgcn_cvt_pk_u8_f32(qb, 2 * (j & 1) + 1, r[j >> 1]);
@@ -135,31 +146,13 @@ __device__ __forceinline__ void avs_f16p8_split8(const float (&v)[8], uint4& hi,
   hi = make_uint4(h[0], h[1], h[2], h[3]);
   rem = make_uint2(r[0], r[1]);
 }
-__device__ __forceinline__ void avs_f16p8_join8(const uint4& hi, const uint2& rem, float (&v)[8]) {
-  const unsigned h[4] = {hi.x, hi.y, hi.z, hi.w}, r[2] = {rem.x, rem.y};
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    float ha, hb;
-    avs_unpack_f16x2(h[j], ha, hb);
-    const float ua = (j & 1) ? avs_ubyte(r[j >> 1], 2) : avs_ubyte(r[j >> 1], 0);
-    const float ub = (j & 1) ? avs_ubyte(r[j >> 1], 3) : avs_ubyte(r[j >> 1], 1);
-    v[2 * j] = ha + avs_f16p8_lo(ha, ua);
-    v[2 * j + 1] = hb + avs_f16p8_lo(hb, ub);
-  }
-}
 // the fp16 lo halves (the matrix cores' second operand) of 8 values from their hi halves and remainder bytes
 __device__ __forceinline__ uint4 avs_f16p8_lo8(const uint4& hi, const uint2& rem) {
-  const unsigned h[4] = {hi.x, hi.y, hi.z, hi.w}, r[2] = {rem.x, rem.y};
-  unsigned l[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    float ha, hb;
-    avs_unpack_f16x2(h[j], ha, hb);
-    const float ua = (j & 1) ? avs_ubyte(r[j >> 1], 2) : avs_ubyte(r[j >> 1], 0);
-    const float ub = (j & 1) ? avs_ubyte(r[j >> 1], 3) : avs_ubyte(r[j >> 1], 1);
-    l[j] = avs_pack_f16x2(avs_f16p8_lo(ha, ua), avs_f16p8_lo(hb, ub));
-  }
-  return make_uint4(l[0], l[1], l[2], l[3]);
+  return make_uint4(avs_f16p8_lo2(hi.x, rem.x, 0), avs_f16p8_lo2(hi.y, rem.x, 2), avs_f16p8_lo2(hi.z, rem.y, 0),
+                    avs_f16p8_lo2(hi.w, rem.y, 2));
+}
+__device__ __forceinline__ void avs_f16p8_join8(const uint4& hi, const uint2& rem, float (&v)[8]) {
+  avs_f16x2_join8(hi, avs_f16p8_lo8(hi, rem), v);
 }
 // element type tag of the elementwise kernels: ONE slot (4 bytes); only whole runs of 8 are ever loaded or stored
 struct avs_h2_tag { unsigned bits; };

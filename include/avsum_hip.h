@@ -81,13 +81,14 @@ int avs_f16x2_pack_f32(const float* d_src, void* d_dst, int64_t n, avs_stream_t 
 int avs_f16x2_unpack_f32(const void* d_src, float* d_dst, int64_t n, avs_stream_t stream);
 
 /* AVS_F16P8: a value as fp16 hi + an 8-BIT remainder, 3 bytes: x ~ hi + (u - 128) * step(hi), hi = fp16(x),
- * step(hi) = ulp(hi) / 256 (2^(frexp exponent of hi - 19)), u = round((x - hi) / step) + 128 clamped to 1..255:
- * 19-20 significant bits.  Every run of 16 values is 48 bytes: the hi halves of values 0-7, of values 8-15, the 16
- * remainder bytes.  The storage format of the wide block outputs of ResNet layers 1-2 in the AVS_F16X2 trunk
- * (features/extractors.py:29,65), which run at the HBM roofline of their dataflow: written by avs_conv2d_nhwc_affine
- * (AVS_Y_F16P8), read as its residual (AVS_RES_F16P8) and as the input of avs_conv2d_nhwc_bnstats (AVS_X_F16P8), where
- * the fp16 lo halves the matrix cores take are rebuilt in registers.  fp32 [n] <-> AVS_F16P8 [n], n a multiple of 16,
- * both sides 16-byte aligned (tests, tools).                                                                      */
+ * step(hi) = ulp(max(|hi|, 2^-6)) / 256 (2^-24, the fp16 grid, below 2^-6), u = round((x - hi) / step) + 128 clamped to
+ * 1..255 (128 when hi = 0): 19-20 significant bits, the absolute floor of AVS_F16X2; every remainder is itself an fp16
+ * number - the lo half AVS_F16X2 holds for the same value.  Every run of 16 values is 48 bytes: the hi halves of
+ * values 0-7, of values 8-15, the 16 remainder bytes.  The storage format of the inner block outputs of ResNet layers
+ * 1-2 in the AVS_F16X2 trunk (features/extractors.py:29,65): written by avs_conv2d_nhwc_affine (AVS_Y_F16P8), read as
+ * its residual (AVS_RES_F16P8) and as the input of avs_conv2d_nhwc_bnstats (AVS_X_F16P8), where the fp16 lo halves the
+ * matrix cores take are rebuilt in registers (the same bits as the AVS_F16X2 input path gives on the same values).
+ * fp32 [n] <-> AVS_F16P8 [n], n a multiple of 16, both sides 16-byte aligned (tests, tools).                      */
 int avs_f16p8_pack_f32(const float* d_src, void* d_dst, int64_t n, avs_stream_t stream);
 int avs_f16p8_unpack_f32(const void* d_src, float* d_dst, int64_t n, avs_stream_t stream);
 
