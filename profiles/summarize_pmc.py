@@ -24,13 +24,15 @@ def load(path, counter):
         m = re.match(r"igemm_kernel<(\d+)(?:, [^,>]+)*?(?:, (\d+))?>", full)
         if m:
             name = f"igemm_kernel<{m.group(1)}>"
-            last = re.search(r", (\d+)(?:, (?:true|false))?>\(", full + "(")   # (a trailing bool: the nine-tap form)
+            last = re.search(r", (\d+)(?:, (?:true|false)){0,2}>\(", full + "(")   # (trailing bools: nine-tap form, AVS_F16P8 input)
             if m.group(1) == "4" and last and last.group(1) == "2":
                 name = "igemm_kernel<4,split2>"      # AVS_F16X2 convolutions (the last template argument)
                 v = re.match(r"igemm_kernel<(\d+), (\d+), \w+, (\w+), (\d+), (\d+)", full)
                 sub = f"igemm_kernel<4,split2,bn={v.group(2)},spatial={v.group(3)},epi={v.group(5)}>"
-                if re.search(r", 2, true>\(", full + "("):
+                if re.search(r", 2, true(?:, false)?>\(", full + "("):
                     sub = sub[:-1] + ",tap9>"
+                if re.search(r", 2, false, true>\(", full + "("):
+                    sub = sub[:-1] + ",p8in>"
                 agg[sub][0] += 1
                 agg[sub][1] += float(r["Counter_Value"])
         # round 3: the AVS_F16X2 tile-local form of 193..224-row groups runs on its own tile (csrc/local224.hip); it is

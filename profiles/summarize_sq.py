@@ -27,11 +27,13 @@ def main():
         m = re.match(r"igemm_kernel<(\d+), (\d+), \w+, (\w+), (\d+), (\d+)", full)
         if m:   # element size, column tile, spatial, row bytes, epilogue form
             name = f"igemm_kernel<es={m.group(1)},bn={m.group(2)},spatial={m.group(3)},epi={m.group(5)}>"
-            last = re.search(r", (\d+)(?:, (?:true|false))?>\(", full + "(")   # (a trailing bool: the nine-tap form)
+            last = re.search(r", (\d+)(?:, (?:true|false)){0,2}>\(", full + "(")   # (trailing bools: nine-tap form, AVS_F16P8 input)
             if m.group(1) == "4" and last and last.group(1) in ("1", "2"):
                 name = name[:-1] + f",split={last.group(1)}>"
-                if re.search(r", 2, true>\(", full + "("):
+                if re.search(r", 2, true(?:, false)?>\(", full + "("):
                     name = name[:-1] + ",tap9>"
+                if re.search(r", 2, false, true>\(", full + "("):
+                    name = name[:-1] + ",p8in>"
         m2 = re.match(r"igemm_h2_local224_kernel<(\w+)", full)
         if m2:   # the 224-row tile-local form (AVS_F16X2): spatial or not
             name = f"igemm_h2_local224_kernel<spatial={m2.group(1)}>"
