@@ -146,6 +146,7 @@ class ResNet50Runner:
         self.defer_res_apply = True  # the downsample's BatchNorm applied inside conv3's residual add (layer 2's first block)
         self.gram_finish_min_k = 128  # >= this many input channels: the Gram kernel stores the finished input in place, so
                                       # the convolution pass (N / 128 column slabs) does not transform it per slab
+        self.affine_variant = 0      # tile override of the one-pass 1x1 form (study: _abi.TILE_128 / TILE_256)
         self.stats_1x1_variant = 0   # tile override of the 1x1 convolution + statistics form (study: _abi.TILE_128 / TILE_256)
         self.p8_blocks = (0, 1, 3, 4, 5) if self.h2 else ()   # AVS_F16X2: the outputs of these bottlenecks (the inner
                                      # blocks of layers 1-2, whose consumers are the next block's conv1 and residual add - both
@@ -315,7 +316,7 @@ class ResNet50Runner:
             if out_p8:
                 y = ops.P8.empty((n, ho, wo, cout), dev)
             ops.conv2d_affine(dcode, n, geom[1], geom[2], cin, sh, geom[7], ho, wo, cout, x, *xs, wsel, wsel.stride(0), y, cout,
-                              gmax, sc, sf, residual, relu, res_affine, w_layout=layout)
+                              gmax, sc, sf, residual, relu, res_affine, w_layout=layout, variant=self.affine_variant)
             return y
         if out_p8 or isinstance(residual, ops.P8):
             raise RuntimeError("an AVS_F16P8 output / residual belongs to the one-pass 1x1 form")
