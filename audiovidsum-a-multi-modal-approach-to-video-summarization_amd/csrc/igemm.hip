@@ -1187,15 +1187,15 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
           uint2 rem;
           avs_f16p8_split8(v, hi, rem);
           char* dst = y + (row * p.ldc) * 3 + p8_hi;
-          __builtin_nontemporal_store(__builtin_bit_cast(u32x4, hi), reinterpret_cast<u32x4*>(dst));
-          __builtin_nontemporal_store(__builtin_bit_cast(u32x2, rem), reinterpret_cast<u32x2*>(dst + p8_rem));
+          *reinterpret_cast<uint4*>(dst) = hi;
+          *reinterpret_cast<uint2*>(dst + p8_rem) = rem;
           continue;
         }
         uint4 hi, lo;
         avs_f16x2_split8(v, hi, lo);
-        u32x4* dst = reinterpret_cast<u32x4*>(ybase + it * ystep);
-        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, hi), dst);
-        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, lo), dst + 1);
+        uint4* dst = reinterpret_cast<uint4*>(ybase + it * ystep);
+        dst[0] = hi;
+        dst[1] = lo;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
