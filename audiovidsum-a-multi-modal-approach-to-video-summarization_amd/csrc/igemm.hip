@@ -1629,93 +1629,92 @@ static bool igemm_tap9_ok(const IgemmParams& p, int es) {
          (long long)(384 + 64) * p.cin * es < (1ll << 31);
 }
 
+// every dispatcher returns whether a kernel was launched: a (dtype, tile, epilogue) combination that has no instantiation
+// is an error of the launcher's rules, reported as AVS_E_UNSUPPORTED - never a silent AVS_OK with an untouched output
+#define AVS_LAUNCH_RET(K)                                     \
+  do {                                                        \
+    hipLaunchKernelGGL(K, grid, dim3(256), 0, stream, p);     \
+    return true;                                              \
+  } while (0)
 template <int ES, int BN, bool ACC64, bool SP, int ROWB, bool PIPE, int WR, bool FK>
-static void igemm_dispatch_epi4(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p) {
+static bool igemm_dispatch_epi4(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p) {
   if constexpr (ES == 2 && WR == 4) {
     if constexpr (SP && ROWB == 64 && PIPE && FK) {   // bf16 3x3 / 1 layers: the nine-tap form
       if ((epi == EPI_BNLOCAL || epi == EPI_STATS) && igemm_tap9_ok(p, ES)) {
         if (epi == EPI_BNLOCAL)
-          hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BNLOCAL, PIPE, WR, FK, 0, true>), grid, dim3(256), 0, stream, p);
+          AVS_LAUNCH_RET((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BNLOCAL, PIPE, WR, FK, 0, true>));
         else
-          hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE, WR, FK, 0, true>), grid, dim3(256), 0, stream, p);
-        return;
+          AVS_LAUNCH_RET((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE, WR, FK, 0, true>));
       }
     }
     if (epi == EPI_BNLOCAL) {
-      hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BNLOCAL, PIPE, WR, FK>), grid, dim3(256), 0, stream, p);
-      return;
+      AVS_LAUNCH_RET((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BNLOCAL, PIPE, WR, FK>));
     }
   }
   if constexpr (ES == 4 && !ACC64) {
     if (p.split == 2) {         // AVS_F16X2: operands stored as fp16 hi | lo runs, three fp16 MFMAs per product
       if (epi == EPI_PLAIN)
-        hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_PLAIN, PIPE, WR, FK, 2>), grid, dim3(256), 0, stream, p);
+        AVS_LAUNCH_RET((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_PLAIN, PIPE, WR, FK, 2>));
       else if (epi == EPI_STATS) {
         if constexpr (SP && ROWB == 64 && PIPE && WR == 4 && FK) {
           if (igemm_tap9_ok(p, ES)) {   // 3x3 / 1 / pad 1 on a dense input: one A fetch per channel block serves all nine taps
-            hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE, WR, FK, 2, true>), grid, dim3(256), 0,
-                               stream, p);
-            return;
+            AVS_LAUNCH_RET((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE, WR, FK, 2, true>));
           }
         }
         if constexpr (!SP && ROWB == 64 && PIPE && FK) {
           if (p.x_p8) {   // AVS_F16P8 input (validated by igemm_launch): A fragments fetched into registers
-            hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE, WR, FK, 2, false, true>), grid, dim3(256), 0,
-                               stream, p);
-            return;
+            AVS_LAUNCH_RET((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE, WR, FK, 2, false, true>));
           }
         }
-        hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE, WR, FK, 2>), grid, dim3(256), 0, stream, p);
+        AVS_LAUNCH_RET((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE, WR, FK, 2>));
       } else if (epi == EPI_BRELU)
-        hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BRELU, PIPE, WR, FK, 2>), grid, dim3(256), 0, stream, p);
+        AVS_LAUNCH_RET((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BRELU, PIPE, WR, FK, 2>));
       else if constexpr (WR == 4) {
         if (epi == EPI_BNLOCAL) {
           if constexpr (SP && ROWB == 64 && PIPE && FK) {
             if (igemm_tap9_ok(p, ES)) {
-              hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BNLOCAL, PIPE, WR, FK, 2, true>), grid, dim3(256), 0,
-                                 stream, p);
-              return;
+              AVS_LAUNCH_RET((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BNLOCAL, PIPE, WR, FK, 2, true>));
             }
           }
-          hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BNLOCAL, PIPE, WR, FK, 2>), grid, dim3(256), 0, stream, p);
+          AVS_LAUNCH_RET((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BNLOCAL, PIPE, WR, FK, 2>));
         }
         if constexpr (!SP && ROWB == 64 && PIPE) {   // (the launcher only sends 1x1 shapes on the pipelined 256-row tiles here)
           if (epi == EPI_AFFINE)
-            hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_AFFINE, PIPE, WR, FK, 2>), grid, dim3(256), 0, stream, p);
+            AVS_LAUNCH_RET((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_AFFINE, PIPE, WR, FK, 2>));
         }
       } else if constexpr (!SP && ROWB == 64 && PIPE && BN == 128) {   // AVS_TILE_128: the given-affine form on 128-row tiles
         if (epi == EPI_AFFINE)
-          hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_AFFINE, PIPE, WR, FK, 2>), grid, dim3(256), 0, stream, p);
+          AVS_LAUNCH_RET((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_AFFINE, PIPE, WR, FK, 2>));
       }
-      return;
+      return false;
     }
     if (p.split || WR == 4) {   // AVS_F32_SPLIT: the same tiles, products as three bf16 MFMAs (WR = 4 exists for it only)
       if (epi == EPI_PLAIN)
-        hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_PLAIN, PIPE, WR, FK, 1>), grid, dim3(256), 0, stream, p);
+        AVS_LAUNCH_RET((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_PLAIN, PIPE, WR, FK, 1>));
       else if (epi == EPI_STATS)
-        hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE, WR, FK, 1>), grid, dim3(256), 0, stream, p);
+        AVS_LAUNCH_RET((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE, WR, FK, 1>));
       else if (epi == EPI_BRELU)
-        hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BRELU, PIPE, WR, FK, 1>), grid, dim3(256), 0, stream, p);
+        AVS_LAUNCH_RET((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BRELU, PIPE, WR, FK, 1>));
       else if constexpr (WR == 2)
-        hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_ANY, PIPE, WR, FK, 1>), grid, dim3(256), 0, stream, p);
-      return;
+        AVS_LAUNCH_RET((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_ANY, PIPE, WR, FK, 1>));
     }
   }
   if constexpr (!(ES == 4 && WR == 4)) {   // (fp32 on 256-row tiles exists as fp32-split only: handled above)
     if (epi == EPI_PLAIN)
-      hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_PLAIN, PIPE, WR, FK>), grid, dim3(256), 0, stream, p);
+      AVS_LAUNCH_RET((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_PLAIN, PIPE, WR, FK>));
     else if (epi == EPI_STATS)
-      hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE, WR, FK>), grid, dim3(256), 0, stream, p);
+      AVS_LAUNCH_RET((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE, WR, FK>));
     else if (epi == EPI_BRELU)
-      hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BRELU, PIPE, WR, FK>), grid, dim3(256), 0, stream, p);
+      AVS_LAUNCH_RET((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BRELU, PIPE, WR, FK>));
     else if constexpr (WR == 2)
-      hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_ANY, PIPE, WR, FK>), grid, dim3(256), 0, stream, p);
+      AVS_LAUNCH_RET((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_ANY, PIPE, WR, FK>));
   }
+  return false;
 }
 
 
 template <int ES, int BN, bool ACC64, bool SP, int ROWB, bool PIPE, int WR>
-static void igemm_dispatch_epi3(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p) {
+static bool igemm_dispatch_epi3(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p) {
   constexpr int BKE = ROWB / ES;
   // the buffer window: a tile's rows (at most 256, spread over whole images) plus the tap walk must stay below 2 GiB
   const long long rows = 256;
@@ -1728,39 +1727,37 @@ static void igemm_dispatch_epi3(int epi, dim3 grid, hipStream_t stream, const Ig
   const bool window_ok = extent * ES < (1ll << 31) && (long long)BN * p.ldb * ES + (long long)p.K * ES < (1ll << 31) &&
                          p.x_img_stride >= 0 && p.x_row_stride >= 0 && p.x_px_stride >= 0;
   if (!(p.variant & AVS_STAGING_GENERIC) && window_ok && p.cin % BKE == 0 && p.K % BKE == 0 && p.K / p.cin <= 32 && p.K % p.cin == 0)
-    igemm_dispatch_epi4<ES, BN, ACC64, SP, ROWB, PIPE, WR, true>(epi, grid, stream, p);
+    return igemm_dispatch_epi4<ES, BN, ACC64, SP, ROWB, PIPE, WR, true>(epi, grid, stream, p);
   else
-    igemm_dispatch_epi4<ES, BN, ACC64, SP, ROWB, PIPE, WR, false>(epi, grid, stream, p);
+    return igemm_dispatch_epi4<ES, BN, ACC64, SP, ROWB, PIPE, WR, false>(epi, grid, stream, p);
 }
 
 template <int ES, int BN, bool ACC64, bool SP, int ROWB, bool PIPE>
-static void igemm_dispatch_epi2(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p) {
+static bool igemm_dispatch_epi2(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p) {
   if constexpr (ACC64) {
-    hipLaunchKernelGGL((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_ANY, false>), grid, dim3(256), 0, stream, p);
+    AVS_LAUNCH_RET((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_ANY, false>));
   } else {
     if constexpr (ROWB == 64 && PIPE) {
       if (p.tall) {  // igemm_launch only sets it for the epilogue forms compiled at WR = 4 (bf16; fp32 only as fp32-split)
-        igemm_dispatch_epi3<ES, BN, ACC64, SP, ROWB, PIPE, 4>(epi, grid, stream, p);
-        return;
+        return igemm_dispatch_epi3<ES, BN, ACC64, SP, ROWB, PIPE, 4>(epi, grid, stream, p);
       }
     }
-    igemm_dispatch_epi3<ES, BN, ACC64, SP, ROWB, PIPE, 2>(epi, grid, stream, p);
+    return igemm_dispatch_epi3<ES, BN, ACC64, SP, ROWB, PIPE, 2>(epi, grid, stream, p);
   }
 }
 
 template <int ES, int BN, bool ACC64, bool SP, int ROWB>
-static void igemm_dispatch_epi(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p) {
+static bool igemm_dispatch_epi(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p) {
   if constexpr (ROWB == 64 && !ACC64) {
     if (g_pipe3 && p.K * ES > 2 * ROWB) {  // at least three steps, else there is nothing to pipeline
-      igemm_dispatch_epi2<ES, BN, ACC64, SP, ROWB, true>(epi, grid, stream, p);
-      return;
+      return igemm_dispatch_epi2<ES, BN, ACC64, SP, ROWB, true>(epi, grid, stream, p);
     }
   }
-  igemm_dispatch_epi2<ES, BN, ACC64, SP, ROWB, false>(epi, grid, stream, p);
+  return igemm_dispatch_epi2<ES, BN, ACC64, SP, ROWB, false>(epi, grid, stream, p);
 }
 
 template <int ES, int BN, bool ACC64>
-static void igemm_dispatch(bool spatial, dim3 grid, hipStream_t stream, const IgemmParams& p) {
+static bool igemm_dispatch(bool spatial, dim3 grid, hipStream_t stream, const IgemmParams& p) {
 #ifdef AVS_STUDY
   const_cast<IgemmParams&>(p).debug = g_debug_flags;
 #endif
@@ -1779,14 +1776,14 @@ static void igemm_dispatch(bool spatial, dim3 grid, hipStream_t stream, const Ig
     epi = EPI_BRELU;
   if (short_k) {
     if (spatial)
-      igemm_dispatch_epi<ES, BN, ACC64, true, 64>(epi, grid, stream, p);
+      return igemm_dispatch_epi<ES, BN, ACC64, true, 64>(epi, grid, stream, p);
     else
-      igemm_dispatch_epi<ES, BN, ACC64, false, 64>(epi, grid, stream, p);
+      return igemm_dispatch_epi<ES, BN, ACC64, false, 64>(epi, grid, stream, p);
   } else {
     if (spatial)
-      igemm_dispatch_epi<ES, BN, ACC64, true, 128>(epi, grid, stream, p);
+      return igemm_dispatch_epi<ES, BN, ACC64, true, 128>(epi, grid, stream, p);
     else
-      igemm_dispatch_epi<ES, BN, ACC64, false, 128>(epi, grid, stream, p);
+      return igemm_dispatch_epi<ES, BN, ACC64, false, 128>(epi, grid, stream, p);
   }
 }
 
@@ -1868,6 +1865,9 @@ static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream
   if (p.affine) {
     const int tile_mode = p.variant & 3;
     p.tall = (!narrow && (tile_mode == AVS_TILE_128 || (tile_mode == AVS_TILE_AUTO && p.K <= AVS_RULE_AFFINE_128_MAX_K))) ? 0 : 1;
+    // the 128-row form exists on 64-byte reduction steps only: a longer reduction keeps the 256-row tile whatever the caller
+    // asks for (the variant is a tuning hint: results do not depend on it)
+    if (!p.tall && (long long)p.K * 4 > g_rowb_threshold_bytes) p.tall = 1;
   }
   const int tile_rows = p.tile_rows ? p.tile_rows : (p.tall ? 256 : 128);
   const long long tiles_m = ((long long)p.M + tile_rows - 1) / tile_rows;
@@ -1898,19 +1898,18 @@ static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream
       return AVS_OK;
     }
   }
+  bool launched;
   if (dtype == AVS_BF16) {
-    if (narrow)
-      igemm_dispatch<2, 64, false>(spatial, grid, stream, p);
-    else
-      igemm_dispatch<2, 128, false>(spatial, grid, stream, p);
+    launched = narrow ? igemm_dispatch<2, 64, false>(spatial, grid, stream, p) : igemm_dispatch<2, 128, false>(spatial, grid, stream, p);
   } else if (dtype == AVS_F32_ACC64) {
-    igemm_dispatch<4, 64, true>(spatial, grid, stream, p);
+    launched = igemm_dispatch<4, 64, true>(spatial, grid, stream, p);
   } else {
-    if (narrow)
-      igemm_dispatch<4, 64, false>(spatial, grid, stream, p);
-    else
-      igemm_dispatch<4, 128, false>(spatial, grid, stream, p);
+    launched = narrow ? igemm_dispatch<4, 64, false>(spatial, grid, stream, p) : igemm_dispatch<4, 128, false>(spatial, grid, stream, p);
   }
+  AVS_REQUIRE(launched, AVS_E_UNSUPPORTED,
+              "%s: no kernel for this combination (dtype %d, %s tile, K = %d, N = %d, variant %d, %s%s%s): nothing was launched", who,
+              dtype, p.tall ? "256-row" : "128-row", p.K, p.N, p.variant, p.affine ? "given-affine " : "", p.tile_rows ? "tile-local " : "",
+              p.stat_part ? "statistics" : "");
   AVS_CHECK_LAUNCH(who);
   return AVS_OK;
 }

@@ -63,6 +63,28 @@ def main():
                         sd_sha256=sd_hash(mf.state_dict()), keys=np.array(sorted(mf.state_dict().keys())),
                         out=y.numpy(), n_params=sum(p.numel() for p in mf.parameters()))
 
+    # configs[1] / configs[3] sequence lengths: the same seeded full-size reference class on
+    # T = 1800 and T = 5000 steps; inputs are regenerated from their seeds, only the scores are stored
+    long_out = {"seed": 7, "sd_sha256": sd_hash(mf.state_dict())}
+    for t_len, in_seed in ((1800, 11800), (5000, 15000)):
+        v = torch.randn(1, t_len, 4096, generator=torch.Generator().manual_seed(in_seed))
+        with torch.no_grad():
+            y = mf(v, torch.zeros(1, t_len, 296))
+        long_out[f"t{t_len}_input_seed"], long_out[f"t{t_len}_out"] = in_seed, y.numpy()
+    np.savez_compressed(os.path.join(HERE, "scorer_long.npz"), **long_out)
+
+    # MultiHeadSelfAttention(1024, 4) at T = 5000 (the reference materialises 4 x 5000 x 5000 scores): 64 output
+    # rows at a fixed stride are stored, parameters and input come from their seeds
+    torch.manual_seed(4242)
+    atl = MHSA(1024, 4).eval()
+    xl = torch.randn(1, 5000, 1024, generator=torch.Generator().manual_seed(4243))
+    with torch.no_grad():
+        yl = atl(xl)
+    rows = np.arange(0, 5000, 79)[:64]
+    np.savez_compressed(os.path.join(HERE, "mhsa_long.npz"), seed=4242, input_seed=4243, t=5000, rows=rows,
+                        sd_sha256=sd_hash(atl.state_dict()), out_rows=yl[0, rows].numpy(),
+                        out_abs_sum=float(yl.double().abs().sum()))
+
     torch.manual_seed(99)
     at = MHSA(64, 4).eval()
     x = torch.randn(2, 19, 64, generator=g)

@@ -470,3 +470,30 @@ def test_gram_statistics_and_affine_pass_f16x2(dev, rpg, k, n, xf, with_res, ra)
     assert all(torch.equal(outs[0].view(torch.int32), o.view(torch.int32)) for o in outs[1:])
     got = ops.f16x2_unpack(outs[0]).cpu().double()
     assert (got - out_ref).abs().max().item() <= TOL * max(1.0, out_ref.abs().max().item())
+
+
+def test_affine_pass_long_reduction_every_variant(dev):
+    """avs_conv2d_nhwc_affine with AVS_TILE_128 and a reduction longer than the 64-byte-step rule (K = 1024) used
+    to return AVS_OK without launching anything.  The tile variant is a hint: every variant must write the same bits, and
+    they must be the convolution's."""
+    ops = _ops()
+    from avsum_amd import _abi
+    code = ops.dtype_code(torch.float32, "f16x2")
+    rpg, groups, k, n = 196, 3, 1024, 256
+    rows = rpg * groups
+    g = torch.Generator().manual_seed(17)
+    xp = emu_pack(torch.randn(rows, k, generator=g))
+    wp = emu_pack(torch.randn(n, k, generator=g) / k ** 0.5)
+    sc, sh = torch.rand(groups, n, generator=g) + 0.5, torch.randn(groups, n, generator=g)
+    gid = torch.arange(rows) // rpg
+    ref = torch.relu(emu_unpack(xp).double() @ emu_unpack(wp).double().t() * sc.double()[gid] + sh.double()[gid])
+    outs = []
+    for variant in (_abi.TILE_AUTO, _abi.TILE_128, _abi.TILE_256):
+        y = torch.full((rows, n), float("nan"), device=dev)
+        ops.conv2d_affine(code, rows, 1, 1, k, 1, 1, 1, 1, n, xp.to(dev), k, k, k, wp.to(dev), k, y, n, rpg, sc.to(dev),
+                          sh.to(dev), None, True, None, w_layout=0, variant=variant)
+        outs.append(y)
+    assert all(torch.equal(outs[0].view(torch.int32), o.view(torch.int32)) for o in outs[1:])
+    got = ops.f16x2_unpack(outs[0]).cpu().double()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() <= TOL * max(1.0, ref.abs().max().item())

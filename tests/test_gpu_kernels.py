@@ -499,7 +499,8 @@ def test_lstm_vs_oracle(dev):
     ops = _ops()
     from oracle import scorer as osc
     g = torch.Generator().manual_seed(9)
-    for hid, inp, lens in ((256, 512, [37, 5, 120]), (16, 32, [9, 1, 30]), (20, 8, [7])):
+    # (256, 512, [5000, 1800]): configs[3] / configs[1] lengths on the scorer's kernel (register / LDS-resident W_hh^T)
+    for hid, inp, lens in ((256, 512, [37, 5, 120]), (16, 32, [9, 1, 30]), (20, 8, [7]), (256, 512, [5000, 1800])):
         rows = sum(lens)
         x = torch.randn(rows, inp, generator=g)
         ws = {k: (torch.rand(s, generator=g) - 0.5) * 2 / hid ** 0.5 for k, s in

@@ -30,7 +30,7 @@ def _guarded_equal_selection(got, ref, tol):
     return int((~safe).sum()), selection.select_frames(ref)
 
 
-@pytest.mark.parametrize("b,t", [(1, 300), (1, 1), (2, 17), (3, 5)])
+@pytest.mark.parametrize("b,t", [(1, 300), (1, 1), (2, 17), (3, 5), (1, 1800), (1, 5000)])
 def test_av_bilstm_full_dims(dev, b, t):
     from oracle import scorer as osc
     m = _seeded_scorer(7)
@@ -47,6 +47,47 @@ def test_av_bilstm_full_dims(dev, b, t):
     if b == 1 and t > 1:
         dropped, _ = _guarded_equal_selection(got.numpy(), ref.numpy(), 2e-6)
         assert dropped <= t // 10
+
+
+@pytest.mark.parametrize("t_len", [1800, 5000])
+def test_av_bilstm_long_golden(dev, t_len):
+    """configs[1] / configs[3] sequence lengths against the scores the REFERENCE CLASS produced (models/av_model.py:6-46;
+    tests/golden/scorer_long.npz, written by tests/golden/make_golden.py from the imported class): 1800- and 5000-step
+    fp32 recurrences on the register / LDS-resident kernel.  North_star's bar: scores within 1e-4."""
+    import os
+    from avsum_amd.models.av_model import AVBiLSTMModel
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scorer_long.npz"))
+    torch.manual_seed(int(z["seed"]))
+    m = AVBiLSTMModel().eval().to(dev)
+    v = torch.randn(1, t_len, 4096, generator=torch.Generator().manual_seed(int(z[f"t{t_len}_input_seed"])))
+    with torch.no_grad():
+        got = m(v.to(dev), torch.zeros(1, t_len, 296, device=dev)).cpu().numpy()
+    ref = z[f"t{t_len}_out"]
+    assert got.shape == ref.shape == (t_len,)
+    err = np.abs(got - ref).max()
+    assert err < 1e-4, err
+    # default init: the scores lie within ~1e-2 of each other, so the selection is decided by 1e-6-level differences;
+    # outside a 2e-6 guard band the selected indices must be the reference's
+    dropped, _ = _guarded_equal_selection(got, ref, 2e-6)
+    assert dropped <= t_len // 10
+
+
+def test_score_rows_config3_share_equals_per_video_calls(dev):
+    """One rank's configs[3] share in ONE call - 50 sequences x 5000 steps as concatenated rows - is bit for bit what 50
+    per-video forward() calls return (the reference scores one video per call, scripts/evaluate.py:15-19): no coupling
+    between sequences, no dependence on where a sequence sits in the launch."""
+    m = _seeded_scorer(7).to(dev)
+    n_seq, t_len = 50, 5000
+    g = torch.Generator(device=dev).manual_seed(31)
+    vis = torch.randn(n_seq * t_len, 4096, generator=g, device=dev)
+    aud = torch.zeros(n_seq * t_len, 296, device=dev)
+    seq = torch.arange(0, (n_seq + 1) * t_len, t_len, dtype=torch.int64, device=dev)
+    with torch.no_grad():
+        together = m.score_rows(vis, aud, seq, attn_batch=1)
+        for i in (0, 1, 17, 49):
+            one = m(vis[i * t_len:(i + 1) * t_len].unsqueeze(0), aud[:t_len].unsqueeze(0))
+            assert torch.equal(one, together[i * t_len:(i + 1) * t_len]), i
+    assert torch.isfinite(together).all()
 
 
 def test_av_bilstm_small_dims_random_audio(dev):
@@ -153,7 +194,7 @@ def test_training_loop_matches_oracle(dev):
 
 
 @pytest.mark.parametrize("e,h,b,t", [(1024, 4, 1, 300), (512, 8, 2, 77), (64, 4, 3, 1), (1024, 4, 1, 1801),
-                                     (512, 4, 2, 33), (256, 4, 1, 129), (1024, 4, 2, 1)])
+                                     (512, 4, 2, 33), (256, 4, 1, 129), (1024, 4, 2, 1), (1024, 4, 1, 5000)])
 def test_mhsa(dev, e, h, b, t):
     from avsum_amd.models.attention import MultiHeadSelfAttention
     from oracle import scorer as osc
@@ -173,6 +214,26 @@ def test_mhsa(dev, e, h, b, t):
     assert (got - ref).abs().max().item() < 1e-4
     assert (got2 - ref).abs().max().item() < 1e-4
     assert (got3 - ref).abs().max().item() < 1e-4
+
+
+def test_mhsa_long_golden(dev):
+    """MultiHeadSelfAttention(1024, 4) at T = 5000 against 64 output rows + the absolute sum of the REFERENCE CLASS's output
+    (models/attention.py:15-25; tests/golden/mhsa_long.npz): the fused f16x2 core ("auto"), the fused fp32 core and the
+    materialising path."""
+    import os
+    from avsum_amd.models.attention import MultiHeadSelfAttention
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mhsa_long.npz"))
+    torch.manual_seed(int(z["seed"]))
+    m = MultiHeadSelfAttention(1024, 4).eval().to(dev)
+    x = torch.randn(1, int(z["t"]), 1024, generator=torch.Generator().manual_seed(int(z["input_seed"]))).to(dev)
+    rows = torch.from_numpy(z["rows"]).to(dev)
+    ref_rows = torch.from_numpy(z["out_rows"])
+    with torch.no_grad():
+        for mode in ("auto", True, "f32", False):
+            m.use_flash = mode
+            got = m(x)
+            assert (got[0, rows].cpu() - ref_rows).abs().max().item() < 1e-4, mode
+            assert abs(float(got.double().abs().sum()) / float(z["out_abs_sum"]) - 1) < 1e-5, mode
 
 
 @pytest.mark.parametrize("e,h,b,t,flash", [(512, 8, 2, 77, True), (1024, 4, 1, 300, True), (64, 4, 3, 5, True),

@@ -54,6 +54,36 @@ def test_scorer_full_golden_and_construction_order():
     assert (out - torch.from_numpy(z["out"])).abs().max().item() < 1e-6
 
 
+@pytest.mark.parametrize("t_len", [1800, 5000])
+def test_scorer_long_golden(t_len):
+    """configs[1] / configs[3] sequence lengths: the oracle's recurrences over 1800 and 5000 steps against the scores the
+    reference class (models/av_model.py:6-46) produced for the same seeded parameters and input."""
+    from avsum_amd.models.av_model import AVBiLSTMModel
+    z = np.load(os.path.join(GOLD, "scorer_long.npz"))
+    torch.manual_seed(int(z["seed"]))
+    sd = AVBiLSTMModel().eval().state_dict()
+    assert _hash(sd) == str(z["sd_sha256"])
+    v = torch.randn(1, t_len, 4096, generator=torch.Generator().manual_seed(int(z[f"t{t_len}_input_seed"])))
+    out = osc.av_bilstm_forward(sd, v, torch.zeros(1, t_len, 296))
+    ref = torch.from_numpy(z[f"t{t_len}_out"])
+    assert out.shape == ref.shape == (t_len,)
+    assert (out - ref).abs().max().item() < 1e-6
+
+
+def test_mhsa_long_golden():
+    """MultiHeadSelfAttention(1024, 4) at T = 5000 (models/attention.py:15-25): 64 stored output rows of the reference
+    class + the absolute sum of the whole output."""
+    from avsum_amd.models.attention import MultiHeadSelfAttention
+    z = np.load(os.path.join(GOLD, "mhsa_long.npz"))
+    torch.manual_seed(int(z["seed"]))
+    sd = MultiHeadSelfAttention(1024, 4).eval().state_dict()
+    assert _hash(sd) == str(z["sd_sha256"])
+    x = torch.randn(1, int(z["t"]), 1024, generator=torch.Generator().manual_seed(int(z["input_seed"])))
+    out = osc.mhsa_forward(sd, x, 4)
+    assert (out[0, z["rows"]] - torch.from_numpy(z["out_rows"])).abs().max().item() < 1e-6
+    assert abs(float(out.double().abs().sum()) / float(z["out_abs_sum"]) - 1) < 1e-6
+
+
 def test_mhsa_golden_and_keys():
     from avsum_amd.models.attention import MultiHeadSelfAttention
     z = np.load(os.path.join(GOLD, "mhsa_small.npz"))
