@@ -116,8 +116,8 @@ _SIGNATURES = {
     "avs_relu_dropout_bwd_f32": (c_int, [P, P, P, c_int64, P, P]),
     "avs_mul_f32": (c_int, [P, P, c_int64, P, P]),
     "avs_score_head_bwd_f32": (c_int, [P, P, P, c_int64, c_int, c_int64, P, P, P, P]),
-    "avs_lstm_train_fwd_f32": (c_int, [P, P, c_int, c_int, c_uint, P, c_int, P, c_int64, c_int, P, P, P]),
-    "avs_lstm_bwd_f32": (c_int, [P, c_int64, c_int, P, P, P, c_int, c_int, c_uint, P, c_int, P, P]),
+    "avs_lstm_train_fwd_f32": (c_int, [P, P, c_int, c_int, c_uint, P, c_int, P, c_int64, c_int, P, P, c_int, P]),
+    "avs_lstm_bwd_f32": (c_int, [P, c_int64, c_int, P, P, P, c_int, c_int, c_uint, P, c_int, P, c_int, P]),
     "avs_cdist_f64": (c_int, [P, c_int, P, c_int, c_int, P, P]),
     "avs_dtw_workspace_bytes": (c_int64, [c_int, c_int]),
     "avs_dtw_path_f64": (c_int, [P, c_int, c_int, P, c_int64, P, P, P, P]),
@@ -158,8 +158,8 @@ def lib():
         fn = getattr(handle, name)
         fn.restype = res
         fn.argtypes = args
-    if handle.avs_abi_version() != 3:
-        raise AvsError(f"ABI version mismatch: library reports {handle.avs_abi_version()}, binding expects 3")
+    if handle.avs_abi_version() != 4:
+        raise AvsError(f"ABI version mismatch: library reports {handle.avs_abi_version()}, binding expects 4")
     if STUDY and os.environ.get("AVS_TUNE_CONVBN_NARROW") is not None:
         handle.avs_tune_convbn_narrow(int(os.environ["AVS_TUNE_CONVBN_NARROW"]))
     if STUDY and os.environ.get("AVS_TUNE_PIPELINE") is not None:  # kernel-study override of the library default

@@ -3,6 +3,7 @@
 // avs_transpose_f32; this file holds the rest: transposes, column sums (bias gradients), the element-wise
 // gradient gates and the LSTM backward-through-time recurrence.
 #include "avs_internal.h"
+#include "lstm_h256.h"
 #include <math.h>
 
 // ---------------------------------------------------------------------------
@@ -155,7 +156,6 @@ extern "C" int avs_score_head_bwd_f32(const float* d_dscores, const float* d_sco
 // LSTM forward that also saves what the backward needs (post-activation gates i,f,g,o and the cell state).
 // Same thread layout as lstm_kernel (scorer.hip).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
 
 __global__ __launch_bounds__(1024) void lstm_train_fwd_kernel(const float* __restrict__ xproj,
                                                               const float* __restrict__ whh_t, int H, int ndir,
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(1024) void lstm_train_fwd_kernel(const float* __res
         gg += pq[2 * H + tid];
         go += pq[3 * H + tid];
       }
-      const float ig = sigm(gi), fg = sigm(gf), cg = tanhf(gg), og = sigm(go);
+      const float ig = avs_sigmoid(gi), fg = avs_sigmoid(gf), cg = tanhf(gg), og = avs_sigmoid(go);
       c_state = fg * c_state + ig * cg;
       const float hv = og * tanhf(c_state);
       h_s[tid] = hv;
@@ -236,13 +236,25 @@ __global__ __launch_bounds__(1024) void lstm_train_fwd_kernel(const float* __res
 
 extern "C" int avs_lstm_train_fwd_f32(const float* d_xproj, const float* d_whh_t, int hidden, int ndir,
                                       unsigned reverse_mask, const int64_t* d_seq_rows, int nseq, float* d_out,
-                                      int64_t ldo, int out_col0, float* d_gates, float* d_cell, avs_stream_t stream) {
+                                      int64_t ldo, int out_col0, float* d_gates, float* d_cell, int variant,
+                                      avs_stream_t stream) {
+  AVS_REQUIRE(variant == AVS_LSTM_AUTO || variant == AVS_LSTM_STREAM, AVS_E_ARG, "avs_lstm_train_fwd_f32: bad variant %d", variant);
   AVS_REQUIRE(hidden > 0 && hidden <= 1024 && ndir > 0 && ndir <= 32 && nseq >= 0 && out_col0 >= 0 &&
                   ldo >= out_col0 + (int64_t)ndir * hidden,
               AVS_E_SHAPE, "avs_lstm_train_fwd_f32: bad extents");
   if (nseq == 0) return AVS_OK;
   AVS_REQUIRE(d_xproj && d_whh_t && d_seq_rows && d_out && d_gates && d_cell, AVS_E_ARG,
               "avs_lstm_train_fwd_f32: null pointer");
+  if (hidden == 256 && variant != AVS_LSTM_STREAM) {
+    // the scorer's size: the inference kernel's resident form (20 of a thread's 64 row-vectors of W_hh^T in registers, 8 in
+    // LDS) that also stores the gates and the cell state - the same fmaf chain, bit-identical to the streaming kernel
+    AVS_REQUIRE(avs_aligned16(d_whh_t), AVS_E_ALIGN, "avs_lstm_train_fwd_f32: whh_t not 16-byte aligned");
+    const bool ok = lstm_h256_launch<20, 8, 4, true>(d_xproj, d_whh_t, ndir, reverse_mask, d_seq_rows, nseq, d_out, (long long)ldo,
+                                                     out_col0, d_gates, d_cell, (hipStream_t)stream);
+    AVS_REQUIRE(ok, AVS_E_HIP, "avs_lstm_train_fwd_f32: cannot reserve the LDS of the resident form");
+    AVS_CHECK_LAUNCH("avs_lstm_train_fwd_f32");
+    return AVS_OK;
+  }
   int KQ = 1024 / hidden;
   if (KQ > hidden) KQ = hidden;
   if (KQ < 1) KQ = 1;
@@ -333,14 +345,166 @@ __global__ __launch_bounds__(1024) void lstm_bwd_kernel(const float* __restrict_
   }
 }
 
+// Backward through time at the scorer's size (hidden = 256), W_hh partly resident on chip like the forward's lstm_h256_kernel.
+// dh_next[k] = sum_j W_hh[j][k] da[j]: W_hh [4H][H] has the shape of the forward's W_hh^T with rows and columns exchanged, so
+// the same decomposition applies - a thread owns 64 row-vectors (rows j of one of 16 slices x 4 consecutive k), the first RK
+// in registers, the next LK in LDS, the rest streamed in batches of DEPTH by buffer loads (a wave = one slice, so the slice base
+// is scalar and a wave's load is one whole 1 KB row of W_hh); da is broadcast from LDS.  The step's inputs (saved gates, cell
+// state, dL/dh) are needed BEFORE its matrix-vector product, so they are fetched one step ahead, under the previous product.
+// Summation order: rows ascending inside a slice, then the 16 slices ascending (fixed: deterministic).
+template <int RK, int LK, int DEPTH>
+__global__ __launch_bounds__(1024) void lstm_bwd_h256_kernel(const float* __restrict__ dout, long long ldo, int out_col0,
+                                                             const float* __restrict__ gates,
+                                                             const float* __restrict__ cell,
+                                                             const float* __restrict__ whh, int ndir,
+                                                             unsigned reverse_mask, const int64_t* __restrict__ seq_rows,
+                                                             float* __restrict__ dxproj) {
+  constexpr int H = 256, G = 4 * H, JS = 16, JPS = 64;
+  static_assert(RK + LK <= JPS, "a thread owns 64 row-vectors");
+  extern __shared__ float sm[];
+  float* da_s = sm;                                          // [G]
+  float* part = sm + G;                                      // [JS][H]
+  float4* wl = reinterpret_cast<float4*>(sm + G + JS * H);   // [LK][1024]: thread-private slots
+  const int seq = blockIdx.x, dir = blockIdx.y;
+  const long long r0 = seq_rows[seq], r1 = seq_rows[seq + 1];
+  const long long T = r1 - r0;
+  const bool rev = (reverse_mask >> dir) & 1u;
+  const long long ldg = (long long)ndir * G, ldc = (long long)ndir * H;
+  const int tid = threadIdx.x;
+  const int js = __builtin_amdgcn_readfirstlane(tid >> 6), kv = tid & 63;
+  const int j0 = js * JPS;
+  const float* __restrict__ W = whh + (long long)dir * G * H;
+  const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(W)) + (size_t)j0 * H * 4, 0, JPS * H * 4, 0x00020000);
+  const int voff = kv * 16;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  auto ldw = [&](int i) -> float4 {
+    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, voff, i * (H * 4), 0));
+    return make_float4(v[0], v[1], v[2], v[3]);
+  };
+  float4 wr[RK];
+#pragma unroll
+  for (int i = 0; i < RK; ++i) wr[i] = ldw(i);
+#pragma unroll
+  for (int i = 0; i < LK; ++i) wl[i * 1024 + tid] = ldw(RK + i);
+
+  const float* __restrict__ gbase = gates + (long long)dir * G + tid;
+  const float* __restrict__ cbase = cell + dir * H + tid;
+  const float* __restrict__ dbase = dout + out_col0 + dir * H + tid;
+  auto row_of = [&](long long s) -> long long { return rev ? (r1 - 1 - s) : (r0 + s); };
+  // the inputs of the step about to be processed (threads < H)
+  float p_i = 0.f, p_f = 0.f, p_g = 0.f, p_o = 0.f, p_c = 0.f, p_cprev = 0.f, p_d = 0.f;
+  if (tid < H && T > 0) {
+    const long long row = row_of(T - 1);
+    p_i = gbase[row * ldg];
+    p_f = gbase[row * ldg + H];
+    p_g = gbase[row * ldg + 2 * H];
+    p_o = gbase[row * ldg + 3 * H];
+    p_c = cbase[row * ldc];
+    p_d = dbase[row * ldo];
+    if (T > 1) p_cprev = cbase[row_of(T - 2) * ldc];
+  }
+  float dc_next = 0.f, dh_next = 0.f;
+  for (long long s = T - 1; s >= 0; --s) {
+    const long long row = row_of(s);
+    if (tid < H) {
+      const float ig = p_i, fg = p_f, cg = p_g, og = p_o, c = p_c, c_prev = s > 0 ? p_cprev : 0.f;
+      const float tc = tanhf(c);
+      const float dh = p_d + dh_next;
+      const float d_o = dh * tc;
+      const float dc = dh * og * (1.f - tc * tc) + dc_next;
+      const float d_i = dc * cg, d_g = dc * ig, d_f = dc * c_prev;
+      dc_next = dc * fg;
+      const float ai = d_i * ig * (1.f - ig), af = d_f * fg * (1.f - fg), ag = d_g * (1.f - cg * cg),
+                  ao = d_o * og * (1.f - og);
+      da_s[tid] = ai;
+      da_s[H + tid] = af;
+      da_s[2 * H + tid] = ag;
+      da_s[3 * H + tid] = ao;
+      float* dx = dxproj + row * ldg + (long long)dir * G;
+      dx[tid] = ai;
+      dx[H + tid] = af;
+      dx[2 * H + tid] = ag;
+      dx[3 * H + tid] = ao;
+      if (s > 0) {   // the next step's inputs, in flight under this step's product
+        const long long nrow = row_of(s - 1);
+        p_i = gbase[nrow * ldg];
+        p_f = gbase[nrow * ldg + H];
+        p_g = gbase[nrow * ldg + 2 * H];
+        p_o = gbase[nrow * ldg + 3 * H];
+        p_d = dbase[nrow * ldo];
+        p_c = p_cprev;
+        if (s > 1) p_cprev = cbase[row_of(s - 2) * ldc];
+      }
+    }
+    __syncthreads();
+    constexpr int NS = JPS - RK - LK;
+    static_assert(NS % DEPTH == 0, "whole batches");
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < RK; ++i) {
+      const float dj = da_s[j0 + i];
+      a.x = fmaf(wr[i].x, dj, a.x);
+      a.y = fmaf(wr[i].y, dj, a.y);
+      a.z = fmaf(wr[i].z, dj, a.z);
+      a.w = fmaf(wr[i].w, dj, a.w);
+    }
+#pragma unroll 2
+    for (int i = 0; i < LK; ++i) {
+      const float4 wv = wl[i * 1024 + tid];
+      const float dj = da_s[j0 + RK + i];
+      a.x = fmaf(wv.x, dj, a.x);
+      a.y = fmaf(wv.y, dj, a.y);
+      a.z = fmaf(wv.z, dj, a.z);
+      a.w = fmaf(wv.w, dj, a.w);
+    }
+#pragma unroll 1
+    for (int b0 = 0; b0 < NS; b0 += DEPTH) {
+      float4 ws[DEPTH];
+#pragma unroll
+      for (int i = 0; i < DEPTH; ++i) ws[i] = ldw(RK + LK + b0 + i);
+#pragma unroll
+      for (int i = 0; i < DEPTH; ++i) {
+        const float dj = da_s[j0 + RK + LK + b0 + i];
+        a.x = fmaf(ws[i].x, dj, a.x);
+        a.y = fmaf(ws[i].y, dj, a.y);
+        a.z = fmaf(ws[i].z, dj, a.z);
+        a.w = fmaf(ws[i].w, dj, a.w);
+      }
+    }
+    reinterpret_cast<float4*>(part + js * H)[kv] = a;
+    __syncthreads();
+    if (tid < H) {
+      float acc = 0.f;
+#pragma unroll
+      for (int q = 0; q < JS; ++q) acc += part[q * H + tid];
+      dh_next = acc;
+    }
+    // da_s / part are rewritten only behind the next barrier pair
+  }
+}
+
 extern "C" int avs_lstm_bwd_f32(const float* d_dout, int64_t ldo, int out_col0, const float* d_gates,
                                 const float* d_cell, const float* d_whh, int hidden, int ndir, unsigned reverse_mask,
-                                const int64_t* d_seq_rows, int nseq, float* d_dxproj, avs_stream_t stream) {
+                                const int64_t* d_seq_rows, int nseq, float* d_dxproj, int variant, avs_stream_t stream) {
+  AVS_REQUIRE(variant == AVS_LSTM_AUTO || variant == AVS_LSTM_STREAM, AVS_E_ARG, "avs_lstm_bwd_f32: bad variant %d", variant);
   AVS_REQUIRE(hidden > 0 && hidden <= 1024 && ndir > 0 && ndir <= 32 && nseq >= 0 && out_col0 >= 0 &&
                   ldo >= out_col0 + (int64_t)ndir * hidden,
               AVS_E_SHAPE, "avs_lstm_bwd_f32: bad extents");
   if (nseq == 0) return AVS_OK;
   AVS_REQUIRE(d_dout && d_gates && d_cell && d_whh && d_seq_rows && d_dxproj, AVS_E_ARG, "avs_lstm_bwd_f32: null pointer");
+  if (hidden == 256 && variant != AVS_LSTM_STREAM) {
+    AVS_REQUIRE(avs_aligned16(d_whh), AVS_E_ALIGN, "avs_lstm_bwd_f32: whh not 16-byte aligned");
+    constexpr int RK = 20, LK = 8, DEPTH = 4;
+    const size_t shm = ((size_t)4 * 256 + 16 * 256) * sizeof(float) + (size_t)LK * 1024 * sizeof(float4);
+    AVS_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bwd_h256_kernel<RK, LK, DEPTH>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess,
+                AVS_E_HIP, "avs_lstm_bwd_f32: cannot reserve %zu bytes of LDS", shm);
+    hipLaunchKernelGGL((lstm_bwd_h256_kernel<RK, LK, DEPTH>), dim3(nseq, ndir), dim3(1024), shm, (hipStream_t)stream, d_dout,
+                       (long long)ldo, out_col0, d_gates, d_cell, d_whh, ndir, reverse_mask, d_seq_rows, d_dxproj);
+    AVS_CHECK_LAUNCH("avs_lstm_bwd_f32");
+    return AVS_OK;
+  }
   int JQ = 1024 / hidden;
   if (JQ < 1) JQ = 1;
   if (JQ > 4 * hidden) JQ = 4 * hidden;

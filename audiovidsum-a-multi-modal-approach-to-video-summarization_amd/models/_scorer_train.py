@@ -23,23 +23,28 @@ class ScorerTrainFunction(torch.autograd.Function):
         hidden = pm["visual_fc.0.weight"].shape[0]
         e = 2 * hidden
 
+        # both BiLSTMs = four independent recurrences: ONE launch (direction d writes fused[:, d*H:]), as in score_rows
         saved = {}
         fused = torch.empty((t, e), dtype=torch.float32, device=dev)
+        hid = pm["visual_bilstm.weight_hh_l0"].shape[1]
+        xproj = torch.empty((t, 16 * hid), dtype=torch.float32, device=dev)   # [v fwd | v rev | a fwd | a rev] x 4H
+        whh_all = []
         col = 0
         for tag, x, keep, fc, lstm in (("v", visual, keep_v, "visual_fc.0.", "visual_bilstm."),
                                        ("a", audio, keep_a, "audio_fc.0.", "audio_bilstm.")):
             r = ops.linear(x, pm[fc + "weight"], pm[fc + "bias"], ops.ACT_RELU)     # Linear + ReLU
             emb = ops.mul(r, keep)                                                   # Dropout (inverted scaling)
-            hid = pm[lstm + "weight_hh_l0"].shape[1]
             wih = torch.cat([pm[lstm + "weight_ih_l0"], pm[lstm + "weight_ih_l0_reverse"]], 0)
             bih = torch.cat([pm[lstm + "bias_ih_l0"] + pm[lstm + "bias_hh_l0"],
                              pm[lstm + "bias_ih_l0_reverse"] + pm[lstm + "bias_hh_l0_reverse"]])
-            whh = torch.stack([pm[lstm + "weight_hh_l0"], pm[lstm + "weight_hh_l0_reverse"]]).contiguous()
-            whh_t = whh.transpose(1, 2).contiguous()
-            xproj = ops.linear(emb, wih, bih)
-            gates, cell = ops.lstm_train_fwd(xproj, whh_t, hid, 2, 0b10, seq, fused, col)
-            saved[tag] = (x, r, keep, emb, wih, whh, gates, cell, hid, col)
+            whh_all += [pm[lstm + "weight_hh_l0"], pm[lstm + "weight_hh_l0_reverse"]]
+            ops.linear(emb, wih, bih, out=xproj[:, col * 4:(col + 2 * hid) * 4])
+            saved[tag] = (x, r, keep, emb, wih, col)
             col += 2 * hid
+        whh = torch.stack(whh_all).contiguous()                  # [4, 4H, H]: the backward's layout
+        whh_t = whh.transpose(1, 2).contiguous()                 # [4, H, 4H]: the forward's
+        gates, cell = ops.lstm_train_fwd(xproj, whh_t, hid, 4, 0b1010, seq, fused, 0)
+        ctx.lstm = (whh, gates, cell, hid)
         w_in, b_in = pm["attention.in_proj_weight"], pm["attention.in_proj_bias"]
         w_v, b_v = w_in[2 * e:3 * e].contiguous(), b_in[2 * e:3 * e].contiguous()
         w_o, b_o = pm["attention.out_proj.weight"], pm["attention.out_proj.bias"]
@@ -79,10 +84,12 @@ class ScorerTrainFunction(torch.autograd.Function):
         g["attention.in_proj_weight"], g["attention.in_proj_bias"] = gw_in, gb_in
         dfused = ops.grad_input(dval, w_v)
         dinputs = {}
+        whh, gates, cell, hid = ctx.lstm
+        t = fused.shape[0]
+        da_all = ops.lstm_bwd(dfused, 0, gates, cell, whh, hid, 4, 0b1010, ctx.seq)   # [T, 4 * 4H], one launch
         for tag, fc, lstm in (("v", "visual_fc.0.", "visual_bilstm."), ("a", "audio_fc.0.", "audio_bilstm.")):
-            x, r, keep, emb, wih, whh, gates, cell, hid, col = ctx.saved[tag]
-            t = x.shape[0]
-            da = ops.lstm_bwd(dfused, col, gates, cell, whh, hid, 2, 0b10, ctx.seq)  # [T, 2*4H]
+            x, r, keep, emb, wih, col = ctx.saved[tag]
+            da = da_all[:, col * 4:(col + 2 * hid) * 4]                                  # this BiLSTM's [T, 2*4H]
             gwih = ops.grad_weight(da, emb)                                             # [8H, hidden]
             gb = ops.colsum(da)
             # h_{t-1} of each direction: forward = the previous row, reverse = the next row (zero at the start)

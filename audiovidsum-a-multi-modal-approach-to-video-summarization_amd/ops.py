@@ -32,7 +32,7 @@ class LaunchProfiler:
     def __init__(self, count_only=False, prealloc=0, sample_every=1):
         """sample_every = n: bracket every n-th launch of each kind only (an event pair is a barrier between kernels:
         timing EVERY launch costs the pipeline ~3 %); all launches are still counted."""
-        self.records = []  # (kind, dtype_code, algorithmic FLOPs (bytes for the HBM-bound kinds), algorithmic bytes, start, end)
+        self.records = []  # (kind, dtype_code, algorithmic FLOPs (bytes for the HBM-bound kinds), algorithmic bytes, start, end, form)
         self.count_only = count_only
         self.count = 0
         self.sample_every = max(1, int(sample_every))
@@ -48,8 +48,23 @@ class LaunchProfiler:
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for kind, dt, flops, nbytes, s, e in self.records:
+        for kind, dt, flops, nbytes, s, e, _ in self.records:
             d = out.setdefault((kind, dt), {"launches": 0, "flops": 0.0, "bytes": 0.0, "ms": 0.0})
+            d["launches"] += 1
+            d["flops"] += flops
+            d["bytes"] += nbytes
+            d["ms"] += s.elapsed_time(e)
+        return out
+
+    def forms(self, kind, dt):
+        """The timed launches of one kind split by the FORM the wrapper tagged them with (epilogue form x filter size of
+        the contraction kernel): {form: {"launches", "flops", "bytes", "ms"}}."""
+        torch.cuda.synchronize()
+        out = {}
+        for k, d_, flops, nbytes, s, e, form in self.records:
+            if k != kind or d_ != dt:
+                continue
+            d = out.setdefault(form or "other", {"launches": 0, "flops": 0.0, "bytes": 0.0, "ms": 0.0})
             d["launches"] += 1
             d["flops"] += flops
             d["bytes"] += nbytes
@@ -65,7 +80,7 @@ def set_profiler(p):
     _profiler = p
 
 
-def _timed(kind, dtype, flops, fn, nbytes=0.0):
+def _timed(kind, dtype, flops, fn, nbytes=0.0, form=None):
     if _profiler is None:
         return fn()
     if _profiler.count_only:
@@ -79,7 +94,7 @@ def _timed(kind, dtype, flops, fn, nbytes=0.0):
     s.record()
     r = fn()
     e.record()
-    _profiler.records.append((kind, dtype, float(flops), float(nbytes), s, e))
+    _profiler.records.append((kind, dtype, float(flops), float(nbytes), s, e, form))
     return r
 
 
@@ -294,12 +309,12 @@ def conv2d_raw(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x, x_i
                                           _p(beta), float(eps), _p(residual),
                                           residual.stride(0) if residual is not None else 0, _stream()),
             "avs_conv2d_nhwc_bnlocal"),
-               cbytes + (float(es) * n * ho * wo * cout if residual is not None else 0.0))
+               cbytes + (float(es) * n * ho * wo * cout if residual is not None else 0.0), form=f"tile-local BatchNorm {kh}x{kw}")
         return None
     if bnstats is None:
         _timed("conv", dtype, flops, lambda: check(
             lib().avs_conv2d_nhwc(ctypes.byref(d), _p(x, x_off), _p(wt), _p(bias), _p(y, y_off), _stream()),
-            "avs_conv2d_nhwc"), cbytes)
+            "avs_conv2d_nhwc"), cbytes, form=f"plain / bias+ReLU {kh}x{kw}")
         return None
     rpg, gamma, beta, eps = bnstats
     if bias is not None or act != ACT_NONE:
@@ -319,7 +334,7 @@ def conv2d_raw(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x, x_i
     _timed("conv", dtype, flops, lambda: check(
         lib().avs_conv2d_nhwc_bnstats(ctypes.byref(d), _p(x, x_off), _p(wt), _p(y, y_off), int(rpg), _p(gamma),
                                       _p(beta), float(eps), _p(scale), _p(shift), _p(ws), ws.numel(), _stream()),
-        "avs_conv2d_nhwc_bnstats"), cbytes)
+        "avs_conv2d_nhwc_bnstats"), cbytes, form=f"convolution + statistics {kh}x{kw}")
     return scale, shift
 
 
@@ -529,7 +544,8 @@ def conv2d_affine(dtype, n, h, w, cin, sh, sw, ho, wo, cout, x, x_img_stride, x_
               + (0.0 if residual is None else (3.0 if res_p8 else 4.0) * rows * cout))
     _timed("conv", dtype, flops, lambda: check(
         lib().avs_conv2d_nhwc_affine(ctypes.byref(d), _p(x), _p(wt), _p(y), int(rows_per_group), _p(scale), _p(shift),
-                                     _p(residual), ldr, _p(rsc), _p(rsh), _stream()), "avs_conv2d_nhwc_affine"), nbytes)
+                                     _p(residual), ldr, _p(rsc), _p(rsh), _stream()), "avs_conv2d_nhwc_affine"), nbytes,
+           form="one-pass given-affine 1x1")
     return yout
 
 
@@ -989,23 +1005,23 @@ def score_head_bwd(dscores, scores, hid, w2):
     return dz, dpre
 
 
-def lstm_train_fwd(xproj, whh_t, hidden, ndir, reverse_mask, seq_rows, out, out_col0):
+def lstm_train_fwd(xproj, whh_t, hidden, ndir, reverse_mask, seq_rows, out, out_col0, variant=0):
     rows = xproj.shape[0]
     gates = torch.empty((rows, ndir * 4 * hidden), dtype=torch.float32, device=xproj.device)
     cell = torch.empty((rows, ndir * hidden), dtype=torch.float32, device=xproj.device)
     nseq = seq_rows.numel() - 1
     check(lib().avs_lstm_train_fwd_f32(_p(xproj), _p(whh_t), hidden, ndir, reverse_mask, _p(seq_rows), nseq, _p(out),
-                                       out.stride(0), out_col0, _p(gates), _p(cell), _stream()),
+                                       out.stride(0), out_col0, _p(gates), _p(cell), int(variant), _stream()),
           "avs_lstm_train_fwd_f32")
     return gates, cell
 
 
-def lstm_bwd(dout, out_col0, gates, cell, whh, hidden, ndir, reverse_mask, seq_rows):
+def lstm_bwd(dout, out_col0, gates, cell, whh, hidden, ndir, reverse_mask, seq_rows, variant=0):
     rows = gates.shape[0]
     dxproj = torch.empty((rows, ndir * 4 * hidden), dtype=torch.float32, device=gates.device)
     nseq = seq_rows.numel() - 1
     check(lib().avs_lstm_bwd_f32(_p(dout), dout.stride(0), out_col0, _p(gates), _p(cell), _p(whh), hidden, ndir,
-                                 reverse_mask, _p(seq_rows), nseq, _p(dxproj), _stream()), "avs_lstm_bwd_f32")
+                                 reverse_mask, _p(seq_rows), nseq, _p(dxproj), int(variant), _stream()), "avs_lstm_bwd_f32")
     return dxproj
 
 

@@ -151,10 +151,30 @@ def roofline_from(prof, dtype, elapsed, traffic, split=False):
                 "algorithmic_flop_per_launch": round(conv["flops"] / conv["launches"], 1),
                 "algorithmic_bytes_per_launch": round(conv["bytes"] / conv["launches"], 1),
                 "share_of_step": round(conv["ms"] * 1e-3 / elapsed * seen / conv["launches"], 3)}
+    # the other reading, side by side: the ALGORITHMIC rate against the nominal dense 16-bit peak (fp32: its own peak)
+    nominal = MFMA_F32_PEAK_TFLOPS if (dtype == torch.float32 and not split) else MFMA_BF16_PEAK_TFLOPS
+    roofline["frac_of_nominal_peak"] = round(achieved / nominal, 4)
+    roofline["nominal_peak"] = nominal
     if split:
         roofline["mfma_rate_tflops"] = round(3.0 * achieved, 1)
         roofline["note"] = ("three 16-bit MFMAs per algorithmic product (hi*hi + hi*lo + lo*hi): peak = 2500 / 3; "
-                            "mfma_rate_tflops = the matrix-core rate behind the algorithmic figure")
+                            "mfma_rate_tflops = the matrix-core rate behind the algorithmic figure; "
+                            "frac_of_nominal_peak = algorithmic rate / 2500")
+    # where the step goes, by form of the contraction kernel (epilogue form x filter size): share of the step,
+    # algorithmic TFLOP/s and algorithmic TB/s of each (matrix-pipe busy per form: profiles/*_sq_counters.json)
+    frm = prof.forms("conv", code)
+    scale_up = seen / conv["launches"]
+    rows = []
+    for name, rec in sorted(frm.items(), key=lambda kv: -kv[1]["ms"]):
+        if rec["ms"] <= 0:
+            continue
+        rows.append({"form": name, "timed_launches": rec["launches"],
+                     "share_of_step": round(rec["ms"] * 1e-3 * scale_up / elapsed, 4),
+                     "tflops": round(rec["flops"] / (rec["ms"] * 1e-3) / 1e12, 1),
+                     "frac_of_peak": round(rec["flops"] / (rec["ms"] * 1e-3) / 1e12 / peak, 4),
+                     "tb_per_s": round(rec["bytes"] / (rec["ms"] * 1e-3) / 1e12, 3),
+                     "frac_of_hbm_peak": round(rec["bytes"] / (rec["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+    roofline["forms"] = rows
     others = []
     for kind, label in (("convbn", "conv1x1_bn_kernel (avs_conv1x1_bn[_in]_bf16)"),
                         ("bn_apply", "bn_apply_kernel / bn_maxpool_kernel (avs_bn_apply, avs_bn_maxpool_nhwc)")):
@@ -302,16 +322,120 @@ def config2_leg(extractor, scorer, dev, steps, videos):
                                "note": "4 B/sample read + the per-shot means written (SURVEY 8 D3, pooled on chip); compute-bound by the exact fp64 DFT, run twice (DESIGN section 3)"}}
 
 
+# ------------------------------------------------------------------------------------------------ configs[4] leg
+def config4_leg(dev, steps=20, lengths=(300, 1800), oracle_steps=6):
+    """configs[4] (scripts/train_av_model.py:70-96 on synthetic labels) at world size 1: the reference's training step -
+    Dropout active, forward, MSE against the one broadcast target, loss.backward(), AdamW(lr 1e-4).step() - for `steps`
+    steps per sequence length, every step through avsum_amd.scripts.train_av_model.train_step (forward and backward are
+    libavsum_hip.so calls; loss / optimiser are the caller's torch, as in the reference).  Features resident on the
+    device.  Also: the LSTM sweeps alone (us per time step, forward with saved gates and backward through time, all four
+    recurrences in one launch), and the first `oracle_steps` losses against the CPU restatement under the same Dropout
+    masks (<= 1e-4 relative)."""
+    from avsum_amd import ops
+    from avsum_amd.models.av_model import AVBiLSTMModel
+    from avsum_amd.scripts.train_av_model import train_step
+    from oracle import scorer as osc
+    out = {"workload": "configs[4]: scripts/train_av_model.py:70-96 on synthetic labels ~U[1,5], one video per step "
+                       f"(B = 1), fp32, world size 1, {steps} timed steps per length (2 warm-up); visual randn "
+                       "[T,4096], audio = zeros [T,296] (SURVEY Q5), features resident in HBM", "lengths": {}}
+    for t_len in lengths:
+        torch.manual_seed(7)
+        model = AVBiLSTMModel().to(dev).train()
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+        g = torch.Generator().manual_seed(5005 + t_len)
+        feats = {"visual": torch.randn(t_len, 4096, generator=g).to(dev), "audio": torch.zeros(t_len, 296, device=dev)}
+        labels = torch.rand(t_len * 30, generator=g) * 4 + 1
+        for _ in range(2):
+            train_step(model, opt, feats, labels, dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = train_step(model, opt, feats, labels, dev)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        # forward-only (inference kernel path) for the ratio
+        model.eval()
+        with torch.no_grad():
+            model(feats["visual"].unsqueeze(0), feats["audio"].unsqueeze(0))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                model(feats["visual"].unsqueeze(0), feats["audio"].unsqueeze(0))
+            torch.cuda.synchronize()
+            dt_inf = time.perf_counter() - t1
+        # the two LSTM sweeps alone, four recurrences per launch
+        hid = 256
+        xproj = torch.randn(t_len, 16 * hid, generator=g).to(dev)
+        whh = torch.stack([model.visual_bilstm.weight_hh_l0, model.visual_bilstm.weight_hh_l0_reverse,
+                           model.audio_bilstm.weight_hh_l0, model.audio_bilstm.weight_hh_l0_reverse]).detach().contiguous()
+        whh_t = whh.transpose(1, 2).contiguous()
+        seq = torch.tensor([0, t_len], dtype=torch.int64, device=dev)
+        fused = torch.empty(t_len, 4 * hid, device=dev)
+        dfused = torch.randn(t_len, 4 * hid, generator=g).to(dev)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        f_ms, b_ms = [], []
+        for _ in range(6):
+            ev[0].record()
+            gates, cell = ops.lstm_train_fwd(xproj, whh_t, hid, 4, 0b1010, seq, fused, 0)
+            ev[1].record()
+            ops.lstm_bwd(dfused, 0, gates, cell, whh, hid, 4, 0b1010, seq)
+            ev[2].record()
+            torch.cuda.synchronize()
+            f_ms.append(ev[0].elapsed_time(ev[1]))
+            b_ms.append(ev[1].elapsed_time(ev[2]))
+        f_us, b_us = statistics.median(f_ms[1:]) * 1e3 / t_len, statistics.median(b_ms[1:]) * 1e3 / t_len
+        out["lengths"][str(t_len)] = {
+            "steps_per_s": round(steps / dt, 2), "ms_per_step": round(dt * 1e3 / steps, 3),
+            "frames_per_s": round(steps * t_len / dt, 1), "last_loss": round(loss, 6),
+            "inference_forward_ms": round(dt_inf * 1e3 / steps, 3),
+            "lstm_forward_us_per_time_step": round(f_us, 3), "lstm_backward_us_per_time_step": round(b_us, 3),
+            "lstm_backward_over_forward": round(b_us / f_us, 3)}
+        log(f"configs[4] T={t_len}: {steps / dt:.1f} steps/s, LSTM {f_us:.2f} / {b_us:.2f} us per time step (fwd / bwd)")
+    # loss trajectory against the oracle (CPU autograd through the restatement), same Dropout masks, T = lengths[0]
+    t_len = lengths[0]
+    torch.manual_seed(7)
+    model = AVBiLSTMModel()
+    ref_params = {k: p.detach().clone().requires_grad_(True) for k, p in model.named_parameters()}
+    opt_ref = torch.optim.AdamW(list(ref_params.values()), lr=1e-4)
+    model = model.to(dev).train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+    g = torch.Generator().manual_seed(99)
+    got, ref = [], []
+    for _ in range(oracle_steps):
+        v, a = torch.randn(1, t_len, 4096, generator=g), torch.zeros(1, t_len, 296)
+        kv = (torch.rand(t_len, 512, generator=g) >= 0.3).float() / 0.7
+        ka = (torch.rand(t_len, 512, generator=g) >= 0.3).float() / 0.7
+        target = torch.rand(1, generator=g) * 4 + 1
+        o_ref = osc.av_bilstm_forward_train(ref_params, v, a, kv, ka)
+        l_ref = torch.nn.functional.mse_loss(o_ref, target.expand_as(o_ref))
+        opt_ref.zero_grad()
+        l_ref.backward()
+        opt_ref.step()
+        model._dropout_keep = (kv.to(dev), ka.to(dev))
+        o = model(v.to(dev), a.to(dev))
+        l_ = torch.nn.functional.mse_loss(o, target.to(dev).expand_as(o))
+        opt.zero_grad()
+        l_.backward()
+        opt.step()
+        got.append(float(l_.item()))
+        ref.append(float(l_ref.item()))
+    rel = max(abs(x - y) / abs(y) for x, y in zip(got, ref))
+    out["loss_trajectory"] = {"steps": oracle_steps, "t": t_len, "hip": [round(x, 7) for x in got],
+                              "oracle": [round(x, 7) for x in ref], "max_rel_err": rel, "bar": 1e-4,
+                              "within_bar": bool(rel <= 1e-4)}
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3],
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3, 4],
                     help="BASELINE config of the headline: 1 = SumMe-shape batch per rank; 2 = the TVSum-shape "
                          "audio + visual + fusion leg alone (one GPU); 3 = one rank's share of the 400 x 5000-frame "
-                         "sharded inference")
+                         "sharded inference; 4 = the training loop leg alone (one GPU; sub_results.config4_training)")
     ap.add_argument("--videos", type=int, default=None)
     ap.add_argument("--mean-frames", type=int, default=None)
     ap.add_argument("--dtype", default="f16x2", choices=["f16x2", "bf16", "f32", "f32split"],
@@ -403,6 +527,18 @@ def main():
     avd.broadcast_module(extractor, 0)  # C1
     avd.broadcast_module(scorer, 0)
 
+    if args.config == 4:
+        # the configs[4] training leg on its own (what sub_results.config4_training runs), for profiling it alone
+        if world != 1:
+            raise SystemExit("--config 4 here is the one-GPU training leg (N > 1: tests/test_dist_cpu.py, dist.allreduce_gradients)")
+        leg = config4_leg(dev, steps=args.steps if args.steps != 5 else 20)
+        best = leg["lengths"]["1800"]
+        print(json.dumps({"metric": "training steps/sec (scripts/train_av_model.py loop, T = 1800)", "value": best["steps_per_s"],
+                          "unit": "steps/s", "n_gpus": 1, "steps": 20, "warmup": 2, "ms_per_step": best["ms_per_step"],
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "synthetic", "config": {"workload": leg["workload"]}, "roofline": None,
+                          "cpu_baseline": None, "detail": leg}))
+        return
     if args.config == 2:
         # the configs[2] leg on its own (what sub_results.config2_audio_visual_fusion runs), for profiling it alone
         if world != 1:
@@ -428,8 +564,11 @@ def main():
     pipe = FrameScoringPipeline(extractor, scorer, use_inception=use_inception, chunk_frames=args.chunk,
                                 frames_per_group=fpg, streams=args.streams)
 
+    last_scores = [None]
+
     def step():
         scores = pipe.score(frames, offsets)
+        last_scores[0] = scores
         if world > 1:
             gathered = avd.gather_video_scores(scores, video_ids, lengths, cfg["num_videos"])   # C2, global ids
             assert all(g is not None for g in gathered), "score gather is incomplete"
@@ -548,6 +687,22 @@ def main():
             pipe32 = FrameScoringPipeline(ext32, scorer, use_inception=False, chunk_frames=4096, frames_per_group=1)
             run_sub("fp32_exact_mode", pipe32, frames, offsets, base + "exact fp32 MFMA (v_mfma_f32_32x32x2_f32, "
                     "157 TFLOP/s peak), fp32 storage", roof=(torch.float32, False), acc=True)
+            if accuracy is not None and last_scores[0] is not None:
+                # the headline arithmetic on ALL the frames it times, against the exact-fp32 HIP path (GPU vs GPU: the CPU
+                # oracle at 35 frames/s cannot cover 45 k frames): score difference, per-video selection agreement
+                s32 = pipe32.score(frames, offsets).cpu().numpy()
+                sh = last_scores[0].cpu().numpy()
+                xr = accuracy_report(sh, s32, offsets)
+                per_video = [float(np.mean((sh[a:b] > sh[a:b].mean()) == (s32[a:b] > s32[a:b].mean())))
+                             for a, b in zip(offsets[:-1], offsets[1:])]
+                accuracy["full_batch_cross_mode"] = {
+                    "what": f"{args.dtype} scores vs exact-fp32 HIP scores on all {total} frames of the timed batch "
+                            f"({len(lengths)} videos, T = {min(lengths)}..{max(lengths)})",
+                    "score_max_abs_diff": round(float(np.abs(sh - s32).max()), 9),
+                    "selection_agreement_unguarded_min_over_videos": round(min(per_video), 6),
+                    "selection_agreement_unguarded_mean": round(float(np.mean(per_video)), 6),
+                    **{k: (round(v, 8) if isinstance(v, float) else v) for k, v in xr.items()}}
+                log(f"cross-mode on the full batch: max |{args.dtype} - fp32| = {np.abs(sh - s32).max():.3e}")
             del ext32, pipe32
             # fp32 storage, convolution products on the bf16 matrix cores as hi*hi + hi*lo + lo*hi (AVS_F32_SPLIT)
             exts = other_mode(torch.float32, True)
@@ -557,7 +712,7 @@ def main():
             del exts, pipes, dev_samples
             frames = None
             torch.cuda.empty_cache()
-            subs["config2_audio_visual_fusion"] = config2_leg(extractor, scorer, dev, 1, 50)
+            subs["config2_audio_visual_fusion"] = config2_leg(extractor, scorer, dev, 3, 50)
             log(f"sub-result config2: {subs['config2_audio_visual_fusion']['value']} frames/s")
             c3 = synthetic.config(3, 0, 1)
             off3 = synthetic.offsets_of(c3["lengths"])
@@ -565,8 +720,10 @@ def main():
             frames3 = synthetic.make_frames_uniform(off3[-1], dev, c3["seed"])
             run_sub("config3_one_rank_share", pipe, frames3, off3, "configs[3]: one rank's share of the 400 x "
                     "5000-frame sharded inference (50 videos x 5000 frames, 37.6 GB of frames in HBM), " + args.dtype +
-                    ", per-frame shots; N > 1 is not measured here (one GPU per box)", steps_=1)
+                    ", per-frame shots; N > 1 is not measured here (one GPU per box)", steps_=3)
             del frames3
+            torch.cuda.empty_cache()
+            subs["config4_training"] = config4_leg(dev)
 
         out = {
             "metric": "frames/sec end-to-end (extract+fuse+score), 224x224 + 16kHz",

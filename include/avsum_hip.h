@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define AVS_ABI_VERSION 3
+#define AVS_ABI_VERSION 4
 
 enum {
   AVS_OK = 0,
@@ -519,15 +519,19 @@ int avs_score_head_bwd_f32(const float* d_dscores, const float* d_scores, const 
                            int d, int64_t ldh, const float* d_w2, float* d_dz, float* d_dhid_pre,
                            avs_stream_t stream);
 /* avs_lstm_f32 that also saves the post-activation gates [rows, ndir*4H] (i,f,g,o) and the cell state
- * [rows, ndir*H] for the backward.                                                                        */
+ * [rows, ndir*H] for the backward (the forward of scripts/train_av_model.py:88).  variant: AVS_LSTM_AUTO (hidden = 256:
+ * W_hh^T partly resident in registers / LDS, as avs_lstm_f32 does) or AVS_LSTM_STREAM; bit-identical outputs.          */
 int avs_lstm_train_fwd_f32(const float* d_xproj, const float* d_whh_t, int hidden, int ndir,
                            unsigned reverse_mask, const int64_t* d_seq_rows, int nseq, float* d_out,
-                           int64_t ldo, int out_col0, float* d_gates, float* d_cell, avs_stream_t stream);
-/* Backward through time: from dL/dh_t (d_dout, same layout as the forward's d_out) to the gradient of the
- * pre-activations d_dxproj [rows, ndir*4H].  d_whh is W_hh in its ORIGINAL layout [ndir, 4H, H].           */
+                           int64_t ldo, int out_col0, float* d_gates, float* d_cell, int variant, avs_stream_t stream);
+/* Backward through time (loss.backward() of scripts/train_av_model.py:93): from dL/dh_t (d_dout, same layout as the
+ * forward's d_out) to the gradient of the pre-activations d_dxproj [rows, ndir*4H].  d_whh is W_hh in its ORIGINAL
+ * layout [ndir, 4H, H].  variant: AVS_LSTM_AUTO (hidden = 256: W_hh partly resident on chip, the step's saved inputs
+ * fetched one step ahead; sums in another fixed order than the streaming kernel's - equal to rounding, deterministic)
+ * or AVS_LSTM_STREAM.                                                                                               */
 int avs_lstm_bwd_f32(const float* d_dout, int64_t ldo, int out_col0, const float* d_gates,
                      const float* d_cell, const float* d_whh, int hidden, int ndir, unsigned reverse_mask,
-                     const int64_t* d_seq_rows, int nseq, float* d_dxproj, avs_stream_t stream);
+                     const int64_t* d_seq_rows, int nseq, float* d_dxproj, int variant, avs_stream_t stream);
 
 /* ---- fusion (K13-K15) --------------------------------------------------- */
 

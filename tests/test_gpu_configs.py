@@ -237,6 +237,8 @@ def test_bench_contract_line(dev):
     assert r["launches"] > 0 and r["avg_launch_us"] > 0 and r["algorithmic_bytes_per_launch"] > 0
     assert abs(r["peak"] - 2500.0 / 3.0) < 1.0 and abs(r["mfma_rate_tflops"] - 3 * r["achieved"]) < 0.5
     assert r["traffic"] is None or "profiles/" in r["traffic_source"]   # replayed from a committed PMC summary, labelled
+    assert abs(r["frac_of_nominal_peak"] - r["achieved"] / 2500.0) < 1e-3   # the other reading, side by side
+    assert r["forms"] and abs(sum(f["share_of_step"] for f in r["forms"]) - r["share_of_step"]) < 0.02
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "frames/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
     assert c["runs"] == 5 and c["min"] <= c["value"] <= c["max"]       # median of 5 runs
@@ -268,6 +270,29 @@ def test_bench_other_headlines(dev, dtype, config):
     assert r is not None and r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     if dtype == "f32split":
         assert abs(r["peak"] - 2500.0 / 3.0) < 1.0
+
+
+def test_bench_config4_training_leg(dev):
+    """BASELINE configs[4] at world size 1 (scripts/train_av_model.py:70-96 on synthetic labels): the leg bench.py reports
+    as sub_results.config4_training - steps/s at T = 300 and 1800, the LSTM sweeps per time step, and the first six losses
+    against the oracle's (<= 1e-4 relative)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "4", "--steps", "3"],
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-800:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    leg = json.loads(lines[0])["detail"]
+    assert leg["loss_trajectory"]["within_bar"] is True and leg["loss_trajectory"]["steps"] == 6
+    for t_len in ("300", "1800"):
+        r = leg["lengths"][t_len]
+        assert r["steps_per_s"] > 0 and r["lstm_forward_us_per_time_step"] > 0
+        # the backward sweep keeps W_hh on chip like the forward: within 2x of its per-step time (VERDICT r3 item 2)
+        assert r["lstm_backward_over_forward"] <= 2.0, r
 
 
 def test_bench_under_the_launcher_one_rank(dev):

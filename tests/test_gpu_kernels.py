@@ -531,6 +531,40 @@ def test_lstm_vs_oracle(dev):
                 assert torch.equal(alt, out)
 
 
+def test_lstm_training_kernels_resident_vs_streaming(dev):
+    """hidden = 256 (the scorer's size): the training forward on the register / LDS-resident kernel is bit for bit the
+    streaming kernel's (outputs, saved gates, cell states); the resident backward sweep (W_hh partly on chip, the saved
+    inputs fetched a step ahead, sums over 16 row slices) equals the streaming sweep to rounding and is deterministic.
+    Four recurrences in one launch, as the training step uses them (scripts/train_av_model.py:88-93)."""
+    ops = _ops()
+    from avsum_amd import _abi
+    hid, ndir, lens = 256, 4, [700, 1, 333]
+    rows = sum(lens)
+    g = torch.Generator().manual_seed(21)
+    xproj = torch.randn(rows, ndir * 4 * hid, generator=g).to(dev)
+    whh = ((torch.rand(ndir, 4 * hid, hid, generator=g) - 0.5) * 2 / hid ** 0.5).to(dev)
+    whh_t = whh.transpose(1, 2).contiguous()
+    seq = torch.tensor(np.cumsum([0] + lens), dtype=torch.int64, device=dev)
+    dout = torch.randn(rows, ndir * hid + 8, generator=g).to(dev)
+    res = {}
+    for variant in (_abi.LSTM_AUTO, _abi.LSTM_STREAM):
+        out = torch.zeros(rows, ndir * hid + 8, device=dev)
+        gates, cell = ops.lstm_train_fwd(xproj, whh_t, hid, ndir, 0b1010, seq, out, 8, variant=variant)
+        dx = ops.lstm_bwd(dout, 8, gates, cell, whh, hid, ndir, 0b1010, seq, variant=variant)
+        dx2 = ops.lstm_bwd(dout, 8, gates, cell, whh, hid, ndir, 0b1010, seq, variant=variant)
+        assert torch.equal(dx, dx2)
+        res[variant] = (out, gates, cell, dx)
+    a, b = res[_abi.LSTM_AUTO], res[_abi.LSTM_STREAM]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    # inference kernel: the same h
+    inf = torch.zeros(rows, ndir * hid + 8, device=dev)
+    ops.lstm(xproj, whh_t, hid, ndir, 0b1010, seq, inf, 8)
+    assert torch.equal(inf, a[0])
+    scale = b[3].abs().max().item()
+    assert (a[3] - b[3]).abs().max().item() <= 2e-5 * scale   # 700-step chains of fp32 sums in two orders
+    assert torch.isfinite(a[3]).all()
+
+
 def test_softmax_score_head_mha(dev):
     ops = _ops()
     from oracle import scorer as osc
