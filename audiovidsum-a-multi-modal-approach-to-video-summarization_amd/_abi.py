@@ -70,6 +70,8 @@ _SIGNATURES = {
     "avs_stem_workspace_bytes": (c_int64, [c_int]),
     "avs_stem_conv_bn_pool_bf16": (c_int, [P, c_int, c_float, POINTER(c_float), POINTER(c_float), P, c_int64, c_int, P, P,
                                            c_float, c_int, c_int, P, P, P, P, c_int64, P]),
+    "avs_stem_f16x2_workspace_bytes": (c_int64, [c_int]),
+    "avs_stem_conv_pool_f16x2": (c_int, [P, c_int, P, c_int64, c_int, P, P, c_float, P, P, P, P, c_int64, P]),
     "avs_bn_gram_affine_bf16": (c_int, [P, c_int64, c_int, P, P, P, c_int64, c_int, c_int64, c_int, P, P, c_float, P, P,
                                         P, c_int64, P]),
     "avs_conv1x1_affine_bf16": (c_int, [P, c_int64, c_int, P, P, P, c_int64, c_int, c_int64, c_int, P, P, P, c_int64,

@@ -169,6 +169,9 @@ class ResNet50Runner:
             return _W(pack(rows))
 
         w = {"stem": mkw(_stem_weight(t[0].weight, 8, dt)), "blocks": []}
+        if self.h2 and tuple(t[0].weight.shape) == (64, 3, 7, 7):
+            # the fused AVS_F16X2 stem: the input normalisation folded into the weights (the constant term in channel 3)
+            w["stem_h2"] = ops.stem_h2_operands(t[0].weight, 1.0, RESNET_MEAN, RESNET_STD)
 
         def bn(m):
             return (m.weight.detach().float().contiguous(), m.bias.detach().float().contiguous(), float(m.eps),
@@ -390,6 +393,14 @@ class ResNet50Runner:
                                                 apply=not raw)
             if raw:
                 x_aff = (sc0, sh0)
+        elif (self.fused_stem and self.h2 and self.bn_mode == "batch" and uniform and "stem_h2" in w and "cat0" in w
+              and self._gram_h2_ok(64, w["cat0"][0].shape[0], 1, 1, gsz * 56 * 56)):
+            # AVS_F16X2: one fused launch (uint8 frames -> conv1 on the fp16 matrix cores, two MFMAs per product -> centred
+            # statistics -> the pooled RAW map); bn1 + ReLU are applied by the first block's Gram pass, which reads the map
+            # anyway and stores the finished activation in place
+            gamma, beta, eps = w["bn1"][:3]
+            x, sc0, sh0 = ops.stem_conv_pool_h2(frames_u8, w["stem_h2"], gsz, gamma, beta, eps)
+            x_aff = (sc0, sh0)
         else:
             x0 = ops.frames_normalize(frames_u8, dt, 1.0, RESNET_MEAN, RESNET_STD, 230, 232, 3, 3, code=self.ecode)
             geom, xs, _ = self._stem_geom(n)
@@ -406,7 +417,26 @@ class ResNet50Runner:
             sd = slot() if "cd" in blk else False
             s3 = slot()
             idn = None
-            if x_aff is not None:
+            if x_aff is not None and self.h2:
+                # AVS_F16X2, first block on the fused stem's RAW pooled map: the Gram pass applies bn1 + ReLU on the way in,
+                # stores the finished activation in place (the identity input of nothing else: conv1 and the downsample
+                # read it) and gives both BatchNorms' affines; then one streaming pass each
+                wcat, gcat, bcat, eps, c1n = w["cat0"]
+                gmax = gsz * hcur * hcur
+                sc, sf = ops.bn_gram_affine_h2(x.view(-1, cin), wcat, gmax, gcat, bcat, eps, in_affine=x_aff, store_input=True)
+                x_aff = None
+                geom, xs, _ = self._nhwc_geom(n, hcur, cin, 1, 1, 0, planes)
+                t1 = torch.empty((n, hcur, hcur, planes), dtype=dt, device=dev)
+                wsel, layout = blk["c1"].conv_operand()
+                ops.conv2d_affine(self.code, n, hcur, hcur, cin, 1, 1, hcur, hcur, planes, x, *xs, wsel, wsel.stride(0), t1,
+                                  planes, gmax, sc[:, :c1n].contiguous(), sf[:, :c1n].contiguous(), None, True, None,
+                                  w_layout=layout)
+                idn = torch.empty((n * hcur * hcur, planes * 4), dtype=dt, device=dev)
+                wsel, layout = blk["cd"].conv_operand()
+                ops.conv2d_affine(self.code, n, hcur, hcur, cin, 1, 1, hcur, hcur, planes * 4, x, *xs, wsel, wsel.stride(0),
+                                  idn, planes * 4, gmax, sc[:, c1n:].contiguous(), sf[:, c1n:].contiguous(), None, False,
+                                  None, w_layout=layout)
+            elif x_aff is not None:
                 # first block on the stem's raw map: one Gram matrix -> the folded affines of conv1 and the downsample,
                 # then one streaming pass each (bn1 + ReLU of the stem applied on the way in)
                 wcat, gcat, bcat, eps, c1n = w["cat0"]

@@ -12,7 +12,7 @@ from ._abi import (ACT_NONE, ACT_RELU, AVS_BF16, AVS_F16X2, AVS_F32, AVS_F32_SPL
                    lib)
 
 __all__ = [
-    "ACT_NONE", "ACT_RELU", "linear", "gemm_nt_batched", "conv2d", "conv2d_raw", "conv_bnlocal_tile_rows", "conv1x1_bn", "conv1x1_gram_bn", "bn_gram_affine", "gram_supported", "frames_normalize", "stem_conv_bn_pool", "resize_bilinear",
+    "ACT_NONE", "ACT_RELU", "linear", "gemm_nt_batched", "conv2d", "conv2d_raw", "conv_bnlocal_tile_rows", "conv1x1_bn", "conv1x1_gram_bn", "bn_gram_affine", "gram_supported", "frames_normalize", "stem_conv_bn_pool", "stem_h2_operands", "stem_conv_pool_h2", "resize_bilinear",
     "bn_batch_stats", "bn_apply", "bn_maxpool", "pool2d", "global_avgpool", "segment_mean", "hsv_frame_diff", "reflect_pad", "stft_f64", "stft_mel_fused", "power_mel",
     "clamp_topdb", "stft_mel_max", "stft_mel_segmean", "fill", "quantize", "resample", "lstm", "mha_batchaxis", "score_head", "mhsa_flash", "softmax_rows", "cdist", "dtw_path",
     "gather_scale", "dtype_code", "f16x2_pack", "f16x2_unpack", "bn_gram_affine_h2", "conv2d_affine",
@@ -641,6 +641,53 @@ def stem_conv_bn_pool(frames_u8, wt, denom, mean, std, frames_per_group, gamma, 
                                          1 if relu else 0, _p(y), _p(scale), _p(shift), _p(ws), ws.numel(),
                                          _stream()),
         "avs_stem_conv_bn_pool_bf16"), float(frames_u8.numel()) + 2.0 * y.numel())
+    return y, scale, shift
+
+
+def stem_h2_operands(weight, denom, mean, std):
+    """The weight operand of avs_stem_conv_pool_f16x2 from the stem's OIHW weight [64,3,7,7], with the normalisation
+    x = (v / denom - mean_c) / std_c folded in (prepared once per parameter version, in float64): an AVS_F16X2 image
+    [64, 224] in the 7 x 8 x 4 layout - channels 0-2 = w / (denom std_c), channel 3 = -sum_c w mean_c / std_c (the kernel
+    feeds it 1 for a pixel inside the image and 0 outside: the zero padding is of the NORMALISED input)."""
+    w64 = weight.detach().double()                                   # [O, C, kh, kw]
+    o, c, kh, kw = w64.shape
+    if (o, c, kh, kw) != (64, 3, 7, 7):
+        raise ValueError("the fused stem is ResNet-50's conv1: weight [64, 3, 7, 7]")
+    std_t = torch.tensor([float(v) for v in std], dtype=torch.float64, device=w64.device).view(1, 3, 1, 1)
+    mean_t = torch.tensor([float(v) for v in mean], dtype=torch.float64, device=w64.device).view(1, 3, 1, 1)
+    wp = torch.zeros((o, kh, 8, 4), dtype=torch.float64, device=w64.device)
+    wp[:, :, :kw, :c] = (w64 / (float(denom) * std_t)).permute(0, 2, 3, 1)
+    wp[:, :, :kw, 3] = -(w64 * (mean_t / std_t)).sum(dim=1)
+    return f16x2_pack(wp.reshape(o, kh * 8 * 4).float().contiguous())
+
+
+def stem_conv_pool_h2(frames_u8, wimg, frames_per_group, gamma, beta, eps):
+    """The fused ResNet-50 stem of the AVS_F16X2 path (avs_stem_conv_pool_f16x2): uint8 [n,224,224,3] -> the pooled RAW map
+    (f16x2 slots in a float32-typed tensor [n,56,56,64]) + bn1's folded affine (scale, shift) [groups, 64]; the finished
+    activation is relu(scale * y + shift), applied by the consumer (bn_gram_affine_h2's in_affine).
+    wimg = stem_h2_operands(...)."""
+    _dev(frames_u8, wimg, gamma, beta)
+    if frames_u8.dtype != torch.uint8 or tuple(frames_u8.shape[1:]) != (224, 224, 3) or not frames_u8.is_contiguous():
+        raise ValueError("frames must be contiguous uint8 [n,224,224,3]")
+    if wimg.dtype != torch.float32 or tuple(wimg.shape) != (64, 224):
+        raise ValueError("the weight operand must come from stem_h2_operands: f16x2 [64, 224]")
+    n = frames_u8.shape[0]
+    dev = frames_u8.device
+    y = torch.empty((n, 56, 56, 64), dtype=torch.float32, device=dev)
+    groups = n // frames_per_group if frames_per_group else 0
+    scale = torch.empty((groups, 64), dtype=torch.float32, device=dev)
+    shift = torch.empty((groups, 64), dtype=torch.float32, device=dev)
+    need = int(lib().avs_stem_f16x2_workspace_bytes(n))
+    ws = _stem_ws.get(_ws_key(dev))
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+        _stem_ws[_ws_key(dev)] = ws
+    # algorithmic: 2 * 147 MACs per output, uint8 frames in, pooled f16x2 map out
+    _timed("stem", AVS_F16X2, 2.0 * n * 112 * 112 * 64 * 147, lambda: check(
+        lib().avs_stem_conv_pool_f16x2(_p(frames_u8), n, _p(wimg), wimg.stride(0), int(frames_per_group),
+                                       _p(gamma), _p(beta), float(eps), _p(y), _p(scale), _p(shift), _p(ws), ws.numel(),
+                                       _stream()),
+        "avs_stem_conv_pool_f16x2"), float(frames_u8.numel()) + 4.0 * y.numel())
     return y, scale, shift
 
 

@@ -220,6 +220,26 @@ int avs_stem_conv_bn_pool_bf16(const uint8_t* d_frames, int n, float denom, cons
                                const float* d_beta, float eps, int apply, int relu, void* d_y, float* d_scale,
                                float* d_shift, void* d_ws, int64_t ws_bytes, avs_stream_t stream);
 
+/* The ResNet-50 stem of the AVS_F16X2 (parity-grade) path in one kernel + a fold: uint8 frames [n,224,224,3] ->
+ * conv1 7x7/2 of (x / denom - mean) / std -> the batch statistics of bn1 over groups of frames_per_group frames, and the
+ * 3x3/2 pad-1 pooling of the RAW convolution output -> d_y AVS_F16X2 [n,56,56,64]: per channel the window's maximum
+ * (gamma >= 0) or minimum (gamma < 0), i.e. maxpool(relu(bn1(.))) = relu(scale * d_y + shift) exactly (monotone map,
+ * sign(scale) = sign(gamma)); the consumer applies that affine + ReLU (avs_bn_gram_affine_f16x2's d_in_scale / d_in_shift).
+ * Replaces avs_frames_normalize_u8 + avs_conv2d_nhwc_bnstats + avs_bn_maxpool_nhwc of features/extractors.py:126-140 +
+ * children()[0:4] (:29,65); the normalised image and the 112x112x64 map never reach HBM.
+ * The normalisation is folded into the operands (x is affine in the byte value v, and bytes are exact fp16 numbers):
+ *   d_w    AVS_F16X2 [64, ldw >= 224 slots], a row = 7 kernel rows x 8 pixels x 4 channels (zero where kx = 7):
+ *          channels 0-2 = w[o,c,ky,kx] / (denom * std_c); channel 3 = -sum_c w[o,c,ky,kx] * mean_c / std_c, which the
+ *          kernel multiplies by 1 for a pixel inside the image and 0 outside (the convolution's zero padding is of
+ *          the NORMALISED input: only the taps inside contribute their constant).
+ * Two fp16 MFMAs per product (the image has no lo half).  Statistics: per frame sums about a pivot (the frame's own
+ * output at an interior pixel), frames merged by Chan's update in frame order: centred, deterministic.
+ * d_scale / d_shift [n / frames_per_group, 64]: bn1's folded affine.  d_ws: avs_stem_f16x2_workspace_bytes(n) bytes.
+ * n must be a multiple of frames_per_group (AVS_E_UNSUPPORTED otherwise: use the unfused sequence).                  */
+int64_t avs_stem_f16x2_workspace_bytes(int n);
+int avs_stem_conv_pool_f16x2(const uint8_t* d_frames, int n, const void* d_w, int64_t ldw, int frames_per_group, const float* d_gamma, const float* d_beta, float eps, void* d_y,
+                             float* d_scale, float* d_shift, void* d_ws, int64_t ws_bytes, avs_stream_t stream);
+
 /* 1x1 convolution + batch-statistics BatchNorm (+ residual, + ReLU) in one kernel, bf16, for equal-sized
  * groups of rows_per_group consecutive rows (a micro-batch of frames at one resolution):
  *   y[m,:] = act( bn_g(x[m,:] . w^T) + residual[m,:] ),  statistics of group g = m / rows_per_group.

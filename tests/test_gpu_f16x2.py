@@ -497,3 +497,67 @@ def test_affine_pass_long_reduction_every_variant(dev):
     got = ops.f16x2_unpack(outs[0]).cpu().double()
     assert torch.isfinite(got).all()
     assert (got - ref).abs().max().item() <= TOL * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("n,fpg,kind", [(6, 1, "random"), (8, 4, "random"), (3, 3, "random"), (4, 1, "low_contrast")])
+def test_fused_stem_f16x2(dev, n, fpg, kind):
+    """avs_stem_conv_pool_f16x2 (uint8 frames -> conv1 7x7/2 with the normalisation folded into the operands -> centred
+    statistics of bn1 -> the pooled RAW map) against (i) float64 on the reference's formula ((x - mean) / std without /255,
+    zero padding of the NORMALISED input, features/extractors.py:126-140 + children()[0:4]) and (ii) the unfused HIP
+    sequence it replaces (avs_frames_normalize_u8 -> avs_conv2d_nhwc_bnstats -> avs_bn_maxpool_nhwc).
+    Bars: statistics <= 2e-5, values <= 1e-5 of the scale (the f16x2 bars of this file); deterministic."""
+    import torch.nn.functional as F
+    ops = _ops()
+    from avsum_amd.cnn import RESNET_MEAN, RESNET_STD, _stem_weight
+    g = torch.Generator().manual_seed(140 + n)
+    if kind == "random":
+        frames = torch.randint(0, 256, (n, 224, 224, 3), dtype=torch.uint8, generator=g)
+    else:   # black / white / grey +- 1 level / letterbox: the stem's output is almost constant per channel
+        frames = torch.zeros((n, 224, 224, 3), dtype=torch.uint8)
+        frames[1] = 255
+        frames[2] = 128
+        frames[2, ::2, 1::2] = 129
+        frames[3, 40:180] = torch.randint(0, 256, (140, 224, 3), dtype=torch.uint8, generator=g)
+    w4 = torch.randn(64, 3, 7, 7, generator=g) * (2.0 / (64 * 49)) ** 0.5
+    gamma = torch.randn(64, generator=g)                      # both signs
+    beta = torch.randn(64, generator=g) * 0.5
+    fd, gd, bd = frames.to(dev), gamma.to(dev), beta.to(dev)
+    wimg = ops.stem_h2_operands(w4.to(dev), 1.0, RESNET_MEAN, RESNET_STD)
+    y, sc, sh = ops.stem_conv_pool_h2(fd, wimg, fpg, gd, bd, 1e-5)
+    y2, sc2, sh2 = ops.stem_conv_pool_h2(fd, wimg, fpg, gd, bd, 1e-5)
+    assert torch.equal(y.view(torch.int32), y2.view(torch.int32)) and torch.equal(sc, sc2) and torch.equal(sh, sh2)
+    assert y.shape == (n, 56, 56, 64) and sc.shape == (n // fpg, 64)
+    # (i) float64 on the fp32 normalised input (the reference's own rounding of x) and the fp32 weights
+    mean = torch.tensor(RESNET_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(RESNET_STD).view(1, 3, 1, 1)
+    x = ((frames.permute(0, 3, 1, 2).float() - mean) / std)
+    raw = F.conv2d(x.double(), w4.double(), None, 2, 3)                              # [n,64,112,112]
+    rg = raw.view(n // fpg, fpg, 64, 112, 112)
+    m = rg.mean((1, 3, 4), keepdim=True)
+    v = rg.var((1, 3, 4), unbiased=False, keepdim=True)
+    scale_ref = gamma.double().view(1, 1, 64, 1, 1) / torch.sqrt(v + 1e-5)
+    shift_ref = beta.double().view(1, 1, 64, 1, 1) - m * scale_ref
+    rel = ((sc.cpu().double() - scale_ref.view(-1, 64)).abs() / scale_ref.view(-1, 64).abs()).max().item()
+    # (the variance of a constant frame's channel is carried by its border pixels alone: ill-conditioned for any arithmetic)
+    assert rel < (2e-5 if kind == "random" else 2e-4), rel
+    ynorm = raw.abs().max().item() * scale_ref.abs().max().item()
+    assert (sh.cpu().double() - shift_ref.view(-1, 64)).abs().max().item() < (2e-5 if kind == "random" else 2e-4) * max(1.0, ynorm)
+    sgn = torch.sign(gamma + (gamma == 0)).double().view(1, 64, 1, 1)
+    pooled = (F.max_pool2d(raw * sgn, 3, 2, 1) * sgn).permute(0, 2, 3, 1)         # max where gamma >= 0, min elsewhere
+    got = ops.f16x2_unpack(y).cpu().double()
+    assert (got - pooled).abs().max().item() <= TOL * max(1.0, raw.abs().max().item())
+    # (ii) the unfused HIP sequence: same statistics to rounding; finished maps agree
+    code = ops.dtype_code(torch.float32, "f16x2")
+    x0 = ops.frames_normalize(fd, torch.float32, 1.0, RESNET_MEAN, RESNET_STD, 230, 232, 3, 3, code=code)
+    wk = ops.f16x2_pack(_stem_weight(w4, 8, torch.float32).to(dev))
+    rawd = torch.empty((n, 112, 112, 64), dtype=torch.float32, device=dev)
+    geom, xs = (n, 230, 112, 32, 7, 1, 2, 1, 0, 0, 112, 112, 64), (230 * 232 * 4, 232 * 4, 8)
+    scu, shu = ops.conv2d_raw(code, *geom, x0, *xs, wk, wk.stride(0), rawd, 64, bnstats=(fpg * 112 * 112, gd, bd, 1e-5))
+    assert ((sc - scu).abs() / scu.abs()).max().item() < (4e-5 if kind == "random" else 4e-4)
+    rows = torch.arange(0, n + 1, fpg, dtype=torch.int64, device=dev) * 112 * 112
+    yu = ops.bn_maxpool(rawd, scu, shu, rows, True, 3, 2, 1, torch.empty((n, 56, 56, 64), device=dev), code=code)
+    gidx = (torch.arange(n) // fpg).to(dev)
+    fin = torch.relu(ops.f16x2_unpack(y) * sc[gidx].view(n, 1, 1, 64) + sh[gidx].view(n, 1, 1, 64))
+    fu = ops.f16x2_unpack(yu)
+    bar = (2e-5 if kind == "random" else 5e-4) * max(1.0, fu.abs().max().item())
+    assert (fin - fu).abs().max().item() <= bar
