@@ -85,6 +85,10 @@ def folded_dft_tables():
     return cos_t, sin_t
 
 
+class _SegmentTable(tuple):
+    """(blocks, seg_block, seg_frames) device tensors + .span = the (first, last) STFT frame the segments cover."""
+
+
 class MelPlan:
     """Device-resident constants + the launch sequence for log2-mel and MFCC."""
 
@@ -92,6 +96,7 @@ class MelPlan:
 
     def __init__(self, sample_rate, n_mels, n_mfcc, device):
         self.sample_rate, self.n_mels, self.n_mfcc, self.device = sample_rate, n_mels, n_mfcc, device
+        self.one_pass_means = True   # segment_means: one DFT pass when the segments cover the track (False: always two)
         basis = windowed_dft_basis()  # [402, 400] float64: fp32 window values x cos/sin evaluated in float64
         bt = np.zeros((N_FFT, 448), dtype=np.float64)
         bt[:, :2 * N_BINS] = basis.T
@@ -170,13 +175,17 @@ class MelPlan:
             seg_block.append(len(blocks))
             seg_frames.append(max(0, b - a))
         mk = lambda v, shape: torch.tensor(v, dtype=torch.int32).reshape(shape).to(device)
-        return mk(blocks, (len(blocks), 3)), mk(seg_block, (len(seg_block),)), mk(seg_frames, (len(seg_frames),))
+        table = _SegmentTable((mk(blocks, (len(blocks), 3)), mk(seg_block, (len(seg_block),)), mk(seg_frames, (len(seg_frames),))))
+        table.span = (int(bounds[0]), int(bounds[-1])) if len(bounds) else (0, 0)   # the STFT frames the segments cover
+        return table
 
     def segment_means(self, wave, table, out_log2=None, out_mfcc_db=None, top_db=80.0):
         """Per segment (a shot's slice of the track) the time mean of the log2-mel rows (out_log2 [nseg, >= n_mels]) and
         of the top_db-clamped dB-mel rows (out_mfcc_db; its DCT is the mean of the MFCC rows: the DCT and mfcc_proj are
-        linear) without the per-frame matrices (features/extractors.py:232-246 pool them over time): two passes over
-        the waveform - the track's maximum for the clamp, then the means - nothing per frame in HBM."""
+        linear); features/extractors.py:232-246 pool the per-frame matrices over time.  The clamp is relative to the
+        TRACK's maximum: when the segments cover the whole track (the usual case) ONE pass of the DFT finds it while it
+        writes the unclamped dB rows to a workspace, and a bandwidth-bound pass clamps and sums them; otherwise the
+        maximum takes its own pass over the track first.  Same values, same order: bit-identical either way."""
         t = wave.numel()
         if t <= N_FFT // 2:
             raise RuntimeError(f"Argument #4: Padding size should be less than the corresponding input dimension, "
@@ -185,7 +194,8 @@ class MelPlan:
         if wave.data_ptr() % 16:
             wave = wave.clone()
         args = (wave, self.window, self.cos_t, self.sin_t, self.fb, self.fb_lo, self.fb_hi)
-        gmax = ops.stft_mel_max(*args) if out_mfcc_db is not None else None
+        covered = getattr(table, "span", None) == (0, 1 + t // HOP)
+        gmax = ops.stft_mel_max(*args) if (out_mfcc_db is not None and not (covered and self.one_pass_means)) else None
         return ops.stft_mel_segmean(*args, *table, gmax=gmax, top_db=top_db, out_log2=out_log2, out_db=out_mfcc_db)
 
     def log2_mel_and_mfcc(self, wave, top_db=80.0):

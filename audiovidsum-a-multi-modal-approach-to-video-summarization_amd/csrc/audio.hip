@@ -195,13 +195,15 @@ __global__ __launch_bounds__(256, 2) void stft_mel_fused_kernel(
     const double* __restrict__ cos_t, const double* __restrict__ sin_t, const float* __restrict__ fb,
     const int* __restrict__ fb_lo, const int* __restrict__ fb_hi, int nmel, float* __restrict__ out_log2,
     float* __restrict__ out_db, float* __restrict__ out_pow, float* __restrict__ gmax, const int* __restrict__ blocks,
-    float* __restrict__ part_log2, float* __restrict__ part_db, const float* __restrict__ max_in, float top_db) {
+    float* __restrict__ part_log2, float* __restrict__ part_db, const float* __restrict__ max_in, float top_db,
+    float* __restrict__ db_rows) {
   constexpr int SPAN = AVS_FUSED_FPB * AVS_FUSED_HOP + (AVS_FUSED_NFFT - AVS_FUSED_HOP);   // 6600 samples
   __shared__ __attribute__((aligned(16))) float span[SPAN];
   __shared__ double win[AVS_FUSED_NFFT];
   __shared__ float pw[AVS_FUSED_FPB][AVS_FUSED_BINS + 3];
   const int tid = threadIdx.x;
-  const long long f0 = SEG ? (long long)blocks[3 * blockIdx.x] : (long long)blockIdx.x * AVS_FUSED_FPB;
+  long long f0 = SEG ? (long long)blocks[3 * blockIdx.x] : (long long)blockIdx.x * AVS_FUSED_FPB;
+  if (SEG) f0 = f0 < 0 ? 0 : (f0 >= frames ? frames - 1 : f0);   // device table: clamped into the track
   // ---- stage the span: padded position q = f0 * 200 + i is sample q - 200, reflected at both ends
   const long long q0 = f0 * AVS_FUSED_HOP - AVS_FUSED_NFFT / 2;
   for (int i = tid * 4; i < SPAN; i += 256 * 4) {
@@ -274,9 +276,14 @@ __global__ __launch_bounds__(256, 2) void stft_mel_fused_kernel(
   __syncthreads();
   // ---- mel + log: a thread owns (frame, mel) pairs and sums its filter's non-zero bins in ascending order
   if constexpr (SEG) {
-    // a thread owns a mel band and walks the block's frames in order: sums of log2(mel + 1e-6) and of the clamped dB
-    const int nf = blocks[3 * blockIdx.x + 1];
-    const float thr = part_db ? 10.f * log10f(*max_in) - top_db : 0.f;
+    // a thread owns a mel band and walks the block's frames in order: sums of log2(mel + 1e-6) and of the clamped dB.
+    // db_rows (one-pass mode): the track's maximum is not known yet - the block's UNCLAMPED dB rows go to the workspace
+    // ([block][32][nmel]) and the maximum of the clamped mel power to gmax; segment_db_sum_kernel clamps and sums them
+    // (same values, same order: bit-identical to the two-pass form)
+    int nf = blocks[3 * blockIdx.x + 1];
+    nf = nf < 0 ? 0 : (nf > AVS_FUSED_FPB ? AVS_FUSED_FPB : nf);   // (the table is device data: never trust it past the tile)
+    const float thr = (part_db && !db_rows) ? 10.f * log10f(*max_in) - top_db : 0.f;
+    float lmax = 0.f;
     for (int m = tid; m < nmel; m += 256) {
       const int lo = fb_lo[m], hi = fb_hi[m];
       float s_log = 0.f, s_db = 0.f;
@@ -284,10 +291,21 @@ __global__ __launch_bounds__(256, 2) void stft_mel_fused_kernel(
         float a = 0.f;
         for (int k = lo; k < hi; ++k) a += pw[f][k] * fb[(long long)k * nmel + m];
         s_log += log2f(a + 1e-6f);
-        s_db += fmaxf(10.f * log10f(fmaxf(a, 1e-10f)), thr);
+        const float cl = fmaxf(a, 1e-10f);
+        const float db = 10.f * log10f(cl);
+        if (db_rows) {
+          lmax = fmaxf(lmax, cl);
+          db_rows[((long long)blockIdx.x * AVS_FUSED_FPB + f) * nmel + m] = db;
+        } else {
+          s_db += fmaxf(db, thr);
+        }
       }
       if (part_log2) part_log2[(long long)blockIdx.x * nmel + m] = s_log;
-      if (part_db) part_db[(long long)blockIdx.x * nmel + m] = s_db;
+      if (part_db && !db_rows) part_db[(long long)blockIdx.x * nmel + m] = s_db;
+    }
+    if (db_rows) {
+      lmax = avs_wave_max(lmax);
+      if ((tid & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(gmax), __float_as_uint(lmax));
     }
     return;
   }
@@ -331,9 +349,25 @@ extern "C" int avs_stft_mel_fused_f32(const float* d_wave, int64_t t, const doub
   AVS_REQUIRE(blocks < (1ll << 31), AVS_E_SHAPE, "%s: too many frames", who);
   hipLaunchKernelGGL(stft_mel_fused_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_wave,
                      (long long)t, frames, d_window, d_cos, d_sin, d_fb, d_fb_lo, d_fb_hi, nmel, d_log2mel, d_db, d_power,
-                     d_max, (const int*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr, 0.f);
+                     d_max, (const int*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr, 0.f, (float*)nullptr);
   AVS_CHECK_LAUNCH(who);
   return AVS_OK;
+}
+
+// One-pass mode of avs_stft_mel_segmean_f32: part_db[b, m] = sum over the block's frames (in order) of max(db_rows, threshold),
+// the threshold from the track maximum the front-end pass has just found.  Bandwidth-bound: reads the dB rows once.
+__global__ __launch_bounds__(256) void segment_db_sum_kernel(const float* __restrict__ db_rows, const int* __restrict__ blocks,
+                                                             int nmel, const float* __restrict__ gmax, float top_db,
+                                                             float* __restrict__ part_db) {
+  int nf = blocks[3 * blockIdx.x + 1];
+  nf = nf < 0 ? 0 : (nf > AVS_FUSED_FPB ? AVS_FUSED_FPB : nf);
+  const float thr = 10.f * log10f(*gmax) - top_db;
+  for (int m = threadIdx.x; m < nmel; m += 256) {
+    const float* __restrict__ r = db_rows + (long long)blockIdx.x * AVS_FUSED_FPB * nmel + m;
+    float s = 0.f;
+    for (int f = 0; f < nf; ++f) s += fmaxf(r[(long long)f * nmel], thr);
+    part_db[(long long)blockIdx.x * nmel + m] = s;
+  }
 }
 
 // out[s, m] = (sum of part[b, m] over the blocks b of segment s, in block order) / frames of s
@@ -349,10 +383,17 @@ __global__ __launch_bounds__(256) void segment_fold_kernel(const float* __restri
   }
 }
 
+extern "C" int64_t avs_stft_mel_segmean_workspace_bytes(int nblocks, int nmel, int want_log2, int want_db, int find_max) {
+  if (nblocks < 0 || nmel <= 0) return AVS_E_SHAPE;
+  const int64_t per = (int64_t)nblocks * nmel * 4;
+  // per-block sums of each requested mean + (one-pass mode) the blocks' unclamped dB rows [nblocks][32][nmel]
+  return per * ((want_log2 ? 1 : 0) + (want_db ? 1 : 0)) + ((want_db && find_max) ? per * AVS_FUSED_FPB : 0);
+}
+
 extern "C" int avs_stft_mel_segmean_f32(const float* d_wave, int64_t t, const double* d_window, const double* d_cos,
                                         const double* d_sin, const float* d_fb, const int* d_fb_lo, const int* d_fb_hi,
                                         int nmel, const int* d_blocks, int nblocks, const int* d_seg_block,
-                                        const int* d_seg_frames, int nseg, const float* d_max, float top_db,
+                                        const int* d_seg_frames, int nseg, float* d_max, int find_max, float top_db,
                                         float* d_mean_log2, int64_t ld_log2, float* d_mean_db, int64_t ld_db, void* d_ws,
                                         int64_t ws_bytes, avs_stream_t stream) {
   const char* who = "avs_stft_mel_segmean_f32";
@@ -368,16 +409,24 @@ extern "C" int avs_stft_mel_segmean_f32(const float* d_wave, int64_t t, const do
   AVS_REQUIRE((!d_mean_log2 || ld_log2 >= nmel) && (!d_mean_db || ld_db >= nmel), AVS_E_SHAPE, "%s: output rows too short", who);
   AVS_REQUIRE(avs_aligned16(d_wave), AVS_E_ALIGN, "%s: the waveform must be 16-byte aligned", who);
   const int64_t per = (int64_t)nblocks * nmel * 4;
-  const int64_t need = per * ((d_mean_log2 ? 1 : 0) + (d_mean_db ? 1 : 0));
+  const bool one_pass = d_mean_db && find_max;
+  const int64_t need = avs_stft_mel_segmean_workspace_bytes(nblocks, nmel, d_mean_log2 != nullptr, d_mean_db != nullptr, find_max);
   AVS_REQUIRE(d_ws && ws_bytes >= need, AVS_E_WORKSPACE, "%s: workspace %lld < %lld bytes", who, (long long)ws_bytes,
               (long long)need);
   float* p_log2 = d_mean_log2 ? (float*)d_ws : nullptr;
   float* p_db = d_mean_db ? (float*)((char*)d_ws + (d_mean_log2 ? per : 0)) : nullptr;
   const long long frames = 1 + t / AVS_FUSED_HOP;
-  if (nblocks > 0)
+  float* rows = one_pass ? (float*)((char*)d_ws + per * ((d_mean_log2 ? 1 : 0) + 1)) : nullptr;
+  if (one_pass) AVS_REQUIRE(hipMemsetAsync(d_max, 0, sizeof(float), (hipStream_t)stream) == hipSuccess, AVS_E_HIP, "%s: memset", who);
+  if (nblocks > 0) {
     hipLaunchKernelGGL(stft_mel_fused_kernel<true>, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, d_wave,
                        (long long)t, frames, d_window, d_cos, d_sin, d_fb, d_fb_lo, d_fb_hi, nmel, (float*)nullptr,
-                       (float*)nullptr, (float*)nullptr, (float*)nullptr, d_blocks, p_log2, p_db, d_max, top_db);
+                       (float*)nullptr, (float*)nullptr, one_pass ? d_max : (float*)nullptr, d_blocks, p_log2, p_db, d_max,
+                       top_db, rows);
+    if (one_pass)
+      hipLaunchKernelGGL(segment_db_sum_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, rows, d_blocks, nmel,
+                         d_max, top_db, p_db);
+  }
   long long gx = avs_cdiv((long long)nseg * nmel, 256);
   if (gx > 4096) gx = 4096;
   if (d_mean_log2)

@@ -872,15 +872,22 @@ _segmean_ws = {}
 
 def stft_mel_segmean(wave, window, cos_t, sin_t, fb, fb_lo, fb_hi, blocks, seg_block, seg_frames, gmax=None,
                      top_db=80.0, out_log2=None, out_db=None):
-    """Time means per segment of log2(mel + 1e-6) (out_log2 [nseg, >= nmel]) and of the top_db-clamped dB mel (out_db,
-    needs gmax from stft_mel_max) straight from the waveform (avs_stft_mel_segmean_f32): no per-frame matrix is written.
+    """Time means per segment of log2(mel + 1e-6) (out_log2 [nseg, >= nmel]) and of the top_db-clamped dB mel (out_db)
+    straight from the waveform (avs_stft_mel_segmean_f32).  gmax: the maximum the clamp is relative to (from
+    stft_mel_max: a second pass of the DFT, nothing per frame in HBM); gmax=None with out_db: ONE pass of the DFT that also
+    finds the maximum over the table's blocks (the whole track when the table covers it), the unclamped dB rows going
+    through the workspace - bit-identical means.
     blocks int32 [nblocks, 3] = (first STFT frame, frames <= 32, segment); seg_block int32 [nseg + 1]; seg_frames
     int32 [nseg] - all on the device (audio.MelPlan.segment_table builds them)."""
     _dev(wave, blocks, seg_block, seg_frames, out_log2, out_db, gmax)
     _f32(wave, "wave")
     nmel = fb.shape[1]
     nblocks, nseg = blocks.shape[0], seg_frames.numel()
-    need = nblocks * nmel * 4 * (int(out_log2 is not None) + int(out_db is not None))
+    find_max = int(out_db is not None and gmax is None)
+    if find_max:
+        gmax = torch.empty(1, dtype=torch.float32, device=wave.device)
+    need = int(lib().avs_stft_mel_segmean_workspace_bytes(nblocks, nmel, int(out_log2 is not None),
+                                                          int(out_db is not None), find_max))
     key = _ws_key(wave.device)
     ws = _segmean_ws.get(key)
     if ws is None or ws.numel() < need:
@@ -890,9 +897,10 @@ def stft_mel_segmean(wave, window, cos_t, sin_t, fb, fb_lo, fb_hi, blocks, seg_b
     nbytes = 4.0 * t + 4.0 * nseg * nmel * (int(out_log2 is not None) + int(out_db is not None))
     _timed("audio", AVS_F32, nbytes, lambda: check(
         lib().avs_stft_mel_segmean_f32(_p(wave), t, _p(window), _p(cos_t), _p(sin_t), _p(fb), _p(fb_lo), _p(fb_hi), nmel,
-                                       _p(blocks), nblocks, _p(seg_block), _p(seg_frames), nseg, _p(gmax), float(top_db),
-                                       _p(out_log2), out_log2.stride(0) if out_log2 is not None else 0, _p(out_db),
-                                       out_db.stride(0) if out_db is not None else 0, _p(ws), ws.numel(), _stream()),
+                                       _p(blocks), nblocks, _p(seg_block), _p(seg_frames), nseg, _p(gmax), find_max,
+                                       float(top_db), _p(out_log2), out_log2.stride(0) if out_log2 is not None else 0,
+                                       _p(out_db), out_db.stride(0) if out_db is not None else 0, _p(ws), ws.numel(),
+                                       _stream()),
         "avs_stft_mel_segmean_f32"))
     return out_log2, out_db
 

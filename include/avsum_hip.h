@@ -419,15 +419,22 @@ int avs_stft_mel_fused_f32(const float* d_wave, int64_t t, const double* d_windo
  * (first STFT frame, frames <= 32, segment) - every segment cut into runs of at most 32 frames, in order -,
  * d_seg_block int32 [nseg + 1] = first block of each segment, d_seg_frames int32 [nseg] = its frame count.  Out:
  * d_mean_log2 [nseg, ld_log2] = mean over the segment's frames of log2(mel + 1e-6), d_mean_db [nseg, ld_db] = mean of
- * max(10 log10(max(mel, 1e-10)), 10 log10(*d_max) - top_db) (d_max: the track's largest clamped mel power, from an
- * avs_stft_mel_fused_f32 call with only d_max requested) - by linearity the DCT / mfcc_proj of that mean IS the mean
- * of the MFCC rows.  Nothing per frame reaches HBM (features/extractors.py:232-246 pool the per-frame matrices over
- * time); d_ws: nblocks * nmel * 4 bytes per requested output; deterministic (block partial sums folded in order).  */
+ * max(10 log10(max(mel, 1e-10)), 10 log10(*d_max) - top_db) - by linearity the DCT / mfcc_proj of that mean IS the mean
+ * of the MFCC rows (features/extractors.py:232-246 pool the per-frame matrices over time).  *d_max = the largest
+ * clamped mel power the clamp is relative to:
+ *   find_max = 0: given by the caller (an avs_stft_mel_fused_f32 call with only d_max requested: a second pass of the
+ *                 DFT over the track) - nothing per frame reaches HBM;
+ *   find_max = 1: found by THIS call over the frames of its blocks (a table that covers the whole track gives the track
+ *                 maximum): ONE pass of the DFT that writes the blocks' unclamped dB rows to the workspace, then a
+ *                 bandwidth-bound pass clamps and sums them - the same values in the same order, bit-identical to
+ *                 find_max = 0 with that maximum.  *d_max is overwritten.
+ * d_ws: avs_stft_mel_segmean_workspace_bytes(...) bytes; deterministic (block partial sums folded in order).          */
+int64_t avs_stft_mel_segmean_workspace_bytes(int nblocks, int nmel, int want_log2, int want_db, int find_max);
 int avs_stft_mel_segmean_f32(const float* d_wave, int64_t t, const double* d_window, const double* d_cos,
                              const double* d_sin, const float* d_fb, const int* d_fb_lo, const int* d_fb_hi, int nmel,
                              const int* d_blocks, int nblocks, const int* d_seg_block, const int* d_seg_frames, int nseg,
-                             const float* d_max, float top_db, float* d_mean_log2, int64_t ld_log2, float* d_mean_db,
-                             int64_t ld_db, void* d_ws, int64_t ws_bytes, avs_stream_t stream);
+                             float* d_max, int find_max, float top_db, float* d_mean_log2, int64_t ld_log2,
+                             float* d_mean_db, int64_t ld_db, void* d_ws, int64_t ws_bytes, avs_stream_t stream);
 
 /* Power spectrum -> mel filterbank -> log.  d_spec is [frames, 2*nbins]
  * (re | im per frame, from avs_gemm_nt against the windowed DFT basis);

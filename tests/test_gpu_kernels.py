@@ -474,12 +474,20 @@ def test_segment_means_without_the_frame_matrices(dev):
     table = plan.segment_table(bounds, dev)
     nseg = len(bounds) - 1
     outs = []
-    for _ in range(2):
+    for one_pass in (True, True, False):   # one DFT pass (dB rows through the workspace) twice, then the two-pass form
+        plan.one_pass_means = one_pass
         m_log2 = torch.zeros((nseg, 130), device=dev)
         m_db = torch.zeros((nseg, 128), device=dev)
         plan.segment_means(wave, table, m_log2, m_db)
         outs.append((m_log2.clone(), m_db.clone()))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    plan.one_pass_means = True
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])     # deterministic
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])     # one pass == two passes, bitwise
+    # a table that does NOT cover the track (frames 34.. only) falls back to the track-maximum pass: the same means
+    sub = plan.segment_table(bounds[3:], dev)
+    s_log2, s_db = torch.zeros((nseg - 3, 130), device=dev), torch.zeros((nseg - 3, 128), device=dev)
+    plan.segment_means(wave, sub, s_log2, s_db)
+    assert torch.equal(s_log2, outs[0][0][3:]) and torch.equal(s_db, outs[0][1][3:])
     mel, mfcc = plan.log2_mel_and_mfcc(wave)
     _, db, _, gmax = plan._fused(wave, db=True)
     ops.clamp_topdb(db, gmax, 80.0)
