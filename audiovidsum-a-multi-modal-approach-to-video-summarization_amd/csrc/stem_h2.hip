@@ -21,7 +21,7 @@
 //  (3) CENTRED STATISTICS WITHOUT A SECOND ROUND: sums of (y - p) and (y - p)^2 about a per-channel pivot p = the frame's
 //      own output at an interior pixel of its first tile (for a constant frame every interior output EQUALS p: exact zeros;
 //      in general |p - mean| is a few standard deviations: one or two bits).  A lane keeps its two sums in registers for
-//      the whole frame (1568 values), the frame's (mean, M2) leave once, frames of a group are merged by Chan's update in
+//      the whole frame (49 tile sums of 32 values each), the frame's (mean, M2) leave once, frames of a group are merged by Chan's update in
 //      frame order: deterministic, nothing of the E[y^2] - E[y]^2 form about the origin.
 //
 // One workgroup (5 waves) = one frame x 32 of the 64 output channels, walking the frame's 49 tiles of 8 x 8 pooled outputs =
@@ -199,18 +199,23 @@ __global__ __launch_bounds__(THREADS, 3) void stem_h2_kernel(StemH2Params p) {
     }
     __syncthreads();   // every wave is done reading the patch: the raw tile may overwrite it; the pivot is published
     if (tile == 0) pivot = piv_s[lr];
-    // ---- statistics of the owned outputs about the pivot; raw tile (fp32) -> LDS [289][32 + pad]
+    // ---- statistics of the owned outputs about the pivot (the tile's 32 values summed first, then added to the frame's
+    // sums: chains of 32 + 49 terms instead of 1568 - on a smooth frame the long chain's rounding errors are correlated
+    // and cost 5e-5 of the variance); raw tile (fp32) -> LDS [289][32 + pad]
+    float t1 = 0.f, t2 = 0.f;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const float v = acc[mt][e];
         const float d = ((own >> (16 * mt + e)) & 1u) ? v - pivot : 0.f;
-        s1 += d;
-        s2 = fmaf(d, d, s2);
+        t1 += d;
+        t2 = fmaf(d, d, t2);
         const int m = wave * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         if (m < MROWS) *reinterpret_cast<float*>(mainb + m * RT_PITCH + lr * 4) = v;
       }
+    s1 += t1;
+    s2 += t2;
     __syncthreads();
     // ---- 3x3 / 2 max (min) over the raw tile: item = (pooled pixel of the 8 x 8, 8 of the 32 channels) -> one 32-byte run.
     // The item's two 16-byte chunks are read in an order that alternates with the pooled column: with the 160-byte row
