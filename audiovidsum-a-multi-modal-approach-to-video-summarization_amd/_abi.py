@@ -81,6 +81,9 @@ _SIGNATURES = {
     "avs_conv2d_nhwc_affine": (c_int, [POINTER(ConvDesc), P, P, P, c_int64, P, P, P, c_int64, P, P, P]),
     "avs_conv2d_bnlocal_tile_rows": (c_int, [POINTER(ConvDesc), c_int64]),
     "avs_conv2d_nhwc_bnlocal": (c_int, [POINTER(ConvDesc), P, P, P, c_int64, P, P, c_float, P, c_int64, P]),
+    "avs_conv2d_bncluster_workspace_bytes": (c_int64, [POINTER(ConvDesc), c_int64, c_int]),
+    "avs_conv2d_nhwc_bncluster": (c_int, [POINTER(ConvDesc), P, P, P, c_int64, c_int, P, P, c_float, P, c_int64, P, c_int64,
+                                          c_uint, P]),
     "avs_gemm_nt": (c_int, [c_int, c_int, c_int, c_int, P, c_int64, c_int64, P, c_int64, c_int64, P, c_int64,
                             c_int64, P, c_int, c_int64, c_float, c_int, c_int, P]),
     "avs_frames_normalize_u8": (c_int, [c_int, P, c_int, c_int, c_int, c_float, POINTER(c_float), POINTER(c_float),

@@ -139,6 +139,7 @@ class ResNet50Runner:
                                      # the split form's extra traffic (measured: 4.5 vs 3.4 ms per 8192 frames)
         self.bn_local = True         # the one-launch tile-local form where the library takes the shape
         self.gram_stats = True       # conv3 / downsample of layers 1-2: Gram-matrix statistics + one streaming pass
+        self.bn_cluster = True       # AVS_F16X2: groups of several 14x14 maps in ONE launch (tiles exchange their statistics)
         self.fused_stem = True       # uint8 frames -> conv1 -> pooled raw map + partial sums in one kernel
         self.stem_raw = True         # bn1 + ReLU ride in the staging of layer 1's first conv1 / downsample (both take the
                                      # one-pass form on ONE Gram matrix of the stem output): no finishing pass
@@ -225,15 +226,23 @@ class ResNet50Runner:
 
     def _local_plan(self, n, gsz):
         """Per layer (forward order): does the one-launch tile-local form take it for n frames in groups of gsz."""
-        key = (n, gsz)
+        key = (n, gsz, self.bn_cluster)
         plan = self._plans.get(key)
         if plan is None:
             dcode = self.code   # (the tile-local form exists for bf16 and f16x2)
             plan = []
             for geom, xs, wrs in self._layer_geoms(n):
                 ho, wo, cout = geom[10], geom[11], geom[12]
-                plan.append(gsz * ho * wo <= 256 and
-                            ops.conv_bnlocal_tile_rows(dcode, *geom, *xs, wrs, cout, gsz * ho * wo) is not None)
+                rows = gsz * ho * wo
+                if rows <= 256:
+                    plan.append(ops.conv_bnlocal_tile_rows(dcode, *geom, *xs, wrs, cout, rows) is not None)
+                elif (self.h2 and self.bn_cluster and gsz >= 2 and 192 < ho * wo <= 224
+                      and ops.conv_bncluster_ok(dcode, *geom, *xs, wrs, cout, rows, gsz)):
+                    # a group of gsz frames whose maps fill one 224-row tile each (layer 3 with the reference's 4-frame
+                    # micro-batches): the clustered tile-local form - the tiles of a group exchange their statistics
+                    plan.append(gsz)
+                else:
+                    plan.append(False)
             if len(self._plans) > 64:
                 self._plans.clear()
             self._plans[key] = plan
@@ -305,7 +314,8 @@ class ResNet50Runner:
         # keeps the shifted statistics pass over the stored output
         fast = uniform and (bf16 or self.f32_split or self.h2)
         if fast and (bf16 or self.h2) and local:
-            conv(act=act, bnlocal=(gmax, gamma, beta, eps, residual))
+            cluster = local if (local is not True and int(local) > 1) else 1   # (the plan: True = one group per tile)
+            conv(act=act, bnlocal=(gmax, gamma, beta, eps, residual), cluster=cluster)
             if pool is not None:
                 out, k, s, p = pooled(y)
                 return ops.pool2d(y, "max", k, s, p, out, code=self.ecode)

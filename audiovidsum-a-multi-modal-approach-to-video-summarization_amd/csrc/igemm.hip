@@ -1890,6 +1890,7 @@ static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream
   if (p.tile_rows && dtype == AVS_F16X2) {
     // a group of 193 .. 224 rows: the tile that fits it (local224.hip), unless the caller asks for the 256-row form
     const bool fits = igemm_h2_local224_ok(p, dtype);
+    AVS_REQUIRE(fits || p.cluster <= 1, AVS_E_UNSUPPORTED, "%s: the clustered form runs on the 224-row tile only", who);
     AVS_REQUIRE(fits || (p.variant & 3) != AVS_TILE_224, AVS_E_UNSUPPORTED,
                 "%s: AVS_TILE_224 takes AVS_F16X2, groups of 193..224 rows, cout in multiples of 128, cin in multiples of 16", who);
     if (fits) {
@@ -2111,6 +2112,68 @@ static int bnlocal_plan(const avs_conv_desc* d, int64_t rpg, IgemmParams& p, con
   p.tiles_n = p.N / bn;
   p.tile_rows = (int)(per_tile * rpg);
   return AVS_OK;
+}
+
+// ---- clustered tile-local BatchNorm (AVS_F16X2, the 224-row kernel): a group of `cluster` frames whose maps fill one
+// 224-row tile each (14 x 14: the reference's 4-frame micro-batches at ResNet-50's layer 3, features/extractors.py:48) ----
+static int bncluster_plan(const avs_conv_desc* d, int64_t rpg, int cluster, IgemmParams& p, const char* who) {
+  int st = conv_fill_params(d, (const void*)16, (const void*)16, nullptr, (void*)16, p, who);
+  if (st != AVS_OK) return st;
+  AVS_REQUIRE(rpg > 0 && cluster >= 2 && cluster <= 16, AVS_E_ARG, "%s: rows_per_group > 0 and 2 <= cluster <= 16", who);
+  if (p.M == 0) return AVS_OK;
+  const bool ok = (g_bnlocal != 0) && (g_pipe3 != 0) && d->dtype == AVS_F16X2 && rpg % cluster == 0 && p.M % rpg == 0 &&
+                  rpg / cluster > 192 && rpg / cluster <= 224 && p.N % 128 == 0 && (long long)p.K * 4 > 128 &&
+                  d->alpha == 1.0f && (p.ldc * 4) % 32 == 0 && (d->variant & AVS_STAGING_GENERIC) == 0;
+  AVS_REQUIRE(ok, AVS_E_UNSUPPORTED,
+              "%s: needs AVS_F16X2, equal groups of `cluster` tiles of 193..224 rows each, cout a multiple of 128, a "
+              "reduction of more than 128 bytes, aligned output rows", who);
+  p.tiles_n = p.N / 128;
+  p.tile_rows = (int)(rpg / cluster);
+  p.rows_per_group = (int)rpg;
+  p.cluster = cluster;
+  return AVS_OK;
+}
+
+extern "C" int64_t avs_conv2d_bncluster_workspace_bytes(const avs_conv_desc* d, int64_t rows_per_group, int cluster) {
+  IgemmParams p{};
+  const int st = bncluster_plan(d, rows_per_group, cluster, p, "avs_conv2d_bncluster_workspace_bytes");
+  if (st != AVS_OK) return st;
+  if (p.M == 0) return 64;
+  // a 64-byte header (the error counter) + 8-byte granules [tiles_m][tiles_n][4 waves][64 lanes]
+  return 64 + (int64_t)(p.M / p.tile_rows) * p.tiles_n * 4 * 64 * 8;
+}
+
+extern "C" int avs_conv2d_nhwc_bncluster(const avs_conv_desc* d, const void* d_x, const void* d_w, void* d_y,
+                                         int64_t rows_per_group, int cluster, const float* d_gamma, const float* d_beta,
+                                         float eps, const void* d_residual, int64_t ldr, void* d_xchg, int64_t xchg_bytes,
+                                         uint32_t epoch, avs_stream_t stream) {
+  const char* who = "avs_conv2d_nhwc_bncluster";
+  IgemmParams p{};
+  int st = bncluster_plan(d, rows_per_group, cluster, p, who);
+  if (st != AVS_OK) return st;
+  if (p.M == 0) return AVS_OK;
+  AVS_REQUIRE(d_x && d_w && d_y && d_gamma && d_beta && d_xchg, AVS_E_ARG, "%s: null pointer", who);
+  AVS_REQUIRE(epoch != 0, AVS_E_ARG, "%s: epoch 0 is the exchange buffer's initial state", who);
+  AVS_REQUIRE((((uintptr_t)d_y) & 31u) == 0 && (((uintptr_t)d_xchg) & 63u) == 0, AVS_E_ALIGN,
+              "%s: y must be 32-byte, the exchange buffer 64-byte aligned", who);
+  AVS_REQUIRE(!d_residual || ((((uintptr_t)d_residual) & 31u) == 0 && ldr % 8 == 0 && ldr >= p.N), AVS_E_ALIGN,
+              "%s: an AVS_F16X2 residual must be 32-byte aligned with a row stride in multiples of 8 slots, at least cout long", who);
+  const int64_t need = 64 + (int64_t)(p.M / p.tile_rows) * p.tiles_n * 4 * 64 * 8;
+  AVS_REQUIRE(xchg_bytes >= need, AVS_E_WORKSPACE, "%s: exchange buffer %lld < %lld bytes", who, (long long)xchg_bytes,
+              (long long)need);
+  p.x = (const char*)d_x;
+  p.w = (const char*)d_w;
+  p.y = (char*)d_y;
+  p.gamma = d_gamma;
+  p.beta = d_beta;
+  p.eps = eps;
+  p.residual = (const char*)d_residual;
+  p.ldr = ldr;
+  p.bias_mode = AVS_BIAS_NONE;
+  p.epoch = epoch;
+  p.xerr = reinterpret_cast<unsigned*>(d_xchg);
+  p.xchg = reinterpret_cast<unsigned long long*>((char*)d_xchg + 64);
+  return igemm_launch(d->dtype, p, 1, (hipStream_t)stream, who);
 }
 
 extern "C" int avs_conv2d_bnlocal_tile_rows(const avs_conv_desc* d, int64_t rows_per_group) {

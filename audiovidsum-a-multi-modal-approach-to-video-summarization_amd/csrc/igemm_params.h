@@ -47,6 +47,13 @@ struct IgemmParams {
   // AVS_F16P8 operands of the AVS_F16X2 1x1 forms (avs_conv_desc.formats): the input of the convolution + statistics
   // form (fetched into registers, the lo halves rebuilt there), the output / the residual of the given-affine form
   int x_p8, y_p8, res_p8;
+  // clustered tile-local BatchNorm (local224.hip): a group = `cluster` consecutive tiles of tile_rows rows; every wave
+  // publishes its tile's (mean, centred sum of squares) per column as 8-byte {value, epoch} granules in xchg
+  // [tiles_m][tiles_n][4 waves][64] and reads its partners' - one exchange, merged by Chan's update in tile order
+  int cluster;
+  unsigned epoch;
+  unsigned long long* xchg;
+  unsigned* xerr;    // a counter of waves whose bounded wait ran out (0 = every exchange completed)
 #ifdef AVS_STUDY
   int debug;  // ablation switches of the kernel-study build (tools/): 1 = skip output stores, 2 = skip A/B loads, ...
 #endif

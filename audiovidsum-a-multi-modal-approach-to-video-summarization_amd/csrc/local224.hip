@@ -51,8 +51,17 @@ __global__ __launch_bounds__(256, 2) void igemm_h2_local224_kernel(IgemmParams p
   const unsigned nwg = gridDim.x, orig = blockIdx.x;
   const unsigned q = nwg >> 3, rr = nwg & 7, xcd = orig & 7;
   const unsigned wg = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
-  const int tn = wg % p.tiles_n;
-  const int tm = wg / p.tiles_n;
+  int tn = wg % p.tiles_n;
+  int tm = wg / p.tiles_n;
+  if (p.cluster > 1) {
+    // clustered form: the tiles of a group wait for each other, so they take CONSECUTIVE block ids (dispatched together);
+    // a unit = cluster x tiles_n blocks, member j = l % cluster of column tile l / cluster: a frame's column tiles then
+    // sit on the XCDs j, j + cluster, ... (round-robin placement: speed only, never correctness)
+    const unsigned unit = (unsigned)p.cluster * (unsigned)p.tiles_n;
+    const unsigned u = orig / unit, l = orig - u * unit;
+    tn = (int)(l / (unsigned)p.cluster);
+    tm = (int)(u * (unsigned)p.cluster + l % (unsigned)p.cluster);
+  }
   const int m0 = tm * p.tile_rows;
   const int n0 = tn * L_BN;
   const int used = m0 + p.tile_rows <= p.M ? p.tile_rows : p.M - m0;   // rows of this tile that exist (one group)
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void igemm_h2_local224_kernel(IgemmParams p
   // The residual rows of the first three blocks are fetched BEFORE the reduction (48 registers through the main loop),
   // the next three when it ends: no memory latency is left in front of the first stores, and the rest land under them.
   const int col = n0 + wave * 32 + lr;
-  const float inv_n = 1.f / (float)p.rows_per_group;
+  const float inv_n = 1.f / (float)p.tile_rows;   // (a tile holds exactly one group, or one member of a cluster)
   const int lim = used - 4 * lh;   // block-local row offsets below this one exist
   // the residual runs of a block: staged row rl0 (+ 16) of the block, columns 8 * grp .. + 7 of the wave's 32
   const int rl0 = lane >> 2, grp = lane & 3;
@@ -282,8 +291,49 @@ __global__ __launch_bounds__(256, 2) void igemm_h2_local224_kernel(IgemmParams p
       s2 = roff < lim ? fmaf(d, d, s2) : s2;
     }
   s2 += __shfl_xor(s2, 32, 64);
-  const float sc = p.gamma[col] / sqrtf(s2 * inv_n + p.eps);
-  const float sf = p.beta[col] - mean * sc;
+  float g_mean = mean, g_var = s2 * inv_n;
+  if (p.cluster > 1) {
+    // ---- one exchange with the other tiles of the group (same columns): lane (lr, lh) publishes the tile's mean (lh = 0) or
+    // centred sum of squares (lh = 1) of column lr as an 8-byte {value, epoch} granule - ONE agent-scope store, untorn, so
+    // the tag IS the flag: no fence, no separate flag word - then reads the same granule of every partner until its tag is
+    // this launch's epoch.  Every wave publishes before it polls (no circular wait); partners are neighbours in dispatch
+    // order; the wait is bounded (p.xerr counts the waves that gave up: 0 after a healthy launch).
+    const int cj = tm % p.cluster, t0 = tm - cj;
+    unsigned long long* slot = p.xchg + (((long long)tm * p.tiles_n + tn) * 4 + wave) * 64 + lane;
+    const float mine = lh ? s2 : mean;
+    __hip_atomic_store(slot, ((unsigned long long)p.epoch << 32) | (unsigned long long)__float_as_uint(mine), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    const float nt = (float)p.tile_rows;
+    float n = 0.f, mu = 0.f, m2 = 0.f;
+    for (int j = 0; j < p.cluster; ++j) {
+      float mj = mean, qj = s2;
+      if (j != cj) {
+        const unsigned long long* src = p.xchg + (((long long)(t0 + j) * p.tiles_n + tn) * 4 + wave) * 64 + lane;
+        unsigned long long g = 0;
+        bool ok = false;
+        for (int spin = 0; spin < (1 << 20); ++spin) {
+          g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = (unsigned)(g >> 32) == p.epoch;
+          if (__builtin_amdgcn_read_exec() == __builtin_amdgcn_ballot_w64(ok)) break;
+          __builtin_amdgcn_s_sleep(8);
+        }
+        if (__builtin_amdgcn_read_exec() != __builtin_amdgcn_ballot_w64(ok) && lane == 0) atomicAdd(p.xerr, 1u);
+        const float v = __uint_as_float((unsigned)g);
+        const float o = __shfl_xor(v, 32, 64);
+        mj = lh ? o : v;
+        qj = lh ? v : o;
+      }
+      // Chan's update in tile order: the same operands in the same order on every tile of the group -> the same bits
+      const float tot = n + nt, delta = mj - mu;
+      mu += delta * (nt / tot);
+      m2 += qj + delta * delta * (n * nt / tot);
+      n = tot;
+    }
+    g_mean = mu;
+    g_var = m2 / n;
+  }
+  const float sc = p.gamma[col] / sqrtf(g_var + p.eps);
+  const float sf = p.beta[col] - g_mean * sc;
 #pragma unroll
   for (int mt = 0; mt < L_MT; ++mt)
 #pragma unroll
@@ -347,7 +397,8 @@ bool igemm_h2_local224_ok(const IgemmParams& p, int dtype) {
   const int tile_mode = p.variant & 3;
   if (dtype != AVS_F16X2 || !(tile_mode == AVS_TILE_AUTO || tile_mode == AVS_TILE_224)) return false;
   if (p.variant & AVS_STAGING_GENERIC) return false;
-  if (p.tile_rows != p.rows_per_group || p.rows_per_group <= 192 || p.rows_per_group > L_ROWS) return false;
+  const int cl = p.cluster > 1 ? p.cluster : 1;
+  if (p.tile_rows * cl != p.rows_per_group || p.tile_rows <= 192 || p.tile_rows > L_ROWS) return false;
   if (p.N % L_BN != 0 || p.M % p.rows_per_group != 0) return false;
   if (p.cin % L_STEP != 0 || p.K % L_STEP != 0 || p.K % p.cin != 0 || p.K / p.cin > 32) return false;
   const long long rows = 256;

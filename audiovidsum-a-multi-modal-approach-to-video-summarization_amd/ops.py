@@ -12,7 +12,7 @@ from ._abi import (ACT_NONE, ACT_RELU, AVS_BF16, AVS_F16X2, AVS_F32, AVS_F32_SPL
                    lib)
 
 __all__ = [
-    "ACT_NONE", "ACT_RELU", "linear", "gemm_nt_batched", "conv2d", "conv2d_raw", "conv_bnlocal_tile_rows", "conv1x1_bn", "conv1x1_gram_bn", "bn_gram_affine", "gram_supported", "frames_normalize", "stem_conv_bn_pool", "stem_h2_operands", "stem_conv_pool_h2", "resize_bilinear",
+    "ACT_NONE", "ACT_RELU", "linear", "gemm_nt_batched", "conv2d", "conv2d_raw", "conv_bnlocal_tile_rows", "conv_bncluster_ok", "cluster_exchange_errors", "conv1x1_bn", "conv1x1_gram_bn", "bn_gram_affine", "gram_supported", "frames_normalize", "stem_conv_bn_pool", "stem_h2_operands", "stem_conv_pool_h2", "resize_bilinear",
     "bn_batch_stats", "bn_apply", "bn_maxpool", "pool2d", "global_avgpool", "segment_mean", "hsv_frame_diff", "reflect_pad", "stft_f64", "stft_mel_fused", "power_mel",
     "clamp_topdb", "stft_mel_max", "stft_mel_segmean", "fill", "quantize", "resample", "lstm", "mha_batchaxis", "score_head", "mhsa_flash", "softmax_rows", "cdist", "dtw_path",
     "gather_scale", "dtype_code", "f16x2_pack", "f16x2_unpack", "bn_gram_affine_h2", "conv2d_affine",
@@ -248,6 +248,47 @@ def conv_bnlocal_tile_rows(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, 
     return int(r)
 
 
+def conv_bncluster_ok(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x_img_stride, x_row_stride, x_px_stride,
+                      w_row_stride, y_px_stride, rows_per_group, cluster):
+    """Does the library take this convolution + BatchNorm as ONE launch with groups of `cluster` tiles (the clustered
+    tile-local form, avs_conv2d_nhwc_bncluster)?"""
+    d = _abi.ConvDesc(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x_img_stride, x_row_stride,
+                      x_px_stride, w_row_stride, y_px_stride, ACT_NONE, 1.0)
+    r = lib().avs_conv2d_bncluster_workspace_bytes(ctypes.byref(d), int(rows_per_group), int(cluster))
+    if r == _abi.E_UNSUPPORTED:
+        return False
+    if r < 0:
+        check(int(r), "avs_conv2d_bncluster_workspace_bytes")
+    return True
+
+
+class _Exchange:
+    """The granule buffer of avs_conv2d_nhwc_bncluster on one (device, stream): zeroed once, epochs count up per call."""
+
+    def __init__(self):
+        self.buf, self.epoch = None, 0
+
+    def get(self, device, nbytes):
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = torch.zeros(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            self.epoch = 0
+        self.epoch += 1
+        if self.epoch >= 0xFFFFFFF0:      # (32-bit tags: start over on a cleared buffer)
+            self.buf.zero_()
+            self.epoch = 1
+        return self.buf, self.epoch
+
+
+_exchanges = {}
+
+
+def cluster_exchange_errors(device):
+    """Waves whose bounded partner wait ran out in the clustered BatchNorm launches on this device's current stream so far
+    (0 after healthy launches); reads the counter back (a host sync: for tests and debugging)."""
+    ex = _exchanges.get(_ws_key(device))
+    return 0 if ex is None or ex.buf is None else int(ex.buf[:4].view(torch.int32).item())
+
+
 _stats_ws = {}
 
 
@@ -270,7 +311,7 @@ def _stats_workspace(device, nbytes):
 
 def conv2d_raw(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x, x_img_stride, x_row_stride, x_px_stride,
                wt, w_row_stride, y, y_px_stride, bias=None, act=ACT_NONE, alpha=1.0, x_off=0, y_off=0, algo_k=None,
-               bnstats=None, bnlocal=None, algo_in_elems=None, w_layout=0, variant=0):
+               bnstats=None, bnlocal=None, algo_in_elems=None, w_layout=0, variant=0, cluster=1):
     """algo_k: the algorithmic reduction length when it differs from kh*kw*cin (zero-padded stem rows);
     algo_in_elems: input elements the launch reads when the geometry does not say (the re-viewed stem image).
     bnstats = (rows_per_group, gamma, beta, eps): the BatchNorm batch statistics of equal-sized row groups from the
@@ -278,6 +319,7 @@ def conv2d_raw(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x, x_i
     (scale, shift) [G, cout], or None when the library declines the shape (groups of < 64 rows).
     bnlocal = (rows_per_group, gamma, beta, eps, residual2d | None): the whole BatchNorm (+ residual, then `act`) in
     the convolution's launch (avs_conv2d_nhwc_bnlocal; shapes for which conv_bnlocal_tile_rows is not None).
+    cluster > 1 (with bnlocal): a group = `cluster` tiles (avs_conv2d_nhwc_bncluster: AVS_F16X2, 14x14 maps).
     w_layout: _abi.AVS_W_ROWS (wt[cout, K]) or AVS_W_KSTEP32 (the image weights_kstep32() makes).
     variant: avs_conv_desc.variant (_abi.TILE_128 / TILE_256 | STAGING_GENERIC): a per-call override of the tile /
     staging choice, for tests and the study tools (the library has no global tuning state)."""
@@ -304,6 +346,20 @@ def conv2d_raw(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout, x, x_i
             _rowmajor2d(residual, "residual")
             if residual.dtype != y.dtype or residual.shape != (n * ho * wo, cout):
                 raise ValueError("residual must be [rows, cout] in the activation dtype")
+        if cluster > 1:
+            need = lib().avs_conv2d_bncluster_workspace_bytes(ctypes.byref(d), int(rpg), int(cluster))
+            if need < 0:
+                check(int(need), "avs_conv2d_bncluster_workspace_bytes")
+            xbuf, epoch = _exchanges.setdefault(_ws_key(x.device), _Exchange()).get(x.device, need)
+            _timed("conv", dtype, flops, lambda: check(
+                lib().avs_conv2d_nhwc_bncluster(ctypes.byref(d), _p(x, x_off), _p(wt), _p(y, y_off), int(rpg), int(cluster),
+                                                _p(gamma), _p(beta), float(eps), _p(residual),
+                                                residual.stride(0) if residual is not None else 0, _p(xbuf), xbuf.numel(),
+                                                int(epoch), _stream()),
+                "avs_conv2d_nhwc_bncluster"),
+                   cbytes + (float(es) * n * ho * wo * cout if residual is not None else 0.0),
+                   form=f"clustered tile-local BatchNorm {kh}x{kw}")
+            return None
         _timed("conv", dtype, flops, lambda: check(
             lib().avs_conv2d_nhwc_bnlocal(ctypes.byref(d), _p(x, x_off), _p(wt), _p(y, y_off), int(rpg), _p(gamma),
                                           _p(beta), float(eps), _p(residual),

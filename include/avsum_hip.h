@@ -172,6 +172,25 @@ int avs_conv2d_bnlocal_tile_rows(const avs_conv_desc* desc, int64_t rows_per_gro
 int avs_conv2d_nhwc_bnlocal(const avs_conv_desc* desc, const void* d_x, const void* d_w, void* d_y,
                             int64_t rows_per_group, const float* d_gamma, const float* d_beta, float eps,
                             const void* d_residual, int64_t ldr, avs_stream_t stream);
+
+/* The same for groups LARGER than a tile, AVS_F16X2: a group = `cluster` consecutive tiles of rows_per_group / cluster
+ * rows each (193..224: one 14x14 map per tile - the reference's micro-batches of 4 frames at ResNet-50's layer 3,
+ * features/extractors.py:48).  Every tile computes its own centred statistics (mean, sum of squares about it) from its
+ * accumulators, publishes them per column as 8-byte {value, epoch} granules (one agent-scope store each: the tag is the
+ * flag), reads its partners' granules, and merges them by Chan's update in tile order - every tile of the group obtains
+ * the same bits; then normalises its accumulators (+ residual, + desc->act) and writes y once.  Nothing raw in HBM, no
+ * statistics / apply passes, deterministic.  The tiles of a group take consecutive block ids (they are dispatched together);
+ * the wait for a partner is bounded: the first word of d_xchg counts the waves whose wait ran out (0 after a healthy
+ * launch; check it where results are validated).
+ * d_xchg: avs_conv2d_bncluster_workspace_bytes(...) bytes, 64-byte aligned, ZEROED ONCE by the caller when allocated and
+ * then left alone; epoch: a value that is new for this buffer on every call (1, 2, 3, ...; never 0) - granules of earlier
+ * calls are then recognisably stale, nothing needs clearing between calls.
+ * AVS_E_UNSUPPORTED: not AVS_F16X2, tiles of fewer than 193 or more than 224 rows, cout not a multiple of 128.          */
+int64_t avs_conv2d_bncluster_workspace_bytes(const avs_conv_desc* desc, int64_t rows_per_group, int cluster);
+int avs_conv2d_nhwc_bncluster(const avs_conv_desc* desc, const void* d_x, const void* d_w, void* d_y,
+                              int64_t rows_per_group, int cluster, const float* d_gamma, const float* d_beta, float eps,
+                              const void* d_residual, int64_t ldr, void* d_xchg, int64_t xchg_bytes, uint32_t epoch,
+                              avs_stream_t stream);
 /* AVS_F16X2, 1x1 convolutions whose BatchNorm groups are too large for a tile (the expanding 1x1 layers of ResNet
  * layers 1-2: conv3 and the downsample branch, features/extractors.py:29,65): the batch statistics of the OUTPUT are
  * taken from the second moments of the narrow INPUT (avs_bn_gram_affine_f16x2: mean_y = W mean(a),

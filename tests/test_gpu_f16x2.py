@@ -278,6 +278,66 @@ def test_conv_bnlocal_f16x2(dev, cfg):
                            bnlocal=(rpg, gamma.to(dev), beta.to(dev), 1e-5, None), variant=_abi.TILE_224)
 
 
+_CLUSTER_CASES = [   # frames, hw (in), cin, cout, k, stride, frames per group, residual, relu, offset
+    (8, 14, 1024, 256, 1, 1, 4, False, True, 0.3),    # layer 3 conv1 with the reference's 4-frame micro-batches
+    (8, 14, 256, 256, 3, 1, 4, False, True, 0.3),     # ... conv2 (3x3, spatial taps)
+    (8, 14, 256, 1024, 1, 1, 4, True, True, 0.3),     # ... conv3 + residual, 8 column tiles
+    (12, 28, 512, 1024, 1, 2, 4, False, False, 0.3),  # the strided downsample to 14x14, no ReLU
+    (6, 14, 256, 256, 1, 1, 2, True, True, 40.0),     # two-frame groups (a video's tail), mean >> spread
+    (9, 14, 128, 128, 3, 1, 3, False, True, 0.3),     # three-frame groups
+    (70, 14, 256, 256, 1, 1, 7, True, True, 0.3),     # more tiles than one round of the chip's slots would order trivially
+]
+
+
+@pytest.mark.parametrize("cfg", _CLUSTER_CASES)
+def test_conv_bncluster_f16x2(dev, cfg):
+    """avs_conv2d_nhwc_bncluster: convolution + the whole batch-statistics BatchNorm (+ residual, + ReLU) in one launch for
+    groups of several 14x14 maps - one 224-row tile per frame, the tiles of a group exchange (mean, centred sum of squares)
+    as tagged 8-byte granules and merge them by Chan's update in tile order - against float64 arithmetic
+    (features/extractors.py:48: micro-batches of 4 frames; train-mode BatchNorm of the trunk, :29,65).
+    Deterministic run to run (the exchange carries values, never partial sums in arrival order); no wait ran out."""
+    ops = _ops()
+    frames, hw, cin, cout, k, s, gf, with_res, relu, offset = cfg
+    pad = k // 2
+    xp, wp, xv, wv = _conv_operands(frames, hw, hw, cin, cout, k, k, sum(cfg[:6]), offset)
+    raw = _conv_ref(xv, wv, s, pad)
+    ho = raw.shape[1]
+    rpg = gf * ho * ho
+    raw = raw.reshape(-1, cout)
+    g = torch.Generator().manual_seed(2)
+    gamma, beta = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    resp = emu_pack(torch.randn(raw.shape[0], cout, generator=g)) if with_res else None
+    ref = _bn_reference(raw, rpg, gamma, beta, emu_unpack(resp).double() if with_res else None, relu)
+    geom = (frames, hw, hw, cin, k, k, s, s, pad, pad, ho, ho, cout)
+    xs = (hw * hw * cin, hw * cin, cin)
+    code = ops.dtype_code(torch.float32, "f16x2")
+    assert ops.conv_bncluster_ok(code, *geom, *xs, wp.shape[1], cout, rpg, gf)
+    assert not ops.conv_bncluster_ok(code, *geom, *xs, wp.shape[1], cout, rpg, gf + 1)      # not whole tiles
+    xd, wd = xp.to(dev), wp.to(dev)
+    amp = max(1.0, (1.0 / torch.sqrt(raw.reshape(-1, rpg, cout).var(1, unbiased=False) + 1e-5)).max().item() *
+              raw.abs().max().item())
+    outs = []
+    for _ in range(3):
+        y = torch.full((frames, ho, ho, cout), float("nan"), device=dev)
+        ops.conv2d_raw(code, *geom, xd, *xs, wd, wd.stride(0), y, cout, act=ops.ACT_RELU if relu else ops.ACT_NONE,
+                       bnlocal=(rpg, gamma.to(dev), beta.to(dev), 1e-5, resp.to(dev) if with_res else None), cluster=gf)
+        outs.append(y)
+    assert ops.cluster_exchange_errors(dev) == 0
+    assert all(torch.equal(outs[0].view(torch.int32), o.view(torch.int32)) for o in outs[1:])
+    got = ops.f16x2_unpack(outs[0]).cpu().double().view(-1, cout)
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() <= TOL * amp
+    # the same group statistics as the unfused sequence (convolution + statistics, then the apply pass) to rounding
+    y2 = torch.empty((frames, ho, ho, cout), device=dev)
+    aff = ops.conv2d_raw(code, *geom, xd, *xs, wd, wd.stride(0), y2, cout, bnstats=(rpg, gamma.to(dev), beta.to(dev), 1e-5))
+    assert aff is not None
+    rows = torch.arange(0, frames // gf + 1, dtype=torch.int64, device=dev) * rpg
+    y2d = y2.view(-1, cout)
+    ops.bn_apply(y2d, aff[0], aff[1], rows, rpg, resp.to(dev) if with_res else None, ops.ACT_RELU if relu else ops.ACT_NONE,
+                 y2d, code=code)
+    assert (ops.f16x2_unpack(y2).cpu().double().view(-1, cout) - got).abs().max().item() <= 2 * TOL * amp
+
+
 def test_elementwise_f16x2(dev):
     """avs_bn_apply (+ residual, + ReLU), avs_bn_maxpool_nhwc, avs_pool2d_nhwc, avs_global_avgpool_nhwc,
     avs_bn_batch_stats on f16x2 tensors against float64 arithmetic on the unpacked values."""
