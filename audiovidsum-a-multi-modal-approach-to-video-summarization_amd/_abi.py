@@ -86,6 +86,7 @@ _SIGNATURES = {
                                           c_uint, P]),
     "avs_gemm_nt": (c_int, [c_int, c_int, c_int, c_int, P, c_int64, c_int64, P, c_int64, c_int64, P, c_int64,
                             c_int64, P, c_int, c_int64, c_float, c_int, c_int, P]),
+    "avs_pull_copy_u8": (c_int, [P, P, c_int64, c_int, P]),
     "avs_frames_normalize_u8": (c_int, [c_int, P, c_int, c_int, c_int, c_float, POINTER(c_float), POINTER(c_float),
                                         POINTER(c_float), P, c_int, c_int, c_int, c_int, P]),
     "avs_resize_bilinear_u8": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, P]),

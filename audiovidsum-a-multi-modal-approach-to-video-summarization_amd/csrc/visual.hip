@@ -928,3 +928,40 @@ extern "C" int avs_hsv_frame_diff_u8(const uint8_t* d_frames, int n, int h, int 
   AVS_CHECK_LAUNCH("avs_hsv_frame_diff_u8");
   return AVS_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Upload of frames by a PULL kernel: a few workgroups read pinned (device-mapped) host memory over PCIe with 16-byte
+// loads and store to HBM.  Unlike a copy-engine / blit transfer its footprint on the chip is the caller's choice
+// (`workgroups` CUs' worth of one 256-thread block each, 4 loads of 16 bytes in flight per lane), so the upload of the
+// next pass can run beside the current pass's kernels at a known, small cost (pipeline.py: the PCIe-inclusive path).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pull_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, long long n16,
+                                                        const uint8_t* __restrict__ tail_src, uint8_t* __restrict__ tail_dst,
+                                                        int tail) {
+  const long long stride = (long long)gridDim.x * 256;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a;
+    dst[i + stride] = b;
+    dst[i + 2 * stride] = c;
+    dst[i + 3 * stride] = d;
+  }
+  for (; i < n16; i += stride) dst[i] = src[i];
+  if (blockIdx.x == 0 && (int)threadIdx.x < tail) tail_dst[threadIdx.x] = tail_src[threadIdx.x];
+}
+
+extern "C" int avs_pull_copy_u8(const uint8_t* h_src_mapped, uint8_t* d_dst, int64_t bytes, int workgroups,
+                                avs_stream_t stream) {
+  AVS_REQUIRE(bytes >= 0 && workgroups > 0 && workgroups <= 1024, AVS_E_SHAPE, "avs_pull_copy_u8: bytes=%lld workgroups=%d",
+              (long long)bytes, workgroups);
+  if (bytes == 0) return AVS_OK;
+  AVS_REQUIRE(h_src_mapped && d_dst, AVS_E_ARG, "avs_pull_copy_u8: null pointer");
+  AVS_REQUIRE(avs_aligned16(h_src_mapped) && avs_aligned16(d_dst), AVS_E_ALIGN, "avs_pull_copy_u8: 16-byte aligned buffers");
+  const long long n16 = bytes / 16;
+  hipLaunchKernelGGL(pull_copy_kernel, dim3((unsigned)workgroups), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const uint4*>(h_src_mapped), reinterpret_cast<uint4*>(d_dst), n16, h_src_mapped + n16 * 16,
+                     d_dst + n16 * 16, (int)(bytes - n16 * 16));
+  AVS_CHECK_LAUNCH("avs_pull_copy_u8");
+  return AVS_OK;
+}

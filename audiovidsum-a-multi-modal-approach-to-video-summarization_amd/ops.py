@@ -12,7 +12,7 @@ from ._abi import (ACT_NONE, ACT_RELU, AVS_BF16, AVS_F16X2, AVS_F32, AVS_F32_SPL
                    lib)
 
 __all__ = [
-    "ACT_NONE", "ACT_RELU", "linear", "gemm_nt_batched", "conv2d", "conv2d_raw", "conv_bnlocal_tile_rows", "conv_bncluster_ok", "cluster_exchange_errors", "conv1x1_bn", "conv1x1_gram_bn", "bn_gram_affine", "gram_supported", "frames_normalize", "stem_conv_bn_pool", "stem_h2_operands", "stem_conv_pool_h2", "resize_bilinear",
+    "ACT_NONE", "ACT_RELU", "linear", "gemm_nt_batched", "conv2d", "conv2d_raw", "conv_bnlocal_tile_rows", "conv_bncluster_ok", "cluster_exchange_errors", "conv1x1_bn", "conv1x1_gram_bn", "bn_gram_affine", "gram_supported", "frames_normalize", "pull_copy", "stem_conv_bn_pool", "stem_h2_operands", "stem_conv_pool_h2", "resize_bilinear",
     "bn_batch_stats", "bn_apply", "bn_maxpool", "pool2d", "global_avgpool", "segment_mean", "hsv_frame_diff", "reflect_pad", "stft_f64", "stft_mel_fused", "power_mel",
     "clamp_topdb", "stft_mel_max", "stft_mel_segmean", "fill", "quantize", "resample", "lstm", "mha_batchaxis", "score_head", "mhsa_flash", "softmax_rows", "cdist", "dtw_path",
     "gather_scale", "dtype_code", "f16x2_pack", "f16x2_unpack", "bn_gram_affine_h2", "conv2d_affine",
@@ -661,6 +661,19 @@ def frames_normalize(frames_u8, dtype, denom, mean, std, out_h, out_w, pad_t, pa
                                         float(denom), m3, s3, a6, _p(out),
                                         out_h, out_w, pad_t, pad_l, _stream()), "avs_frames_normalize_u8")
     return out
+
+
+def pull_copy(host_pinned, dst, workgroups=16):
+    """dst (device uint8, contiguous) <- host_pinned (pinned host uint8, contiguous, same numel) by avs_pull_copy_u8: a kernel
+    of `workgroups` blocks reading the mapped host memory over PCIe, on the CURRENT stream."""
+    if host_pinned.is_cuda or not host_pinned.is_pinned() or not host_pinned.is_contiguous():
+        raise ValueError("pull_copy: the source must be a contiguous tensor in pinned host memory")
+    _dev(dst)
+    if not dst.is_contiguous() or dst.numel() * dst.element_size() != host_pinned.numel() * host_pinned.element_size():
+        raise ValueError("pull_copy: destination must be contiguous and of the same byte size")
+    check(lib().avs_pull_copy_u8(c_void_p(host_pinned.data_ptr()), _p(dst), dst.numel() * dst.element_size(), int(workgroups),
+                                 _stream()), "avs_pull_copy_u8")
+    return dst
 
 
 _stem_ws = {}

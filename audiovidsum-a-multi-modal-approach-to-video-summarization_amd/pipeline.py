@@ -16,8 +16,9 @@ class _HostStager:
     """Double-buffered upload of passes of frames from pinned host memory: a copy stream fills buffer i % 2 while the
     compute stream works on the other one; events order the two streams, nothing blocks the host."""
 
-    def __init__(self, host_frames, max_frames, device):
+    def __init__(self, host_frames, max_frames, device, pull_workgroups=0):
         self.host = host_frames
+        self.pull_workgroups = int(pull_workgroups)   # > 0: uploads by avs_pull_copy_u8 with that many workgroups
         self.bufs = [torch.empty((max_frames,) + tuple(host_frames.shape[1:]), dtype=torch.uint8, device=device)
                      for _ in range(2)]
         self.copy_stream = torch.cuda.Stream(device=device)
@@ -37,7 +38,10 @@ class _HostStager:
                 self.copy_stream.wait_event(self.freed[k])    # the pass that used this buffer has finished
             if contiguous:
                 cnt = where[1] - where[0]
-                self.bufs[k][:cnt].copy_(self.host[where[0]:where[1]], non_blocking=True)
+                if self.pull_workgroups > 0:
+                    ops.pull_copy(self.host[where[0]:where[1]], self.bufs[k][:cnt], self.pull_workgroups)
+                else:
+                    self.bufs[k][:cnt].copy_(self.host[where[0]:where[1]], non_blocking=True)
             else:
                 cnt = len(where)
                 for j, src in enumerate(where.tolist()):      # ragged tails: a few frames, copied one by one
@@ -70,6 +74,7 @@ class FrameScoringPipeline:
         # frames in pinned host memory: the first pass's upload has no computation to hide behind, so the first pass is
         # a short one (its upload is the only exposed copy of the step)
         self.host_lead_frames = 4096
+        self.host_pull_workgroups = 0   # > 0: the uploads run as a pull kernel of that many workgroups (ops.pull_copy)
         # streams = 2: consecutive passes of the ResNet trunk run on two HIP streams, pass i + 1 starting when pass i
         # has launched its layers 1-2: the HBM-bound half of one pass then shares the chip with the matrix-core-bound
         # half (layers 3-4) of the other.  Passes are independent (disjoint frames, disjoint rows of the output).
@@ -150,8 +155,8 @@ class FrameScoringPipeline:
             for a in range(lo, hi, per_pass):
                 b = min(a + per_pass, hi)
                 passes.append((gsz, (a, b) if contiguous else where[a:b], contiguous))
-        stage = _HostStager(frames_u8, max((p[1][1] - p[1][0]) if p[2] else len(p[1]) for p in passes), dev) \
-            if host and passes else None
+        stage = _HostStager(frames_u8, max((p[1][1] - p[1][0]) if p[2] else len(p[1]) for p in passes), dev,
+                            self.host_pull_workgroups) if host and passes else None
         if stage is not None:
             stage.upload(0, passes[0])
         # two-stream overlap: device-resident contiguous passes of the ResNet-only path (the common case)

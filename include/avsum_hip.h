@@ -342,6 +342,12 @@ int avs_frames_normalize_u8(int dtype, const uint8_t* d_src, int n, int h, int w
                             const float* affine6, void* d_out, int out_h, int out_w,
                             int pad_t, int pad_l, avs_stream_t stream);
 
+/* Upload by a PULL kernel: `workgroups` 256-thread blocks read h_src_mapped - PINNED host memory by its device-visible
+ * address (hipHostMalloc / torch pin_memory: the same pointer) - over PCIe and store to d_dst.  The upload's footprint on
+ * the chip is the caller's choice, so the frames of the next pass can stream in beside the current pass's kernels
+ * (the PCIe-inclusive path of the pipeline; the reference hands over host arrays, features/extractors.py:43).           */
+int avs_pull_copy_u8(const uint8_t* h_src_mapped, uint8_t* d_dst, int64_t bytes, int workgroups, avs_stream_t stream);
+
 /* OpenCV-style bilinear resize of uint8 HWC frames (cv2.resize INTER_LINEAR,
  * fixed-point 11-bit coefficients): features/extractors.py:132,147.          */
 int avs_resize_bilinear_u8(const uint8_t* d_src, int n, int sh, int sw,

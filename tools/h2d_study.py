@@ -17,7 +17,8 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--leads", default="4096,1024,512,256,0")
+    ap.add_argument("--leads", default="1024,0")
+    ap.add_argument("--pull", default="0,4,8,16,32", help="0 = torch copy_ (copy engine); n = avs_pull_copy_u8 with n workgroups")
     args = ap.parse_args()
     from avsum_amd import synthetic
     from avsum_amd.features.extractors import VisualFeatureExtractor
@@ -55,11 +56,22 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(f"one 12288-frame upload alone: {dt * 1e3:.1f} ms = {12288 * 150528 / dt / 1e9:.1f} GB/s")
-    for lead in [int(v) for v in args.leads.split(",")]:
-        pipe.host_lead_frames = lead
-        rate, s_host = timed(host)
-        print(f"pinned host, lead pass {lead:5d}: {rate:9.1f} frames/s = {rate / base:.4f} of resident; "
-              f"scores identical: {torch.equal(s_host, s_dev)}")
+    for pull in [int(v) for v in args.pull.split(",")]:
+        pipe.host_pull_workgroups = pull
+        if pull:
+            from avsum_amd import ops
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ops.pull_copy(host[:12288], buf, pull)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            print(f"pull kernel, {pull} workgroups: one 12288-frame upload alone {dt * 1e3:.1f} ms = "
+                  f"{12288 * 150528 / dt / 1e9:.1f} GB/s; equal: {torch.equal(buf, frames[:12288])}")
+        for lead in [int(v) for v in args.leads.split(",")]:
+            pipe.host_lead_frames = lead
+            rate, s_host = timed(host)
+            print(f"pinned host, {'pull kernel x' + str(pull) if pull else 'copy engine'}, lead pass {lead:5d}: {rate:9.1f} frames/s = "
+                  f"{rate / base:.4f} of resident; scores identical: {torch.equal(s_host, s_dev)}")
 
 
 if __name__ == "__main__":
