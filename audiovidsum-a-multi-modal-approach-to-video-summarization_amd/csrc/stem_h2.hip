@@ -24,33 +24,42 @@
 //      the whole frame (49 tile sums of 32 values each), the frame's (mean, M2) leave once, frames of a group are merged by Chan's update in
 //      frame order: deterministic, nothing of the E[y^2] - E[y]^2 form about the origin.
 //
-// One workgroup (5 waves) = one frame x 32 of the 64 output channels, walking the frame's 49 tiles of 8 x 8 pooled outputs =
-// 17 x 17 convolution outputs (16 x 16 owned + the pooling halo, recomputed).  Patch 39 x 39 pixels of 4 x fp16 in LDS (bytes
-// fetched into registers one tile ahead), A fragment = the 16 bytes of two neighbouring patch pixels (K = 7 kernel rows x
-// 8 pixels x 4 channels = 224, zero weights in the padding), weights resident in LDS as f16x2 rows, v_mfma_f32_32x32x16_f16.
+// One workgroup (4 waves) = one frame x 32 of the 64 output channels, walking the frame's 56 tiles of 8 x 7 pooled outputs =
+// 17 x 15 convolution outputs (16 x 14 owned + the pooling halo row / column, recomputed) = 255 GEMM rows: eight 32-row
+// blocks, two per wave - the four SIMDs carry the same matrix work.  Patch 39 x 36 pixels of 4 x fp16 in LDS (one unaligned
+// dword per pixel fetched into registers a tile ahead), A fragment = the 16 bytes of two neighbouring patch pixels (K = 7
+// kernel rows x 8 pixels x 4 channels = 224, zero weights in the padding), weights resident in LDS as f16x2 rows.
+// THE PHASES OVERLAP INSIDE EVERY WAVE: the patch and the raw tile have their own LDS regions, so the pooling of tile i - 1
+// (LDS reads + VALU, then the stores of its 56 pooled pixels) is written between the matrix steps of tile i - the matrix
+// pipe and the vector / LDS pipes are separate, and a wave's MFMAs run on while it issues the pooling.  Two barriers per
+// tile: [patch i and raw i - 1 ready] -> matrix work i || pooling i - 1 -> [both read] -> statistics + raw tile i.
+// (The first version ran staging, matrix, statistics, raw tile and pooling one after the other between three barriers, five
+// waves on four SIMDs: 24.8 ms per 11 286 frames, the matrix pipe 19 % busy.)
 #include "avs_internal.h"
+#include <type_traits>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 constexpr int IMG = 224, CONV = 112, POOL = 56, COUT = 64;
-constexpr int TILES = 7;                 // tiles per side: 7 x 8 pooled = 56
-constexpr int TW = 17;                   // convolution outputs per tile side (16 owned + 1 halo)
-constexpr int MROWS = TW * TW;           // 289 used rows of the 320-row GEMM tile
-constexpr int PH = 39, PW = 40;          // patch rows / pixels (pixel = 4 x fp16 = 8 bytes)
+constexpr int TY = 7, TX = 8;            // tiles per frame: 7 rows of 8
+constexpr int TH = 17, TWD = 15;         // convolution outputs per tile: 17 rows x 15 columns (16 x 14 owned + the halo)
+constexpr int PPY = 8, PPX = 7;          // pooled outputs per tile
+constexpr int MROWS = TH * TWD;          // 255 used rows of the 256-row GEMM tile
+constexpr int PH = 39, PW = 36;          // patch rows / pixels (pixel = 4 x fp16 = 8 bytes)
 constexpr int PATCH_BYTES = PH * PW * 8;
 constexpr int KDIM = 224;                // 7 kernel rows x 8 pixels x 4 channels
 constexpr int CW = 32;                   // output channels per workgroup
 constexpr int W_PITCH = KDIM * 4 + 16;   // an f16x2 weight row (hi8 | lo8 per 32 bytes) + 16: 16 rows -> 16 different slots
 constexpr int W_BYTES = CW * W_PITCH;
-constexpr int RT_PITCH = 160;            // raw tile row: 32 fp32 + 32 bytes (40 dwords: the pooling's b128 reads are conflict-free)
-constexpr int RT_BYTES = MROWS * RT_PITCH;
-constexpr int MAIN_BYTES = RT_BYTES > PATCH_BYTES ? RT_BYTES : PATCH_BYTES;
-constexpr int WAVES = 5, THREADS = WAVES * 64;
+constexpr int RT_PITCH = 144;            // raw tile row: 32 fp32 + 16 bytes
+constexpr int RT_BYTES = 256 * RT_PITCH;
+constexpr int WAVES = 4, THREADS = WAVES * 64;
 constexpr int SRED_BYTES = WAVES * 2 * CW * 4, PIV_BYTES = CW * 4;
-constexpr int SMEM_BYTES = W_BYTES + MAIN_BYTES + SRED_BYTES + PIV_BYTES;
-constexpr int PIVOT_ROW = 9 * TW + 9;    // tile row of the pivot: convolution output (8, 8) of tile (0, 0), an interior pixel
+constexpr int SMEM_BYTES = W_BYTES + PATCH_BYTES + RT_BYTES + SRED_BYTES + PIV_BYTES;
+constexpr int PIVOT_ROW = 9 * TWD + 7;   // tile row of the pivot: convolution output (8, 6) of tile (0, 0), an interior pixel
+static_assert(SMEM_BYTES <= 80 * 1024, "two workgroups per CU");
 }  // namespace
 
 struct StemH2Params {
@@ -62,12 +71,14 @@ struct StemH2Params {
   long long ldw;
 };
 
-// (two workgroups per CU = 10 waves: three waves on some SIMDs -> at most 168 registers)
-__global__ __launch_bounds__(THREADS, 3) void stem_h2_kernel(StemH2Params p) {
+struct __attribute__((packed, aligned(1))) avs_u32_unaligned { unsigned v; };
+
+__global__ __launch_bounds__(THREADS, 2) void stem_h2_kernel(StemH2Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* wimg = smem;
-  char* mainb = smem + W_BYTES;
-  float* sred = reinterpret_cast<float*>(smem + W_BYTES + MAIN_BYTES);          // [WAVES][2][CW]
+  char* patch = smem + W_BYTES;
+  char* rawt = patch + PATCH_BYTES;
+  float* sred = reinterpret_cast<float*>(rawt + RT_BYTES);                      // [WAVES][2][CW]
   float* piv_s = sred + WAVES * 2 * CW;                                         // [CW]
   const int t = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
@@ -82,43 +93,38 @@ __global__ __launch_bounds__(THREADS, 3) void stem_h2_kernel(StemH2Params p) {
     *reinterpret_cast<uint4*>(wimg + n * W_PITCH + ch * 16) =
         *reinterpret_cast<const uint4*>(p.w + ((long long)(c0 + n) * p.ldw) * 4 + ch * 16);
   }
-
   // per-lane constants: A base offsets of this lane's two 32-row blocks; per accumulator element (bit 16 mt + e) whether
-  // it is owned (not the halo row / column)
+  // it is owned (not the halo row / column, not the tile's padding row 255)
   int abase[2];
   unsigned own = 0;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     int m = wave * 64 + mt * 32 + lr;
-    if (m >= MROWS) m = MROWS - 1;   // rows 289 .. 319 compute garbage from a valid address and are never stored
-    const int ly = m / TW, lx = m - ly * TW;
+    if (m >= MROWS) m = MROWS - 1;   // row 255 computes garbage from a valid address; it is stored to the raw tile's spare row
+    const int ly = m / TWD, lx = m - ly * TWD;
     abase[mt] = ((2 * ly) * PW + 2 * lx) * 8 + lh * 16;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int me = wave * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-      const int ey = me / TW, ex = me - ey * TW;
-      const unsigned bit = 1u << (16 * mt + e);
-      if (me < MROWS && ey >= 1 && ex >= 1) own |= bit;
+      const int ey = me / TWD, ex = me - ey * TWD;
+      if (me < MROWS && ey >= 1 && ex >= 1) own |= 1u << (16 * mt + e);
     }
   }
   const int bbase = lr * W_PITCH + lh * 32;
-  // pooling: an item = (pooled pixel, 8 channels); the channels with gamma < 0 pool -y (max of -y = -min of y)
-  const int p_cg = t & 3, p_pp = (t >> 2) & 63;    // threads 0 .. 255
-  const int p_pyl = p_pp >> 3, p_pxl = p_pp & 7;
-  // the item's two 16-byte chunks are read in an order that alternates with the pooled column (bank spread, below):
-  // chunk a = channels ja .. ja + 3 of the item's 8, chunk b the other four
-  const int p_ja = (p_pxl & 1) * 4, p_jb = 4 - p_ja;
-  float sga[4], sgb[4];
+  // pooling: an item = (pooled pixel, 8 channels), threads 0 .. 223; the channels with gamma < 0 pool -y
+  // (threads 224 .. 255 run item 0's arithmetic too and store nothing: no divergent block between the matrix instructions)
+  const bool pool_on = t < PPY * PPX * 4;
+  const int p_cg = t & 3, p_pp = pool_on ? (t >> 2) : 0;
+  const int p_pyl = p_pp / PPX, p_pxl = p_pp - p_pyl * PPX;
+  float sg[8];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    sga[j] = p.gamma[c0 + p_cg * 8 + p_ja + j] < 0.f ? -1.f : 1.f;
-    sgb[j] = p.gamma[c0 + p_cg * 8 + p_jb + j] < 0.f ? -1.f : 1.f;
-  }
+  for (int j = 0; j < 8; ++j) sg[j] = p.gamma[c0 + p_cg * 8 + j] < 0.f ? -1.f : 1.f;
+  const char* praw = rawt + ((2 * p_pyl) * TWD + 2 * p_pxl) * RT_PITCH + p_cg * 32;
 
-  // the patch pixels of a tile are fetched into REGISTERS one tile ahead (byte loads issued before the matrix work of the
-  // previous tile), converted and written to LDS at the top of their tile
-  constexpr int PPT = (PH * PW + THREADS - 1) / THREADS;   // patch pixels per thread (5)
-  unsigned pb0[PPT], pb1[PPT], pb2[PPT];
+  // the patch pixels of a tile are fetched into REGISTERS one tile ahead: ONE unaligned dword per pixel (its 3 bytes and a
+  // neighbour's), converted and written to LDS at the top of their tile
+  constexpr int PPT = (PH * PW + THREADS - 1) / THREADS;   // patch pixels per thread (6)
+  unsigned pbytes[PPT];
   unsigned inside = 0u;
   int pyx[PPT];   // this thread's patch pixels: row << 8 | column
 #pragma unroll
@@ -128,20 +134,20 @@ __global__ __launch_bounds__(THREADS, 3) void stem_h2_kernel(StemH2Params p) {
     pyx[j] = (py << 8) | (i - (i / PW) * PW);
   }
   auto gload = [&](int tile) {
-    const int ty = tile / TILES, tx = tile - ty * TILES;
-    const int iy0 = 32 * ty - 5, ix0 = 32 * tx - 5;
+    const int ty = tile / TX, tx = tile - ty * TX;
+    const int iy0 = 32 * ty - 5, ix0 = 28 * tx - 5;
     const int ylo = iy0 < 0 ? -iy0 : 0, yhi = IMG - iy0 < PH ? IMG - iy0 : PH;
-    const int xlo = ix0 < 0 ? -ix0 : 0, xhi = IMG - ix0 < PH ? IMG - ix0 : PH;   // (column 39 is layout padding)
-    const uint8_t* org = src + (iy0 * IMG + ix0) * 3;
+    const int xlo = ix0 < 0 ? -ix0 : 0, xhi = IMG - ix0 < PW ? IMG - ix0 : PW;
     inside = 0u;
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
       const int py = pyx[j] >> 8, px = pyx[j] & 255;
       if (py >= ylo && py < yhi && px >= xlo && px < xhi) {
-        const uint8_t* s = org + (py * IMG + px) * 3;
-        pb0[j] = s[0];
-        pb1[j] = s[1];
-        pb2[j] = s[2];
+        const int o = ((iy0 + py) * IMG + ix0 + px) * 3;          // the pixel's first byte inside the frame
+        // bytes o - 1 .. o + 2 (one byte of the pixel before, then B G R), except for the tensor's very first pixel
+        const bool prev = o > 0 || img > 0;
+        const unsigned d = reinterpret_cast<const avs_u32_unaligned*>(src + o - (prev ? 1 : 0))->v;
+        pbytes[j] = prev ? d >> 8 : d;
         inside |= 1u << j;
       }
     }
@@ -153,22 +159,58 @@ __global__ __launch_bounds__(THREADS, 3) void stem_h2_kernel(StemH2Params p) {
       if (i >= PH * PW) break;
       unsigned lo = 0u, hi = 0u;
       if ((inside >> j) & 1u) {   // bytes are exact in fp16 (round-toward-zero conversion of an integer <= 255)
-        lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz((float)pb0[j], (float)pb1[j]));
-        hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz((float)pb2[j], 1.f));   // channel 3: "inside the image"
+        const float b0 = (float)(pbytes[j] & 255u), b1 = (float)((pbytes[j] >> 8) & 255u), b2 = (float)((pbytes[j] >> 16) & 255u);
+        lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(b0, b1));
+        hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(b2, 1.f));   // channel 3: "inside the image"
       }
-      *reinterpret_cast<uint2*>(mainb + i * 8) = make_uint2(lo, hi);
+      *reinterpret_cast<uint2*>(patch + i * 8) = make_uint2(lo, hi);
     }
   };
-  gload(0);
-  __syncthreads();   // the weights are published
-  float pivot = 0.f, s1 = 0.f, s2 = 0.f;
-  for (int tile = 0; tile < TILES * TILES; ++tile) {
-    const int ty = tile / TILES, tx = tile - ty * TILES;
-    pstore();
-    __syncthreads();
-    if (tile + 1 < TILES * TILES) gload(tile + 1);
+  // the pooled pixel of tile `tile` from the raw tile in LDS: taps read between the matrix steps (tap = 0 .. 8), then finish
+  float pm[8];
+  auto pool_tap = [&](int tile, int tap) {
+    const int ty = tile / TX, tx = tile - ty * TX;
+    const int dy = tap / 3, dx = tap - dy * 3;
+    // convolution row / column -1 lies outside the map (maxpool pads with -inf): that tap's products are replaced by -inf
+    // (a select, not a branch: the pooling sits between matrix instructions)
+    const bool out = (dy == 0 && ty == 0 && p_pyl == 0) || (dx == 0 && tx == 0 && p_pxl == 0);
+    const char* row = praw + (dy * TWD + dx) * RT_PITCH;
+    const float4 va = *reinterpret_cast<const float4*>(row);
+    const float4 vb = *reinterpret_cast<const float4*>(row + 16);
+    const float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float x = v[j] * sg[j];
+      if (dy == 0 || dx == 0) x = out ? -INFINITY : x;
+      pm[j] = tap == 0 ? x : fmaxf(pm[j], x);
+    }
+  };
+  auto pool_finish = [&](int tile) {
+    const int ty = tile / TX, tx = tile - ty * TX;
+    float v8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v8[j] = pm[j] * sg[j];
+    uint4 hi, lo;
+    avs_f16x2_split8(v8, hi, lo);
+    const long long o = (((img * POOL + PPY * ty + p_pyl) * POOL + PPX * tx + p_pxl) * COUT + c0 + p_cg * 8) * 4;
+    if (pool_on) {
+      *reinterpret_cast<uint4*>(p.osel + o) = hi;
+      *reinterpret_cast<uint4*>(p.osel + o + 16) = lo;
+    }
+  };
 
-    // ---- implicit GEMM: 14 steps of 16 reduction elements = (kernel row, half of its 8 pixels); hi(w) then lo(w)
+  gload(0);
+  float pivot = 0.f, s1 = 0.f, s2 = 0.f;
+  constexpr int NT = TY * TX;
+  // one tile: POOL = the previous tile's pooling rides between the matrix steps (every tile but the first: the first is
+  // peeled so that the loop body is ONE basic block the scheduler can interleave freely)
+  auto body = [&](auto pool_c, int tile) {
+    constexpr bool POOLING = decltype(pool_c)::value;
+    pstore();
+    __syncthreads();   // patch(tile) and raw(tile - 1) are complete (and, the first time, the weights)
+    if (tile + 1 < NT) gload(tile + 1);
+
+    // ---- implicit GEMM: 14 steps of 16 reduction elements = (kernel row, half of its 8 pixels), hi(w) then lo(w)
     f32x16 acc[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -179,7 +221,7 @@ __global__ __launch_bounds__(THREADS, 3) void stem_h2_kernel(StemH2Params p) {
       const int aoff = (s >> 1) * (PW * 8) + (s & 1) * 32;
       uint4 fa[2];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) fa[mt] = *reinterpret_cast<const uint4*>(mainb + abase[mt] + aoff);
+      for (int mt = 0; mt < 2; ++mt) fa[mt] = *reinterpret_cast<const uint4*>(patch + abase[mt] + aoff);
       const uint4 fbh = *reinterpret_cast<const uint4*>(wimg + bbase + s * 64);
       const uint4 fbl = *reinterpret_cast<const uint4*>(wimg + bbase + s * 64 + 16);
 #pragma unroll
@@ -190,18 +232,29 @@ __global__ __launch_bounds__(THREADS, 3) void stem_h2_kernel(StemH2Params p) {
       for (int mt = 0; mt < 2; ++mt)
         acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[mt]), __builtin_bit_cast(f16x8, fbl),
                                                          acc[mt], 0, 0, 0);
+      if constexpr (POOLING) {
+        if (s < 9) pool_tap(tile - 1, s);
+        if (s == 9) pool_finish(tile - 1);
+        // the step's instruction mix, in issue order: 4 fragment reads + the tap's 2 reads, then per matrix instruction a
+        // slice of the vector work (an MFMA holds the vector issue for 8 of its 32 cycles: ~6 plain VALU fit beside it)
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);   // DS reads
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);   // VALU
+        }
+      }
     }
     if (tile == 0 && wave == PIVOT_ROW / 64 && lh == ((PIVOT_ROW % 32) >> 2 & 1)) {
-      // (row 162 = wave 2, block 1, row 2 of the block: element e with (e & 3) + 8 (e >> 2) + 4 lh == 2 -> e = 2, lh = 0)
       constexpr int PMT = (PIVOT_ROW % 64) / 32, PR = PIVOT_ROW % 32;
       constexpr int PE = (PR & 3) + 4 * (PR >> 3);
       piv_s[lr] = acc[PMT][PE];
     }
-    __syncthreads();   // every wave is done reading the patch: the raw tile may overwrite it; the pivot is published
+    __syncthreads();   // every wave is done reading patch(tile) and raw(tile - 1); the pivot is published
     if (tile == 0) pivot = piv_s[lr];
     // ---- statistics of the owned outputs about the pivot (the tile's 32 values summed first, then added to the frame's
-    // sums: chains of 32 + 49 terms instead of 1568 - on a smooth frame the long chain's rounding errors are correlated
-    // and cost 5e-5 of the variance); raw tile (fp32) -> LDS [289][32 + pad]
+    // sums: chains of 32 + 56 terms - on a smooth frame a long chain's rounding errors are correlated and cost 5e-5 of the
+    // variance); raw tile (fp32) -> LDS [256][32 + pad]
     float t1 = 0.f, t2 = 0.f;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -212,55 +265,18 @@ __global__ __launch_bounds__(THREADS, 3) void stem_h2_kernel(StemH2Params p) {
         t1 += d;
         t2 = fmaf(d, d, t2);
         const int m = wave * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        if (m < MROWS) *reinterpret_cast<float*>(mainb + m * RT_PITCH + lr * 4) = v;
+        *reinterpret_cast<float*>(rawt + m * RT_PITCH + lr * 4) = v;
       }
     s1 += t1;
     s2 += t2;
-    __syncthreads();
-    // ---- 3x3 / 2 max (min) over the raw tile: item = (pooled pixel of the 8 x 8, 8 of the 32 channels) -> one 32-byte run.
-    // The item's two 16-byte chunks are read in an order that alternates with the pooled column: with the 160-byte row
-    // pitch the 16 lanes that share an LDS cycle then touch 16 different 16-byte slots.
-    if (t < 256) {
-      const int pyl = p_pyl, pxl = p_pxl;
-      const int ca = (2 * p_cg) * 16 + p_ja * 4, cb = (2 * p_cg) * 16 + p_jb * 4;
-      float ma[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, mb[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  };
+  body(std::false_type{}, 0);
+  for (int tile = 1; tile < NT; ++tile) body(std::true_type{}, tile);
+  // ---- the last tile's pooling
+  __syncthreads();
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        const int ly = 2 * pyl + dy;
-        if (ty == 0 && ly == 0) continue;   // convolution row -1: outside the map (maxpool pads with -inf)
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const int lx = 2 * pxl + dx;
-          if (tx == 0 && lx == 0) continue;
-          const char* row = mainb + (ly * TW + lx) * RT_PITCH;
-          const float4 va = *reinterpret_cast<const float4*>(row + ca);
-          const float4 vb = *reinterpret_cast<const float4*>(row + cb);
-          ma[0] = fmaxf(ma[0], va.x * sga[0]);
-          ma[1] = fmaxf(ma[1], va.y * sga[1]);
-          ma[2] = fmaxf(ma[2], va.z * sga[2]);
-          ma[3] = fmaxf(ma[3], va.w * sga[3]);
-          mb[0] = fmaxf(mb[0], vb.x * sgb[0]);
-          mb[1] = fmaxf(mb[1], vb.y * sgb[1]);
-          mb[2] = fmaxf(mb[2], vb.z * sgb[2]);
-          mb[3] = fmaxf(mb[3], vb.w * sgb[3]);
-        }
-      }
-      const bool swap = (pxl & 1) != 0;   // chunk a holds the item's channels 4 .. 7
-      float v8[8];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float xa = ma[j] * sga[j], xb = mb[j] * sgb[j];
-        v8[j] = swap ? xb : xa;
-        v8[4 + j] = swap ? xa : xb;
-      }
-      uint4 hi, lo;
-      avs_f16x2_split8(v8, hi, lo);
-      const long long o = (((img * POOL + 8 * ty + pyl) * POOL + 8 * tx + pxl) * COUT + c0 + p_cg * 8) * 4;
-      *reinterpret_cast<uint4*>(p.osel + o) = hi;
-      *reinterpret_cast<uint4*>(p.osel + o + 16) = lo;
-    }
-    __syncthreads();   // the raw tile has been read: the next patch may overwrite it
-  }
+  for (int tap = 0; tap < 9; ++tap) pool_tap(NT - 1, tap);
+  pool_finish(NT - 1);
   // ---- the frame's statistics: lanes -> waves (fixed order) -> (mean, M2) of this workgroup's 32 channels
   s1 += __shfl_xor(s1, 32, 64);
   s2 += __shfl_xor(s2, 32, 64);

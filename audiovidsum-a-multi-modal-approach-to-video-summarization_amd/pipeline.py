@@ -16,15 +16,24 @@ class _HostStager:
     """Double-buffered upload of passes of frames from pinned host memory: a copy stream fills buffer i % 2 while the
     compute stream works on the other one; events order the two streams, nothing blocks the host."""
 
-    def __init__(self, host_frames, max_frames, device, pull_workgroups=0):
+    def __init__(self, host_frames, max_frames, device, pull_workgroups=0, cache=None):
         self.host = host_frames
         self.pull_workgroups = int(pull_workgroups)   # > 0: uploads by avs_pull_copy_u8 with that many workgroups
-        self.bufs = [torch.empty((max_frames,) + tuple(host_frames.shape[1:]), dtype=torch.uint8, device=device)
-                     for _ in range(2)]
-        self.copy_stream = torch.cuda.Stream(device=device)
-        # the staging buffers come from the COMPUTE stream's allocator pool: a block may still be read by kernels its
-        # previous owner queued there, so the first upload into each buffer must be ordered behind everything the
-        # compute stream has been given so far (later uploads are ordered by the `freed` events)
+        # the copy stream and the two staging buffers live as long as the pipeline (`cache`: a dict it owns): creating a
+        # stream and 3.4 GB of buffers per call showed up as 2 - 3 % of a 1.8 s step
+        cache = cache if cache is not None else {}
+        shape = (max_frames,) + tuple(host_frames.shape[1:])
+        bufs = cache.get("bufs")
+        if bufs is None or bufs[0].device != device or bufs[0].shape[1:] != shape[1:] or bufs[0].shape[0] < max_frames:
+            bufs = [torch.empty(shape, dtype=torch.uint8, device=device) for _ in range(2)]
+            cache["bufs"] = bufs
+        self.bufs = bufs
+        if cache.get("stream") is None or cache["stream"].device != device:
+            cache["stream"] = torch.cuda.Stream(device=device)
+        self.copy_stream = cache["stream"]
+        # the staging buffers come from the COMPUTE stream's allocator pool and are reused from call to call: the first
+        # upload into each buffer must be ordered behind everything the compute stream has been given so far (kernels of
+        # the previous call that still read them; later uploads are ordered by the `freed` events)
         self.copy_stream.wait_stream(torch.cuda.current_stream(device))
         self.filled = [torch.cuda.Event(), torch.cuda.Event()]
         self.freed = [None, None]
@@ -73,8 +82,12 @@ class FrameScoringPipeline:
         self.frames_per_group = int(frames_per_group)
         # frames in pinned host memory: the first pass's upload has no computation to hide behind, so the first pass is
         # a short one (its upload is the only exposed copy of the step)
-        self.host_lead_frames = 4096
-        self.host_pull_workgroups = 0   # > 0: the uploads run as a pull kernel of that many workgroups (ops.pull_copy)
+        self.host_lead_frames = 1024
+        # the uploads run as a pull kernel of that many workgroups (ops.pull_copy) on the copy stream; 0 = torch's copy_
+        # (the copy engine).  Measured (tools/h2d_study.py, 45 143 frames, 4 steps): 0.977 of the HBM-resident rate with the
+        # pull kernel x16 and a 1024-frame lead pass, 0.955 - 0.960 with the copy engine
+        self.host_pull_workgroups = 16
+        self._stager_cache = {}
         # streams = 2: consecutive passes of the ResNet trunk run on two HIP streams, pass i + 1 starting when pass i
         # has launched its layers 1-2: the HBM-bound half of one pass then shares the chip with the matrix-core-bound
         # half (layers 3-4) of the other.  Passes are independent (disjoint frames, disjoint rows of the output).
@@ -156,7 +169,7 @@ class FrameScoringPipeline:
                 b = min(a + per_pass, hi)
                 passes.append((gsz, (a, b) if contiguous else where[a:b], contiguous))
         stage = _HostStager(frames_u8, max((p[1][1] - p[1][0]) if p[2] else len(p[1]) for p in passes), dev,
-                            self.host_pull_workgroups) if host and passes else None
+                            self.host_pull_workgroups, self._stager_cache) if host and passes else None
         if stage is not None:
             stage.upload(0, passes[0])
         # two-stream overlap: device-resident contiguous passes of the ResNet-only path (the common case)
