@@ -658,6 +658,7 @@ class InceptionV3Runner:
         self.f32_split = "f16x2" if self.h2 else (bool(f32_split) and dtype == torch.float32)
         self.ecode = ops.dtype_code(dtype, "f16x2") if self.h2 else ops.dtype_code(dtype)   # storage format
         self.pool_after_conv = True   # branch_pool: 1x1 convolution first, average pooling on its (narrow) output
+        self.split_tail_columns = True   # cout = 128 k + r (r <= 64): two launches instead of a mostly empty last column tile
         self._key = None
         self._w = None
 
@@ -669,9 +670,21 @@ class InceptionV3Runner:
             bias = (bn.bias.float() - bn.running_mean.float() * s).contiguous()
             rows = _stem_weight(wt, stem_px, self.dtype) if stem_px else _ohwi(wt, self.dtype)
             w = _W(ops.f16x2_pack(rows) if self.h2 else rows)
+            # column tiles are 128 wide (64 for cout <= 64): a layer with cout = 128 k + r, 0 < r <= 64 (192, 160, 320, 448:
+            # most of Inception-v3) would spend a whole 128-column tile's matrix work on its last r columns - 25 - 37 % of
+            # the layer.  Such a layer runs as TWO launches, the first 128 k columns on the wide tile and the last r on
+            # the 64-column one, each writing its own channel slice: the same outputs, bit for bit
+            parts = None
+            cout = conv.out_channels
+            r = cout % 128
+            if self.split_tail_columns and not stem_px and cout > 128 and 0 < r <= 64:
+                parts = []
+                for a, b in ((0, cout - r), (cout - r, cout)):
+                    pr = rows[a:b].contiguous()
+                    parts.append((a, b, _W(ops.f16x2_pack(pr) if self.h2 else pr), bias[a:b].contiguous()))
         kh, kw = conv.kernel_size
         return {"w": w, "b": bias, "kh": kh, "kw": kw, "s": conv.stride[0], "ph": conv.padding[0],
-                "pw": conv.padding[1], "cout": conv.out_channels}
+                "pw": conv.padding[1], "cout": conv.out_channels, "parts": parts}
 
     def _prepare(self):
         key = tuple((p.data_ptr(), p._version) for p in self.net.parameters()) + \
@@ -693,6 +706,12 @@ class InceptionV3Runner:
         wo = (ww + 2 * c["pw"] - c["kw"]) // c["s"] + 1
         if out is None:
             out = torch.empty((n, ho, wo, c["cout"]), dtype=self.dtype, device=x.device)
+        if c["parts"] is not None:
+            for a, b, wp, bp in c["parts"]:
+                wsel, layout = wp.conv_operand()
+                ops.conv2d(x, wsel, c["kh"], c["kw"], c["s"], (c["ph"], c["pw"]), out[..., a:b], bp, ops.ACT_RELU,
+                           split=self.f32_split, w_layout=layout)
+            return out
         wsel, layout = c["w"].conv_operand()
         return ops.conv2d(x, wsel, c["kh"], c["kw"], c["s"], (c["ph"], c["pw"]), out, c["b"], ops.ACT_RELU,
                           split=self.f32_split, w_layout=layout)
@@ -706,8 +725,9 @@ class InceptionV3Runner:
         c = w[name]
         n, h, ww, _ = x.shape
         z = torch.empty((n, h, ww, c["cout"]), dtype=self.dtype, device=x.device)
-        wsel, layout = c["w"].conv_operand()
-        ops.conv2d(x, wsel, 1, 1, 1, (0, 0), z, None, ops.ACT_NONE, split=self.f32_split, w_layout=layout)
+        for a, b, wp, _ in (c["parts"] or [(0, c["cout"], c["w"], None)]):
+            wsel, layout = wp.conv_operand()
+            ops.conv2d(x, wsel, 1, 1, 1, (0, 0), z[..., a:b], None, ops.ACT_NONE, split=self.f32_split, w_layout=layout)
         return ops.pool2d(z, "avg", 3, 1, 1, out, c["b"], ops.ACT_RELU, code=self.ecode)
 
     def _pool(self, x, mode, k, s, p, out=None):

@@ -52,9 +52,19 @@ class _HostStager:
                 else:
                     self.bufs[k][:cnt].copy_(self.host[where[0]:where[1]], non_blocking=True)
             else:
+                # an index set: runs of consecutive frames (whole videos minus their tails, or the tails themselves), one
+                # transfer per run
                 cnt = len(where)
-                for j, src in enumerate(where.tolist()):      # ragged tails: a few frames, copied one by one
-                    self.bufs[k][j].copy_(self.host[src], non_blocking=True)
+                idx = np.asarray(where, dtype=np.int64)
+                cuts = np.flatnonzero(np.diff(idx) != 1) + 1
+                starts = np.concatenate([[0], cuts])
+                ends = np.concatenate([cuts, [cnt]])
+                for a, b in zip(starts.tolist(), ends.tolist()):
+                    src = self.host[int(idx[a]):int(idx[a]) + (b - a)]
+                    if self.pull_workgroups > 0:
+                        ops.pull_copy(src, self.bufs[k][a:b], self.pull_workgroups)
+                    else:
+                        self.bufs[k][a:b].copy_(src, non_blocking=True)
             self.filled[k].record(self.copy_stream)
         self.counts[k] = cnt
 

@@ -743,7 +743,7 @@ def test_resnet50_bf16_local_form_close_to_split_form(dev, gsize):
     groups = list(range(0, 17, gsize))
     local = ResNet50Runner(trunk, torch.bfloat16)
     got = local.forward(frames, groups).cpu()
-    plan = local._plans[(16, gsize)]
+    plan = local._plans[(16, gsize, local.bn_cluster)]
     assert sum(plan) == (28 if gsize == 1 else 9)     # the form really ran (14x14 + 7x7 layers / 7x7 layers)
     split = ResNet50Runner(trunk, torch.bfloat16)
     split.bn_local = False
