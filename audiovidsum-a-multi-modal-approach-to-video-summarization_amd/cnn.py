@@ -658,7 +658,10 @@ class InceptionV3Runner:
         self.f32_split = "f16x2" if self.h2 else (bool(f32_split) and dtype == torch.float32)
         self.ecode = ops.dtype_code(dtype, "f16x2") if self.h2 else ops.dtype_code(dtype)   # storage format
         self.pool_after_conv = True   # branch_pool: 1x1 convolution first, average pooling on its (narrow) output
-        self.split_tail_columns = True   # cout = 128 k + r (r <= 64): two launches instead of a mostly empty last column tile
+        self.split_tail_columns = False  # cout = 128 k + r (r <= 64): two launches instead of a mostly empty last column tile
+        #                                  (measured: no gain - these layers are not bound by the matrix work; off)
+        self.stack_heads = True          # AVS_F16X2: the 1x1 heads of a block that read the block input run as ONE contraction
+        #                                  over their stacked filters (avs_conv2d_nhwc_split): the input is fetched once
         self._key = None
         self._w = None
 
@@ -716,6 +719,38 @@ class InceptionV3Runner:
         return ops.conv2d(x, wsel, c["kh"], c["kw"], c["s"], (c["ph"], c["pw"]), out, c["b"], ops.ACT_RELU,
                           split=self.f32_split, w_layout=layout)
 
+    def _heads(self, w, p, x, first, others, first_out):
+        """The block's 1x1 convolutions that read x: `first` (or None) writes first_out (its slice of the block's
+        concatenated output), `others` feed further convolutions.  Returns the NHWC views of the others' outputs.  With
+        stack_heads (AVS_F16X2): one contraction over the stacked filters, two destinations."""
+        names = [p + "." + nm for nm in others]
+        couts = [w[nm]["cout"] for nm in names]
+        n, h, ww, _ = x.shape
+        if not (self.h2 and self.stack_heads) or any(w[nm]["parts"] is not None for nm in names):
+            if first is not None:
+                self._conv(w, p + "." + first, x, first_out)
+            return [self._conv(w, nm, x) for nm in names]
+        key = ("stack", p, first, tuple(others))
+        st = w.get(key)
+        if st is None:
+            members = ([p + "." + first] if first is not None else []) + names
+            # (an AVS_F16X2 row is packed by itself - runs of 8 inside the row: the stacked image is the rows one after another)
+            rows = torch.cat([w[nm]["w"].rows for nm in members]).contiguous()
+            st = (_W(rows), torch.cat([w[nm]["b"] for nm in members]).contiguous())
+            w[key] = st
+        wst, bst = st
+        tmp = torch.empty((n, h, ww, sum(couts)), dtype=self.dtype, device=x.device)
+        wsel, layout = wst.conv_operand()
+        if first is not None:
+            ops.conv2d_split(x, wsel, first_out, w[p + "." + first]["cout"], tmp, bst, ops.ACT_RELU, w_layout=layout)
+        else:
+            ops.conv2d(x, wsel, 1, 1, 1, (0, 0), tmp, bst, ops.ACT_RELU, split=self.f32_split, w_layout=layout)
+        views, o = [], 0
+        for c in couts:
+            views.append(tmp[..., o:o + c])
+            o += c
+        return views
+
     def _pool_branch(self, w, name, x, out):
         """branch_pool = avg_pool2d(3, 1, 1) -> 1x1 conv -> folded BN -> ReLU, run as 1x1 conv (no bias) -> average ->
         + bias -> ReLU: the two linear maps commute (count_include_pad's zero padding included), and the pooling pass
@@ -749,9 +784,9 @@ class InceptionV3Runner:
 
     def _block_a(self, w, p, x, pf):
         buf, (o1, o5, o3, op) = self._cat_buffer(x, [64, 64, 96, pf])
-        self._conv(w, p + ".branch1x1", x, o1)
-        self._conv(w, p + ".branch5x5_2", self._conv(w, p + ".branch5x5_1", x), o5)
-        t = self._conv(w, p + ".branch3x3dbl_2", self._conv(w, p + ".branch3x3dbl_1", x))
+        t5, t3 = self._heads(w, p, x, "branch1x1", ["branch5x5_1", "branch3x3dbl_1"], o1)
+        self._conv(w, p + ".branch5x5_2", t5, o5)
+        t = self._conv(w, p + ".branch3x3dbl_2", t3)
         self._conv(w, p + ".branch3x3dbl_3", t, o3)
         self._pool_branch(w, p + ".branch_pool", x, op)
         return buf
@@ -766,10 +801,10 @@ class InceptionV3Runner:
 
     def _block_c(self, w, p, x):
         buf, (o1, o7, od, op) = self._cat_buffer(x, [192, 192, 192, 192])
-        self._conv(w, p + ".branch1x1", x, o1)
-        t = self._conv(w, p + ".branch7x7_2", self._conv(w, p + ".branch7x7_1", x))
+        t7, td = self._heads(w, p, x, "branch1x1", ["branch7x7_1", "branch7x7dbl_1"], o1)
+        t = self._conv(w, p + ".branch7x7_2", t7)
         self._conv(w, p + ".branch7x7_3", t, o7)
-        t = self._conv(w, p + ".branch7x7dbl_1", x)
+        t = td
         for i in (2, 3, 4):
             t = self._conv(w, f"{p}.branch7x7dbl_{i}", t)
         self._conv(w, p + ".branch7x7dbl_5", t, od)
@@ -778,9 +813,9 @@ class InceptionV3Runner:
 
     def _block_d(self, w, p, x):
         buf, (o3, o7, op) = self._cat_buffer(x, [320, 192, x.shape[3]], stride=2)
-        self._conv(w, p + ".branch3x3_2", self._conv(w, p + ".branch3x3_1", x), o3)
-        t = self._conv(w, p + ".branch7x7x3_1", x)
-        t = self._conv(w, p + ".branch7x7x3_2", t)
+        t3, t7 = self._heads(w, p, x, None, ["branch3x3_1", "branch7x7x3_1"], None)
+        self._conv(w, p + ".branch3x3_2", t3, o3)
+        t = self._conv(w, p + ".branch7x7x3_2", t7)
         t = self._conv(w, p + ".branch7x7x3_3", t)
         self._conv(w, p + ".branch7x7x3_4", t, o7)
         self._pool(x, "max", 3, 2, 0, op)
@@ -788,11 +823,10 @@ class InceptionV3Runner:
 
     def _block_e(self, w, p, x):
         buf, (o1, o3a, o3b, oda, odb, op) = self._cat_buffer(x, [320, 384, 384, 384, 384, 192])
-        self._conv(w, p + ".branch1x1", x, o1)
-        t = self._conv(w, p + ".branch3x3_1", x)
+        t, td = self._heads(w, p, x, "branch1x1", ["branch3x3_1", "branch3x3dbl_1"], o1)
         self._conv(w, p + ".branch3x3_2a", t, o3a)
         self._conv(w, p + ".branch3x3_2b", t, o3b)
-        t = self._conv(w, p + ".branch3x3dbl_2", self._conv(w, p + ".branch3x3dbl_1", x))
+        t = self._conv(w, p + ".branch3x3dbl_2", td)
         self._conv(w, p + ".branch3x3dbl_3a", t, oda)
         self._conv(w, p + ".branch3x3dbl_3b", t, odb)
         self._pool_branch(w, p + ".branch_pool", x, op)

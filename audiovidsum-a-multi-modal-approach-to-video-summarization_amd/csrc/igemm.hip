@@ -1140,8 +1140,12 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
       const long long row0 = (long long)m0 + wr * 64 + mt * 32 + rl0;
-      char* const ybase = y + (row0 * p.ldc + col8) * 4;
-      const long long ystep = (long long)RSTEP * p.ldc * 4;
+      char* ybase = y + (row0 * p.ldc + col8) * 4;
+      long long ystep = (long long)RSTEP * p.ldc * 4;
+      if (p.nsplit > 0 && col8 >= p.nsplit) {   // the second destination of avs_conv2d_nhwc_split (a lane's run is whole)
+        ybase = p.y2 + (row0 * p.ldc2 + (col8 - p.nsplit)) * 4;
+        ystep = (long long)RSTEP * p.ldc2 * 4;
+      }
 #pragma unroll
       for (int it = 0; it < NU; ++it) {
         const float* src = wreg + (rl0 + it * RSTEP) * H2_P + grp * 8;
@@ -1975,6 +1979,26 @@ extern "C" int avs_conv2d_nhwc(const avs_conv_desc* d, const void* d_x, const vo
   int st = conv_fill_params(d, d_x, d_w, d_bias, d_y, p, "avs_conv2d_nhwc");
   if (st != AVS_OK) return st;
   return igemm_launch(d->dtype, p, 1, (hipStream_t)stream, "avs_conv2d_nhwc");
+}
+
+// Several convolutions that read the SAME input as one contraction: their filters stacked into one weight matrix, output
+// columns [0, n_split) to d_y and [n_split, cout) to d_y2 - e.g. an Inception block's 1x1 heads, of which one writes its
+// slice of the block's concatenated output and the others feed further convolutions (features/extractors.py:26,73-90).
+extern "C" int avs_conv2d_nhwc_split(const avs_conv_desc* d, const void* d_x, const void* d_w, const float* d_bias,
+                                     void* d_y, int n_split, void* d_y2, int64_t y2_px_stride, avs_stream_t stream) {
+  const char* who = "avs_conv2d_nhwc_split";
+  IgemmParams p{};
+  int st = conv_fill_params(d, d_x, d_w, d_bias, d_y, p, who);
+  if (st != AVS_OK) return st;
+  AVS_REQUIRE(d->dtype == AVS_F16X2, AVS_E_UNSUPPORTED, "%s: built for AVS_F16X2", who);
+  AVS_REQUIRE(n_split > 0 && n_split < p.N && n_split % 8 == 0 && n_split <= p.ldc && y2_px_stride >= p.N - n_split &&
+                  y2_px_stride % 8 == 0,
+              AVS_E_SHAPE, "%s: 0 < n_split < cout in multiples of 8 slots, both destinations wide enough (n_split = %d)", who, n_split);
+  AVS_REQUIRE(d_y2 && (((uintptr_t)d_y2) & 31u) == 0, AVS_E_ALIGN, "%s: the second destination must be 32-byte aligned", who);
+  p.y2 = (char*)d_y2;
+  p.ldc2 = y2_px_stride;
+  p.nsplit = n_split;
+  return igemm_launch(d->dtype, p, 1, (hipStream_t)stream, who);
 }
 
 // ---- convolution + deterministic BatchNorm batch statistics (EPI_STATS) ----

@@ -47,6 +47,11 @@ struct IgemmParams {
   // AVS_F16P8 operands of the AVS_F16X2 1x1 forms (avs_conv_desc.formats): the input of the convolution + statistics
   // form (fetched into registers, the lo halves rebuilt there), the output / the residual of the given-affine form
   int x_p8, y_p8, res_p8;
+  // two destinations (AVS_F16X2, avs_conv2d_nhwc_split): output columns >= nsplit go to y2 (row stride ldc2, column c at
+  // c - nsplit) - several 1x1 convolutions that read the same input run as ONE contraction with their filters stacked
+  char* y2;
+  long long ldc2;
+  int nsplit;
   // clustered tile-local BatchNorm (local224.hip): a group = `cluster` consecutive tiles of tile_rows rows; every wave
   // publishes its tile's (mean, centred sum of squares) per column as 8-byte {value, epoch} granules in xchg
   // [tiles_m][tiles_n][4 waves][64] and reads its partners' - one exchange, merged by Chan's update in tile order

@@ -12,7 +12,7 @@ from ._abi import (ACT_NONE, ACT_RELU, AVS_BF16, AVS_F16X2, AVS_F32, AVS_F32_SPL
                    lib)
 
 __all__ = [
-    "ACT_NONE", "ACT_RELU", "linear", "gemm_nt_batched", "conv2d", "conv2d_raw", "conv_bnlocal_tile_rows", "conv_bncluster_ok", "cluster_exchange_errors", "conv1x1_bn", "conv1x1_gram_bn", "bn_gram_affine", "gram_supported", "frames_normalize", "pull_copy", "stem_conv_bn_pool", "stem_h2_operands", "stem_conv_pool_h2", "resize_bilinear",
+    "ACT_NONE", "ACT_RELU", "linear", "gemm_nt_batched", "conv2d", "conv2d_raw", "conv2d_split", "conv_bnlocal_tile_rows", "conv_bncluster_ok", "cluster_exchange_errors", "conv1x1_bn", "conv1x1_gram_bn", "bn_gram_affine", "gram_supported", "frames_normalize", "pull_copy", "stem_conv_bn_pool", "stem_h2_operands", "stem_conv_pool_h2", "resize_bilinear",
     "bn_batch_stats", "bn_apply", "bn_maxpool", "pool2d", "global_avgpool", "segment_mean", "hsv_frame_diff", "reflect_pad", "stft_f64", "stft_mel_fused", "power_mel",
     "clamp_topdb", "stft_mel_max", "stft_mel_segmean", "fill", "quantize", "resample", "lstm", "mha_batchaxis", "score_head", "mhsa_flash", "softmax_rows", "cdist", "dtw_path",
     "gather_scale", "dtype_code", "f16x2_pack", "f16x2_unpack", "bn_gram_affine_h2", "conv2d_affine",
@@ -642,6 +642,31 @@ def conv2d(x, wt, kh, kw, stride, pad, out, bias=None, act=ACT_NONE, bnstats=Non
                    x.stride(1), x.stride(2), wt, wt.stride(0), out, yps, bias, act, bnstats=bnstats, w_layout=w_layout,
                    variant=variant)
     return out if bnstats is None else r
+
+
+def conv2d_split(x, wt, out, n_split, out2, bias=None, act=ACT_NONE, w_layout=0):
+    """A 1x1 / stride-1 convolution over STACKED filters with two destinations (avs_conv2d_nhwc_split, AVS_F16X2): x NHWC
+    view [n,h,w,cin]; wt f16x2 [cout, cin]; output columns [0, n_split) -> out [n,h,w,n_split] (an NHWC view, e.g. a channel
+    slice of a concatenation buffer), columns [n_split, cout) -> out2 [n,h,w,cout - n_split]."""
+    n, h, w, cin = x.shape
+    cout = wt.shape[0]
+    for o, c in ((out, n_split), (out2, cout - n_split)):
+        if tuple(o.shape) != (n, h, w, c) or o.stride(3) != 1 or o.dtype != x.dtype:
+            raise ValueError("conv2d_split: destinations must be NHWC views [n,h,w,n_split] and [n,h,w,cout - n_split]")
+        if n * h * w > 1 and not (o.stride(1) == w * o.stride(2) and (n == 1 or o.stride(0) == h * w * o.stride(2))):
+            raise ValueError("conv2d_split: destination pixels must be dense in (n,h,w) order")
+    if wt.shape[1] != cin or wt.dtype != x.dtype or x.stride(3) != 1:
+        raise ValueError("conv2d_split: bad operands")
+    _dev(x, wt, out, out2, bias)
+    d = _abi.ConvDesc(AVS_F16X2, n, h, w, cin, 1, 1, 1, 1, 0, 0, h, w, cout, x.stride(0), x.stride(1), x.stride(2),
+                      wt.stride(0), out.stride(2), act, 1.0, int(w_layout), 0, 0)
+    flops = 2.0 * n * h * w * cout * cin
+    nbytes = 4.0 * n * h * w * (cin + cout)
+    _timed("conv", AVS_F16X2, flops, lambda: check(
+        lib().avs_conv2d_nhwc_split(ctypes.byref(d), _p(x), _p(wt), _p(bias), _p(out), int(n_split), _p(out2),
+                                    out2.stride(2), _stream()), "avs_conv2d_nhwc_split"), nbytes,
+           form="plain / bias+ReLU 1x1 (stacked heads)")
+    return out, out2
 
 
 # --------------------------------------------------------------------------- visual front end

@@ -142,6 +142,13 @@ enum { AVS_TILE_AUTO = 0, AVS_TILE_128 = 1, AVS_TILE_256 = 2, AVS_TILE_224 = 3, 
 
 int avs_conv2d_nhwc(const avs_conv_desc* desc, const void* d_x, const void* d_w,
                     const float* d_bias, void* d_y, avs_stream_t stream);
+/* The same with TWO destinations, AVS_F16X2: output columns [0, n_split) go to d_y (row stride desc->y_px_stride), columns
+ * [n_split, cout) to d_y2 (row stride y2_px_stride, column c at c - n_split).  Convolutions that read the same input - an
+ * Inception block's 1x1 heads (features/extractors.py:26,73-90) - run as ONE contraction over their stacked filters: the
+ * input is fetched once, and the head that belongs to the block's concatenated output still lands in its channel slice.
+ * n_split, both strides in multiples of 8 slots.                                                                       */
+int avs_conv2d_nhwc_split(const avs_conv_desc* desc, const void* d_x, const void* d_w, const float* d_bias, void* d_y,
+                          int n_split, void* d_y2, int64_t y2_px_stride, avs_stream_t stream);
 
 /* The same convolution (no bias, no activation) that also produces the BatchNorm batch statistics of its output
  * in its epilogue and folds them into the affine of avs_bn_batch_stats: for every group g = output_row /
