@@ -107,6 +107,8 @@ _SIGNATURES = {
     "avs_stft_mel_segmean_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "avs_stft_mel_segmean_f32": (c_int, [P, c_int64, P, P, P, P, P, P, c_int, P, c_int, P, P, c_int, P, c_int, c_float, P,
                                          c_int64, P, c_int64, P, c_int64, P]),
+    "avs_stft_mel_segmean_batch_f32": (c_int, [P, P, P, c_int, P, P, P, P, P, P, c_int, P, c_int, P, P, c_int, P, c_float, P,
+                                               c_int64, P, c_int64, P, c_int64, P]),
     "avs_power_mel_f32": (c_int, [P, c_int64, c_int, P, P, P, c_int, c_int, P, P, P]),
     "avs_clamp_topdb_f32": (c_int, [P, c_int64, P, c_float, P]),
     "avs_fill_f32": (c_int, [P, c_int64, c_float, P]),

@@ -179,6 +179,45 @@ class MelPlan:
         table.span = (int(bounds[0]), int(bounds[-1])) if len(bounds) else (0, 0)   # the STFT frames the segments cover
         return table
 
+    @staticmethod
+    def batch_tables(waves, bounds_per_track, device):
+        """A batch of tracks for segment_means_batch: the waveforms one after another (16-byte aligned starts) + per track the
+        STFT-frame boundaries of its consecutive segments (each list must start at 0 and end at the track's frame count: the
+        clamp is relative to the TRACK's maximum) -> (waves_cat, track_off, track_len, blocks [nblocks, 4], seg_block, seg_frames)."""
+        offs, lens, cur = [], [], 0
+        for w in waves:
+            offs.append(cur)
+            lens.append(int(w.numel()))
+            cur += (int(w.numel()) + 3) // 4 * 4
+        cat = torch.zeros(max(cur, 4), dtype=torch.float32, device=device)
+        for w, o in zip(waves, offs):
+            cat[o:o + w.numel()] = w.to(device=device, dtype=torch.float32)
+        blocks, seg_block, seg_frames = [], [0], []
+        sgm = 0
+        for trk, (bounds, ln) in enumerate(zip(bounds_per_track, lens)):
+            if ln <= N_FFT // 2:
+                raise RuntimeError(f"track {trk}: reflect padding needs more than {N_FFT // 2} samples")
+            if int(bounds[0]) != 0 or int(bounds[-1]) != 1 + ln // HOP:
+                raise ValueError("segment_means_batch: a track's segments must cover it (the clamp is relative to the track's maximum)")
+            for a, b in zip(bounds[:-1], bounds[1:]):
+                a, b = int(a), int(b)
+                for f in range(a, b, 32):
+                    blocks.append((f, min(32, b - f), sgm, trk))
+                seg_block.append(len(blocks))
+                seg_frames.append(max(0, b - a))
+                sgm += 1
+        mk = lambda v, shape, dt: torch.tensor(v, dtype=dt).reshape(shape).to(device)
+        return (cat, mk(offs, (len(offs),), torch.int64), mk(lens, (len(lens),), torch.int64),
+                mk(blocks, (len(blocks), 4), torch.int32), mk(seg_block, (len(seg_block),), torch.int32),
+                mk(seg_frames, (len(seg_frames),), torch.int32))
+
+    def segment_means_batch(self, tables, out_log2=None, out_mfcc_db=None, top_db=80.0):
+        """segment_means for every track of a batch in ONE set of launches (tables = batch_tables(...)); segments are
+        numbered over the batch in track order."""
+        cat, toff, tlen, blocks, seg_block, seg_frames = tables
+        return ops.stft_mel_segmean_batch(cat, toff, tlen, self.window, self.cos_t, self.sin_t, self.fb, self.fb_lo, self.fb_hi,
+                                          blocks, seg_block, seg_frames, top_db=top_db, out_log2=out_log2, out_db=out_mfcc_db)[:2]
+
     def segment_means(self, wave, table, out_log2=None, out_mfcc_db=None, top_db=80.0):
         """Per segment (a shot's slice of the track) the time mean of the log2-mel rows (out_log2 [nseg, >= n_mels]) and
         of the top_db-clamped dB-mel rows (out_mfcc_db; its DCT is the mean of the MFCC rows: the DCT and mfcc_proj are

@@ -196,13 +196,23 @@ __global__ __launch_bounds__(256, 2) void stft_mel_fused_kernel(
     const int* __restrict__ fb_lo, const int* __restrict__ fb_hi, int nmel, float* __restrict__ out_log2,
     float* __restrict__ out_db, float* __restrict__ out_pow, float* __restrict__ gmax, const int* __restrict__ blocks,
     float* __restrict__ part_log2, float* __restrict__ part_db, const float* __restrict__ max_in, float top_db,
-    float* __restrict__ db_rows) {
+    float* __restrict__ db_rows, const long long* __restrict__ track_off, const long long* __restrict__ track_len) {
+  // SEG batch mode (track_off != nullptr): block rows are (first frame, frames, segment, track); the block's waveform is
+  // x + track_off[track] (track_len[track] samples), its maximum gmax[track] - every track of a batch in ONE launch
+  const int bstride = (SEG && track_off) ? 4 : 3;
+  if (SEG && track_off) {
+    const int trk = blocks[4 * blockIdx.x + 3];
+    x += track_off[trk];
+    t = track_len[trk];
+    frames = 1 + t / AVS_FUSED_HOP;
+    if (gmax) gmax += trk;
+  }
   constexpr int SPAN = AVS_FUSED_FPB * AVS_FUSED_HOP + (AVS_FUSED_NFFT - AVS_FUSED_HOP);   // 6600 samples
   __shared__ __attribute__((aligned(16))) float span[SPAN];
   __shared__ double win[AVS_FUSED_NFFT];
   __shared__ float pw[AVS_FUSED_FPB][AVS_FUSED_BINS + 3];
   const int tid = threadIdx.x;
-  long long f0 = SEG ? (long long)blocks[3 * blockIdx.x] : (long long)blockIdx.x * AVS_FUSED_FPB;
+  long long f0 = SEG ? (long long)blocks[bstride * blockIdx.x] : (long long)blockIdx.x * AVS_FUSED_FPB;
   if (SEG) f0 = f0 < 0 ? 0 : (f0 >= frames ? frames - 1 : f0);   // device table: clamped into the track
   // ---- stage the span: padded position q = f0 * 200 + i is sample q - 200, reflected at both ends
   const long long q0 = f0 * AVS_FUSED_HOP - AVS_FUSED_NFFT / 2;
@@ -280,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void stft_mel_fused_kernel(
     // db_rows (one-pass mode): the track's maximum is not known yet - the block's UNCLAMPED dB rows go to the workspace
     // ([block][32][nmel]) and the maximum of the clamped mel power to gmax; segment_db_sum_kernel clamps and sums them
     // (same values, same order: bit-identical to the two-pass form)
-    int nf = blocks[3 * blockIdx.x + 1];
+    int nf = blocks[bstride * blockIdx.x + 1];
     nf = nf < 0 ? 0 : (nf > AVS_FUSED_FPB ? AVS_FUSED_FPB : nf);   // (the table is device data: never trust it past the tile)
     const float thr = (part_db && !db_rows) ? 10.f * log10f(*max_in) - top_db : 0.f;
     float lmax = 0.f;
@@ -349,7 +359,8 @@ extern "C" int avs_stft_mel_fused_f32(const float* d_wave, int64_t t, const doub
   AVS_REQUIRE(blocks < (1ll << 31), AVS_E_SHAPE, "%s: too many frames", who);
   hipLaunchKernelGGL(stft_mel_fused_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_wave,
                      (long long)t, frames, d_window, d_cos, d_sin, d_fb, d_fb_lo, d_fb_hi, nmel, d_log2mel, d_db, d_power,
-                     d_max, (const int*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr, 0.f, (float*)nullptr);
+                     d_max, (const int*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr, 0.f, (float*)nullptr,
+                     (const long long*)nullptr, (const long long*)nullptr);
   AVS_CHECK_LAUNCH(who);
   return AVS_OK;
 }
@@ -357,10 +368,11 @@ extern "C" int avs_stft_mel_fused_f32(const float* d_wave, int64_t t, const doub
 // One-pass mode of avs_stft_mel_segmean_f32: part_db[b, m] = sum over the block's frames (in order) of max(db_rows, threshold),
 // the threshold from the track maximum the front-end pass has just found.  Bandwidth-bound: reads the dB rows once.
 __global__ __launch_bounds__(256) void segment_db_sum_kernel(const float* __restrict__ db_rows, const int* __restrict__ blocks,
-                                                             int nmel, const float* __restrict__ gmax, float top_db,
-                                                             float* __restrict__ part_db) {
-  int nf = blocks[3 * blockIdx.x + 1];
+                                                             int bstride, int nmel, const float* __restrict__ gmax,
+                                                             float top_db, float* __restrict__ part_db) {
+  int nf = blocks[bstride * blockIdx.x + 1];
   nf = nf < 0 ? 0 : (nf > AVS_FUSED_FPB ? AVS_FUSED_FPB : nf);
+  if (bstride == 4) gmax += blocks[4 * blockIdx.x + 3];   // batch mode: the block's track
   const float thr = 10.f * log10f(*gmax) - top_db;
   for (int m = threadIdx.x; m < nmel; m += 256) {
     const float* __restrict__ r = db_rows + (long long)blockIdx.x * AVS_FUSED_FPB * nmel + m;
@@ -422,9 +434,57 @@ extern "C" int avs_stft_mel_segmean_f32(const float* d_wave, int64_t t, const do
     hipLaunchKernelGGL(stft_mel_fused_kernel<true>, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, d_wave,
                        (long long)t, frames, d_window, d_cos, d_sin, d_fb, d_fb_lo, d_fb_hi, nmel, (float*)nullptr,
                        (float*)nullptr, (float*)nullptr, one_pass ? d_max : (float*)nullptr, d_blocks, p_log2, p_db, d_max,
-                       top_db, rows);
+                       top_db, rows, (const long long*)nullptr, (const long long*)nullptr);
     if (one_pass)
-      hipLaunchKernelGGL(segment_db_sum_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, rows, d_blocks, nmel,
+      hipLaunchKernelGGL(segment_db_sum_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, rows, d_blocks, 3, nmel,
+                         d_max, top_db, p_db);
+  }
+  long long gx = avs_cdiv((long long)nseg * nmel, 256);
+  if (gx > 4096) gx = 4096;
+  if (d_mean_log2)
+    hipLaunchKernelGGL(segment_fold_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, p_log2, d_seg_block,
+                       d_seg_frames, nseg, nmel, d_mean_log2, (long long)ld_log2);
+  if (d_mean_db)
+    hipLaunchKernelGGL(segment_fold_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, p_db, d_seg_block,
+                       d_seg_frames, nseg, nmel, d_mean_db, (long long)ld_db);
+  AVS_CHECK_LAUNCH(who);
+  return AVS_OK;
+}
+
+// The same for a BATCH of tracks in one set of launches: d_waves holds the tracks one after another (track i at sample offset
+// d_track_off[i], a multiple of 4; d_track_len[i] samples), block rows are (first STFT frame inside the track, frames <= 32,
+// segment, track), segments are numbered over the whole batch; d_max [ntracks] receives every track's maximum (find_max = 1
+// semantics: the table covers every track).  Four launches for all tracks instead of five per track.
+extern "C" int avs_stft_mel_segmean_batch_f32(const float* d_waves, const int64_t* d_track_off, const int64_t* d_track_len,
+                                              int ntracks, const double* d_window, const double* d_cos, const double* d_sin,
+                                              const float* d_fb, const int* d_fb_lo, const int* d_fb_hi, int nmel,
+                                              const int* d_blocks, int nblocks, const int* d_seg_block, const int* d_seg_frames,
+                                              int nseg, float* d_max, float top_db, float* d_mean_log2, int64_t ld_log2,
+                                              float* d_mean_db, int64_t ld_db, void* d_ws, int64_t ws_bytes, avs_stream_t stream) {
+  const char* who = "avs_stft_mel_segmean_batch_f32";
+  AVS_REQUIRE(ntracks >= 0 && nmel > 0 && nmel <= 1024 && nblocks >= 0 && nseg >= 0, AVS_E_SHAPE, "%s: ntracks=%d nmel=%d nblocks=%d nseg=%d",
+              who, ntracks, nmel, nblocks, nseg);
+  if (nseg == 0 || ntracks == 0) return AVS_OK;
+  AVS_REQUIRE(d_waves && d_track_off && d_track_len && d_window && d_cos && d_sin && d_fb && d_fb_lo && d_fb_hi && d_blocks &&
+                  d_seg_block && d_seg_frames && d_max,
+              AVS_E_ARG, "%s: null pointer", who);
+  AVS_REQUIRE(d_mean_log2 || d_mean_db, AVS_E_ARG, "%s: no output requested", who);
+  AVS_REQUIRE((!d_mean_log2 || ld_log2 >= nmel) && (!d_mean_db || ld_db >= nmel), AVS_E_SHAPE, "%s: output rows too short", who);
+  AVS_REQUIRE(avs_aligned16(d_waves), AVS_E_ALIGN, "%s: the waveforms must be 16-byte aligned", who);
+  const int64_t per = (int64_t)nblocks * nmel * 4;
+  const int64_t need = avs_stft_mel_segmean_workspace_bytes(nblocks, nmel, d_mean_log2 != nullptr, d_mean_db != nullptr, 1);
+  AVS_REQUIRE(d_ws && ws_bytes >= need, AVS_E_WORKSPACE, "%s: workspace %lld < %lld bytes", who, (long long)ws_bytes, (long long)need);
+  float* p_log2 = d_mean_log2 ? (float*)d_ws : nullptr;
+  float* p_db = d_mean_db ? (float*)((char*)d_ws + (d_mean_log2 ? per : 0)) : nullptr;
+  float* rows = d_mean_db ? (float*)((char*)d_ws + per * ((d_mean_log2 ? 1 : 0) + 1)) : nullptr;
+  AVS_REQUIRE(hipMemsetAsync(d_max, 0, sizeof(float) * ntracks, (hipStream_t)stream) == hipSuccess, AVS_E_HIP, "%s: memset", who);
+  if (nblocks > 0) {
+    hipLaunchKernelGGL(stft_mel_fused_kernel<true>, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, d_waves, 0ll, 0ll,
+                       d_window, d_cos, d_sin, d_fb, d_fb_lo, d_fb_hi, nmel, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                       d_mean_db ? d_max : (float*)nullptr, d_blocks, p_log2, p_db, d_max, top_db, rows,
+                       (const long long*)d_track_off, (const long long*)d_track_len);
+    if (d_mean_db)
+      hipLaunchKernelGGL(segment_db_sum_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, rows, d_blocks, 4, nmel,
                          d_max, top_db, p_db);
   }
   long long gx = avs_cdiv((long long)nseg * nmel, 256);

@@ -14,7 +14,7 @@ from ._abi import (ACT_NONE, ACT_RELU, AVS_BF16, AVS_F16X2, AVS_F32, AVS_F32_SPL
 __all__ = [
     "ACT_NONE", "ACT_RELU", "linear", "gemm_nt_batched", "conv2d", "conv2d_raw", "conv2d_split", "conv_bnlocal_tile_rows", "conv_bncluster_ok", "cluster_exchange_errors", "conv1x1_bn", "conv1x1_gram_bn", "bn_gram_affine", "gram_supported", "frames_normalize", "pull_copy", "stem_conv_bn_pool", "stem_h2_operands", "stem_conv_pool_h2", "resize_bilinear",
     "bn_batch_stats", "bn_apply", "bn_maxpool", "pool2d", "global_avgpool", "segment_mean", "hsv_frame_diff", "reflect_pad", "stft_f64", "stft_mel_fused", "power_mel",
-    "clamp_topdb", "stft_mel_max", "stft_mel_segmean", "fill", "quantize", "resample", "lstm", "mha_batchaxis", "score_head", "mhsa_flash", "softmax_rows", "cdist", "dtw_path",
+    "clamp_topdb", "stft_mel_max", "stft_mel_segmean", "stft_mel_segmean_batch", "fill", "quantize", "resample", "lstm", "mha_batchaxis", "score_head", "mhsa_flash", "softmax_rows", "cdist", "dtw_path",
     "gather_scale", "dtype_code", "f16x2_pack", "f16x2_unpack", "bn_gram_affine_h2", "conv2d_affine",
 ]
 
@@ -738,11 +738,12 @@ def stem_conv_bn_pool(frames_u8, wt, denom, mean, std, frames_per_group, gamma, 
     return y, scale, shift
 
 
-def stem_h2_operands(weight, denom, mean, std):
+def stem_h2_operands(weight, denom, mean, std, pack=True):
     """The weight operand of avs_stem_conv_pool_f16x2 from the stem's OIHW weight [64,3,7,7], with the normalisation
     x = (v / denom - mean_c) / std_c folded in (prepared once per parameter version, in float64): an AVS_F16X2 image
     [64, 224] in the 7 x 8 x 4 layout - channels 0-2 = w / (denom std_c), channel 3 = -sum_c w mean_c / std_c (the kernel
-    feeds it 1 for a pixel inside the image and 0 outside: the zero padding is of the NORMALISED input)."""
+    feeds it 1 for a pixel inside the image and 0 outside: the zero padding is of the NORMALISED input).
+    pack=False: the fp32 rows before the AVS_F16X2 packing (host-side checks of the folding)."""
     w64 = weight.detach().double()                                   # [O, C, kh, kw]
     o, c, kh, kw = w64.shape
     if (o, c, kh, kw) != (64, 3, 7, 7):
@@ -752,7 +753,8 @@ def stem_h2_operands(weight, denom, mean, std):
     wp = torch.zeros((o, kh, 8, 4), dtype=torch.float64, device=w64.device)
     wp[:, :, :kw, :c] = (w64 / (float(denom) * std_t)).permute(0, 2, 3, 1)
     wp[:, :, :kw, 3] = -(w64 * (mean_t / std_t)).sum(dim=1)
-    return f16x2_pack(wp.reshape(o, kh * 8 * 4).float().contiguous())
+    rows = wp.reshape(o, kh * 8 * 4).float().contiguous()
+    return f16x2_pack(rows) if pack else rows
 
 
 def stem_conv_pool_h2(frames_u8, wimg, frames_per_group, gamma, beta, eps):
@@ -997,6 +999,34 @@ def stft_mel_segmean(wave, window, cos_t, sin_t, fb, fb_lo, fb_hi, blocks, seg_b
                                        _stream()),
         "avs_stft_mel_segmean_f32"))
     return out_log2, out_db
+
+
+def stft_mel_segmean_batch(waves, track_off, track_len, window, cos_t, sin_t, fb, fb_lo, fb_hi, blocks, seg_block, seg_frames,
+                           top_db=80.0, out_log2=None, out_db=None):
+    """stft_mel_segmean for a batch of tracks in one set of launches (avs_stft_mel_segmean_batch_f32): waves = the tracks one
+    after another (fp32, 16-byte aligned starts), track_off / track_len int64 [ntracks] on the device, blocks int32
+    [nblocks, 4] = (first frame inside the track, frames <= 32, segment, track).  Returns (out_log2, out_db, gmax[ntracks])."""
+    _dev(waves, track_off, track_len, blocks, seg_block, seg_frames, out_log2, out_db)
+    _f32(waves, "waves")
+    nmel = fb.shape[1]
+    ntracks = track_len.numel()
+    nblocks, nseg = blocks.shape[0], seg_frames.numel()
+    gmax = torch.empty(max(ntracks, 1), dtype=torch.float32, device=waves.device)
+    need = int(lib().avs_stft_mel_segmean_workspace_bytes(nblocks, nmel, int(out_log2 is not None), int(out_db is not None), 1))
+    key = _ws_key(waves.device)
+    ws = _segmean_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=waves.device)
+        _segmean_ws[key] = ws
+    nbytes = 4.0 * waves.numel() + 4.0 * nseg * nmel * (int(out_log2 is not None) + int(out_db is not None))
+    _timed("audio", AVS_F32, nbytes, lambda: check(
+        lib().avs_stft_mel_segmean_batch_f32(_p(waves), _p(track_off), _p(track_len), ntracks, _p(window), _p(cos_t), _p(sin_t),
+                                             _p(fb), _p(fb_lo), _p(fb_hi), nmel, _p(blocks), nblocks, _p(seg_block),
+                                             _p(seg_frames), nseg, _p(gmax), float(top_db), _p(out_log2),
+                                             out_log2.stride(0) if out_log2 is not None else 0, _p(out_db),
+                                             out_db.stride(0) if out_db is not None else 0, _p(ws), ws.numel(), _stream()),
+        "avs_stft_mel_segmean_batch_f32"))
+    return out_log2, out_db, gmax
 
 
 def clamp_topdb(x, gmax, top_db):

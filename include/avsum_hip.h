@@ -467,6 +467,17 @@ int avs_stft_mel_segmean_f32(const float* d_wave, int64_t t, const double* d_win
                              const int* d_blocks, int nblocks, const int* d_seg_block, const int* d_seg_frames, int nseg,
                              float* d_max, int find_max, float top_db, float* d_mean_log2, int64_t ld_log2,
                              float* d_mean_db, int64_t ld_db, void* d_ws, int64_t ws_bytes, avs_stream_t stream);
+/* The same for a BATCH of tracks in one set of launches (find_max = 1 semantics per track): d_waves holds the tracks one
+ * after another - track i at sample offset d_track_off[i] (a multiple of 4: 16-byte aligned), d_track_len[i] samples -,
+ * d_blocks int32 [nblocks, 4] = (first STFT frame inside its track, frames <= 32, segment, track), segments numbered over
+ * the whole batch (d_seg_block / d_seg_frames as above), d_max fp32 [ntracks] receives every track's maximum.  Four
+ * launches for all tracks of a batch instead of five per track (configs[2]: 50 tracks).                                */
+int avs_stft_mel_segmean_batch_f32(const float* d_waves, const int64_t* d_track_off, const int64_t* d_track_len, int ntracks,
+                                   const double* d_window, const double* d_cos, const double* d_sin, const float* d_fb,
+                                   const int* d_fb_lo, const int* d_fb_hi, int nmel, const int* d_blocks, int nblocks,
+                                   const int* d_seg_block, const int* d_seg_frames, int nseg, float* d_max, float top_db,
+                                   float* d_mean_log2, int64_t ld_log2, float* d_mean_db, int64_t ld_db, void* d_ws,
+                                   int64_t ws_bytes, avs_stream_t stream);
 
 /* Power spectrum -> mel filterbank -> log.  d_spec is [frames, 2*nbins]
  * (re | im per frame, from avs_gemm_nt against the windowed DFT basis);

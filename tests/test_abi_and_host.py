@@ -340,3 +340,40 @@ def test_pipeline_pass_sizes_cover_every_frame_in_equal_passes():
         passes = -(-count // per)
         assert passes == max(1, -(-count // max(gsz, chunk // gsz * gsz)))     # never more passes than the cap needs
         assert (passes - 1) * per < count <= passes * per
+
+
+def test_audio_batch_tables_host_logic():
+    """MelPlan.batch_tables: tracks laid out one after another at 16-byte aligned offsets, block rows (first frame inside
+    the track, frames <= 32, segment over the batch, track)."""
+    import torch
+    from avsum_amd.audio import MelPlan
+    waves = [torch.arange(1001, dtype=torch.float32), torch.ones(7000)]
+    bounds = [[0, 2, 1 + 1001 // 200], [0, 33, 33, 1 + 7000 // 200]]
+    cat, toff, tlen, blocks, seg_block, seg_frames = MelPlan.batch_tables(waves, bounds, torch.device("cpu"))
+    assert toff.tolist() == [0, 1004] and tlen.tolist() == [1001, 7000] and cat.numel() == 1004 + 7000
+    assert torch.equal(cat[:1001], waves[0]) and cat[1001:1004].abs().sum() == 0 and torch.equal(cat[1004:], waves[1])
+    assert seg_frames.tolist() == [2, 4, 33, 0, 3] and seg_block.tolist() == [0, 1, 2, 4, 4, 5]
+    assert blocks.tolist() == [[0, 2, 0, 0], [2, 4, 1, 0], [0, 32, 2, 1], [32, 1, 2, 1], [33, 3, 4, 1]]
+
+
+def test_stem_normalisation_folded_into_the_weights():
+    """ops.stem_h2_operands: conv1 of the NORMALISED image ((v - mean_c) / std_c, zero padded AFTER the normalisation,
+    features/extractors.py:126-140 + the trunk's conv1) equals the convolution of the RAW bytes + an "inside the image"
+    channel with the folded weights - border rows / columns included (float64 check of the algebra the fused f16x2 stem
+    relies on; its kernel is tested on the GPU)."""
+    import torch
+    import torch.nn.functional as F
+    from avsum_amd import ops
+    from avsum_amd.cnn import RESNET_MEAN, RESNET_STD
+    g = torch.Generator().manual_seed(4)
+    w = torch.randn(64, 3, 7, 7, generator=g)
+    v = torch.randint(0, 256, (2, 3, 37, 41), generator=g).double()
+    mean = torch.tensor(RESNET_MEAN, dtype=torch.float64).view(1, 3, 1, 1)
+    std = torch.tensor(RESNET_STD, dtype=torch.float64).view(1, 3, 1, 1)
+    ref = F.conv2d((v - mean) / std, w.double(), None, 2, 3)
+    rows = ops.stem_h2_operands(w, 1.0, RESNET_MEAN, RESNET_STD, pack=False)          # [64, 7 * 8 * 4]
+    w4 = rows.double().view(64, 7, 8, 4)[:, :, :7, :].permute(0, 3, 1, 2)             # [64, 4, 7, 7]
+    v4 = torch.cat([v, torch.ones(2, 1, 37, 41, dtype=torch.float64)], 1)             # the 4th channel: inside the image
+    got = F.conv2d(v4, w4, None, 2, 3)
+    assert rows.view(64, 7, 8, 4)[:, :, 7].abs().max() == 0                            # the 8th pixel of a kernel row is padding
+    assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()            # (the folded rows are fp32)

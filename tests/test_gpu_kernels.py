@@ -503,6 +503,39 @@ def test_segment_means_without_the_frame_matrices(dev):
     assert outs[0][0][:, 128:].abs().max().item() == 0      # the columns past n_mels are not touched
 
 
+def test_segment_means_batch_equals_per_track(dev):
+    """avs_stft_mel_segmean_batch_f32 (every track of a batch in one set of launches, the tracks one after another in one
+    buffer) gives bit for bit the per-track calls' means (features/extractors.py:232-246 per shot); tracks of different
+    lengths, 1-frame and empty segments."""
+    from avsum_amd.audio import MelPlan
+    plan = MelPlan.get(16000, 128, 40, dev)
+    g = torch.Generator().manual_seed(17)
+    waves, bounds = [], []
+    for i, tt in enumerate((16123, 50000, 801, 33333)):
+        time = torch.arange(tt) / 16000.0
+        waves.append((0.4 * torch.sin(2 * np.pi * (300 + 170 * i) * time) + 0.05 * torch.randn(tt, generator=g)).to(dev))
+        frames = 1 + tt // 200
+        cuts = sorted(set([0, 1, min(frames, 34), min(frames, 34), frames // 2, frames]))
+        bounds.append([0] + [c for c in cuts if c > 0] if cuts[0] == 0 else cuts)
+    bounds[1] = [0, 7, 7, 100, 1 + 50000 // 200]          # an empty segment
+    tables = plan.batch_tables(waves, bounds, dev)
+    nseg = sum(len(b) - 1 for b in bounds)
+    got_log2, got_db = torch.zeros((nseg, 128), device=dev), torch.zeros((nseg, 128), device=dev)
+    plan.segment_means_batch(tables, got_log2, got_db)
+    again_log2, again_db = torch.zeros_like(got_log2), torch.zeros_like(got_db)
+    plan.segment_means_batch(tables, again_log2, again_db)
+    assert torch.equal(got_log2, again_log2) and torch.equal(got_db, again_db)
+    row = 0
+    for w, b in zip(waves, bounds):
+        k = len(b) - 1
+        ref_log2, ref_db = torch.zeros((k, 128), device=dev), torch.zeros((k, 128), device=dev)
+        plan.segment_means(w, plan.segment_table(b, dev), ref_log2, ref_db)
+        assert torch.equal(got_log2[row:row + k], ref_log2) and torch.equal(got_db[row:row + k], ref_db)
+        row += k
+    with pytest.raises(ValueError, match="cover"):
+        plan.batch_tables(waves[:1], [[0, 5]], dev)
+
+
 def test_lstm_vs_oracle(dev):
     ops = _ops()
     from oracle import scorer as osc
