@@ -87,7 +87,11 @@ int avs_f16x2_unpack_f32(const void* d_src, float* d_dst, int64_t n, avs_stream_
  * values 0-7, of values 8-15, the 16 remainder bytes.  The storage format of the inner block outputs of ResNet layers
  * 1-2 in the AVS_F16X2 trunk (features/extractors.py:29,65): written by avs_conv2d_nhwc_affine (AVS_Y_F16P8), read as
  * its residual (AVS_RES_F16P8) and as the input of avs_conv2d_nhwc_bnstats (AVS_X_F16P8), where the fp16 lo halves the
- * matrix cores take are rebuilt in registers (the same bits as the AVS_F16X2 input path gives on the same values).
+ * matrix cores take are rebuilt in registers: the same VALUES as the AVS_F16X2 input path on the same tensor, and the same
+ * operand bits for |x| >= 2^-6 (below that the hi | lo split of a value is not unique - the 2^-24 floor - so outputs agree to
+ * the format's resolution there, not bit for bit: tests/test_gpu_f16p8.py).
+ * Both formats SATURATE at +-65504 and store a NaN as -65504 (the clamp is an fmin / fmax pair): the trunk's un-divided
+ * inputs (up to 1131) with He-scale weights give raw stem outputs of O(10^3), far from the limit.
  * fp32 [n] <-> AVS_F16P8 [n], n a multiple of 16, both sides 16-byte aligned (tests, tools).                      */
 int avs_f16p8_pack_f32(const float* d_src, void* d_dst, int64_t n, avs_stream_t stream);
 int avs_f16p8_unpack_f32(const void* d_src, float* d_dst, int64_t n, avs_stream_t stream);
