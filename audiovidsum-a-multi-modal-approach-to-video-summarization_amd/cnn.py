@@ -513,7 +513,10 @@ class ResNet50Runner:
             # 3-byte storage of this block's output: conv3 is the one-pass form here and so is the next block's (same
             # layer), whose conv1 is the convolution + statistics form on dense rows
             p8 = (bi in self.p8_blocks and self.bn_mode == "batch" and uniform and not s3 and self.block_hook is None
-                  and (aff2 is not None or self._gram_h2_ok(planes, planes * 4, 1, 1, gmax3)) and (planes * 4) % 32 == 0)
+                  and (aff2 is not None or self._gram_h2_ok(planes, planes * 4, 1, 1, gmax3)) and (planes * 4) % 32 == 0
+                  # ... and the READER agrees: the next block's conv1 (dense 1x1 on this output, convolution + statistics)
+                  and bi + 1 < len(w["blocks"]) and w["blocks"][bi + 1]["stride"] == 1 and "cd" not in w["blocks"][bi + 1]
+                  and ops.conv_bnstats_p8_input_ok(self.code, n, hout, planes * 4, w["blocks"][bi + 1]["planes"], gmax3))
             x = self._conv_bn(geom, xs, t2, blk["c3"], blk["b3"], groups, residual=idn, relu=True, local=s3,
                               in_affine=aff2, res_affine=affd, out_p8=p8)
             del t2, idn

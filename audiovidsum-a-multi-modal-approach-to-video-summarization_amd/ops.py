@@ -262,6 +262,19 @@ def conv_bncluster_ok(dtype, n, h, w, cin, kh, kw, sh, sw, ph, pw, ho, wo, cout,
     return True
 
 
+def conv_bnstats_p8_input_ok(dtype, n, h, cin, cout, rows_per_group):
+    """Does avs_conv2d_nhwc_bnstats take a dense 1x1 / stride-1 convolution [n,h,h,cin] -> cout with an AVS_F16P8 INPUT?
+    (the planner's question before it stores a block output in that format: the next block's conv1 is the reader)"""
+    d = _abi.ConvDesc(dtype, n, h, h, cin, 1, 1, 1, 1, 0, 0, h, h, cout, h * h * cin, h * cin, cin, cin, cout, ACT_NONE, 1.0,
+                      0, 0, _abi.X_F16P8)
+    r = lib().avs_conv2d_bnstats_workspace_bytes(ctypes.byref(d), int(rows_per_group))
+    if r == _abi.E_UNSUPPORTED:
+        return False
+    if r < 0:
+        check(int(r), "avs_conv2d_bnstats_workspace_bytes")
+    return True
+
+
 class _Exchange:
     """The granule buffer of avs_conv2d_nhwc_bncluster on one (device, stream): zeroed once, epochs count up per call."""
 

@@ -517,7 +517,7 @@ def main():
     if rank == 0 and args.cpu_sample > 0 and world == 1:
         sd_cpu = ({k: v.clone() for k, v in extractor.resnet.state_dict().items()},
                   {k: v.clone() for k, v in scorer.state_dict().items()},
-                  {k: v.clone() for k, v in extractor.inception.state_dict().items()} if use_inception else None)
+                  {k: v.clone() for k, v in extractor.inception.state_dict().items()})
     runner = extractor._resnet_runner
     runner.bn_local = args.bn_local == "on"
     if args.p8 == "off":
@@ -604,7 +604,7 @@ def main():
             torch.set_num_threads(cores)
             log(f"CPU baseline: {args.cpu_runs} runs of {args.cpu_sample} frames on {cores} cores")
             s_frames, s_ref, secs = cpu_runs(sd_cpu[0], sd_cpu[1], args.cpu_sample, args.cpu_runs, use_inception,
-                                             sd_cpu[2], fpg)
+                                             sd_cpu[2] if use_inception else None, fpg)
             rates = [args.cpu_sample / s for s in secs]
             cpu = {"value": round(statistics.median(rates), 2), "unit": "frames/s", "cores": cores, "kind": "port",
                    "runs": len(rates), "min": round(min(rates), 2), "max": round(max(rates), 2),
@@ -666,11 +666,22 @@ def main():
                     frames, offsets, base + "bf16, both trunks of VisualFeatureExtractor.forward (Inception-v3: eval "
                     "BatchNorm folded, 299x299 bilinear resize on the GPU)")
             del ext16, pipe16
-            run_sub("resnet50+inception3", FrameScoringPipeline(extractor, scorer, use_inception=True,
-                                                                chunk_frames=min(args.chunk, 8192), frames_per_group=fpg),
-                    frames, offsets, base + args.dtype + ", both trunks of VisualFeatureExtractor.forward in the headline "
-                    "arithmetic (Inception-v3: eval BatchNorm folded, bias + ReLU epilogue, 299x299 bilinear resize "
-                    "on the GPU)")
+            pipe_both = FrameScoringPipeline(extractor, scorer, use_inception=True, chunk_frames=min(args.chunk, 8192),
+                                             frames_per_group=fpg)
+            run_sub("resnet50+inception3", pipe_both, frames, offsets, base + args.dtype + ", both trunks of "
+                    "VisualFeatureExtractor.forward in the headline arithmetic (Inception-v3: eval BatchNorm folded, bias + ReLU "
+                    "epilogue, the 1x1 heads of a block as one contraction, 299x299 bilinear resize on the GPU): the 4096-d "
+                    "embedding with both halves live", roof=(dtype, split))
+            if sd_cpu is not None and args.cpu_sample > 0:
+                # its accuracy against the oracle with BOTH trunks on the CPU: two of the cpu_baseline's sample videos
+                log("both trunks: oracle scores of 2 sample videos (ResNet-50 + Inception-v3 on the CPU)")
+                b_frames, b_ref, _ = cpu_runs(sd_cpu[0], sd_cpu[1], args.cpu_sample, 2, True, sd_cpu[2], fpg)
+                b_off = synthetic.offsets_of([args.cpu_sample] * 2)
+                b_dev = torch.from_numpy(np.concatenate(b_frames)).to(dev)
+                a_ = accuracy_report(pipe_both.score(b_dev, b_off).cpu().numpy(), np.concatenate(b_ref), b_off)
+                subs["resnet50+inception3"]["accuracy"] = {k: (round(v, 8) if isinstance(v, float) else v) for k, v in a_.items()}
+                del b_dev
+            del pipe_both
             run_sub("frames_per_group_1", FrameScoringPipeline(extractor, scorer, use_inception=False,
                                                                chunk_frames=args.chunk, frames_per_group=1),
                     frames, offsets, base + args.dtype + ", every frame its own one-frame shot = its own BatchNorm "
