@@ -98,6 +98,7 @@ class FrameScoringPipeline:
         # pull kernel x16 and a 1024-frame lead pass, 0.955 - 0.960 with the copy engine
         self.host_pull_workgroups = 16
         self._stager_cache = {}
+        self.check_exchange = True      # score(): verify that no clustered-BatchNorm exchange timed out (one counter read)
         # streams = 2: consecutive passes of the ResNet trunk run on two HIP streams, pass i + 1 starting when pass i
         # has launched its layers 1-2: the HBM-bound half of one pass then shares the chip with the matrix-core-bound
         # half (layers 3-4) of the other.  Passes are independent (disjoint frames, disjoint rows of the output).
@@ -248,7 +249,15 @@ class FrameScoringPipeline:
             audio_rows = torch.zeros((visual.shape[0], self.scorer.audio_fc[0].in_features), dtype=torch.float32,
                                      device=visual.device)
         seq = torch.tensor(video_offsets, dtype=torch.int64, device=visual.device)
-        return self.scorer.score_rows(visual, audio_rows, seq, attn_batch=1)
+        scores = self.scorer.score_rows(visual, audio_rows, seq, attn_batch=1)
+        if self.check_exchange:
+            # the clustered BatchNorm launches of this call: a bounded wait that ran out means partner tiles were not
+            # co-resident (never seen; the dispatch order is not a HIP guarantee) - fail loudly instead of returning
+            # features normalised with incomplete statistics.  Reads one counter back (the caller syncs for the scores anyway)
+            bad = ops.cluster_exchange_errors(visual.device)
+            if bad:
+                raise RuntimeError(f"clustered BatchNorm: {bad} wave(s) gave up waiting for a partner tile's statistics")
+        return scores
 
     @staticmethod
     def select(scores, video_offsets):
