@@ -79,7 +79,7 @@ _SIGNATURES = {
     "avs_bn_gram_affine_f16x2": (c_int, [P, c_int64, c_int, P, P, P, c_int64, c_int, c_int64, c_int, P, P, c_float, P, P,
                                          P, c_int64, P]),
     "avs_conv2d_nhwc_affine": (c_int, [POINTER(ConvDesc), P, P, P, c_int64, P, P, P, c_int64, P, P, P]),
-    "avs_conv2d_nhwc_split": (c_int, [POINTER(ConvDesc), P, P, P, P, c_int, P, c_int64, P]),
+    "avs_conv2d_nhwc_split": (c_int, [POINTER(ConvDesc), P, P, P, P, c_int, P, c_int64, c_int, P]),
     "avs_conv2d_bnlocal_tile_rows": (c_int, [POINTER(ConvDesc), c_int64]),
     "avs_conv2d_nhwc_bnlocal": (c_int, [POINTER(ConvDesc), P, P, P, c_int64, P, P, c_float, P, c_int64, P]),
     "avs_conv2d_bncluster_workspace_bytes": (c_int64, [POINTER(ConvDesc), c_int64, c_int]),

@@ -663,6 +663,7 @@ class InceptionV3Runner:
         self.pool_after_conv = True   # branch_pool: 1x1 convolution first, average pooling on its (narrow) output
         self.split_tail_columns = False  # cout = 128 k + r (r <= 64): two launches instead of a mostly empty last column tile
         #                                  (measured: no gain - these layers are not bound by the matrix work; off)
+        self.stack_pool_head = True      # ... branch_pool's convolution too (its columns without bias / ReLU: they follow the pooling)
         self.stack_heads = True          # AVS_F16X2: the 1x1 heads of a block that read the block input run as ONE contraction
         #                                  over their stacked filters (avs_conv2d_nhwc_split): the input is fetched once
         self._key = None
@@ -722,39 +723,50 @@ class InceptionV3Runner:
         return ops.conv2d(x, wsel, c["kh"], c["kw"], c["s"], (c["ph"], c["pw"]), out, c["b"], ops.ACT_RELU,
                           split=self.f32_split, w_layout=layout)
 
-    def _heads(self, w, p, x, first, others, first_out):
+    def _heads(self, w, p, x, first, others, first_out, pool=None):
         """The block's 1x1 convolutions that read x: `first` (or None) writes first_out (its slice of the block's
-        concatenated output), `others` feed further convolutions.  Returns the NHWC views of the others' outputs.  With
-        stack_heads (AVS_F16X2): one contraction over the stacked filters, two destinations."""
+        concatenated output), `others` feed further convolutions, `pool` (or None) is branch_pool's convolution, whose
+        average pooling, bias and ReLU follow (_pool_branch).  Returns the NHWC views of the others' outputs (+ the pool
+        head's raw output, or None when it was not run here).  With stack_heads (AVS_F16X2): ONE contraction over the
+        stacked filters, two destinations, the pool head's columns without bias / ReLU."""
         names = [p + "." + nm for nm in others]
         couts = [w[nm]["cout"] for nm in names]
         n, h, ww, _ = x.shape
         if not (self.h2 and self.stack_heads) or any(w[nm]["parts"] is not None for nm in names):
             if first is not None:
                 self._conv(w, p + "." + first, x, first_out)
-            return [self._conv(w, nm, x) for nm in names]
-        key = ("stack", p, first, tuple(others))
+            return [self._conv(w, nm, x) for nm in names] + [None]
+        with_pool = (pool is not None and first is not None and self.pool_after_conv and self.stack_pool_head
+                     and w[p + "." + pool]["parts"] is None)
+        key = ("stack", p, first, tuple(others), with_pool)
         st = w.get(key)
         if st is None:
             members = ([p + "." + first] if first is not None else []) + names
             # (an AVS_F16X2 row is packed by itself - runs of 8 inside the row: the stacked image is the rows one after another)
-            rows = torch.cat([w[nm]["w"].rows for nm in members]).contiguous()
-            st = (_W(rows), torch.cat([w[nm]["b"] for nm in members]).contiguous())
+            rows = [w[nm]["w"].rows for nm in members]
+            bias = [w[nm]["b"] for nm in members]
+            if with_pool:
+                rows.append(w[p + "." + pool]["w"].rows)
+                bias.append(torch.zeros_like(w[p + "." + pool]["b"]))      # its bias comes after the pooling
+            st = (_W(torch.cat(rows).contiguous()), torch.cat(bias).contiguous())
             w[key] = st
         wst, bst = st
-        tmp = torch.empty((n, h, ww, sum(couts)), dtype=self.dtype, device=x.device)
+        cpool = w[p + "." + pool]["cout"] if with_pool else 0
+        tmp = torch.empty((n, h, ww, sum(couts) + cpool), dtype=self.dtype, device=x.device)
         wsel, layout = wst.conv_operand()
         if first is not None:
-            ops.conv2d_split(x, wsel, first_out, w[p + "." + first]["cout"], tmp, bst, ops.ACT_RELU, w_layout=layout)
+            ops.conv2d_split(x, wsel, first_out, w[p + "." + first]["cout"], tmp, bst, ops.ACT_RELU, w_layout=layout,
+                             relu_cols=(wst.rows.shape[0] - cpool) if with_pool else 0)
         else:
             ops.conv2d(x, wsel, 1, 1, 1, (0, 0), tmp, bst, ops.ACT_RELU, split=self.f32_split, w_layout=layout)
         views, o = [], 0
         for c in couts:
             views.append(tmp[..., o:o + c])
             o += c
+        views.append(tmp[..., o:o + cpool] if with_pool else None)
         return views
 
-    def _pool_branch(self, w, name, x, out):
+    def _pool_branch(self, w, name, x, out, z=None):
         """branch_pool = avg_pool2d(3, 1, 1) -> 1x1 conv -> folded BN -> ReLU, run as 1x1 conv (no bias) -> average ->
         + bias -> ReLU: the two linear maps commute (count_include_pad's zero padding included), and the pooling pass
         then moves cout (32-192) instead of cin (192-2048) channels."""
@@ -762,10 +774,11 @@ class InceptionV3Runner:
             return self._conv(w, name, self._pool(x, "avg", 3, 1, 1), out)
         c = w[name]
         n, h, ww, _ = x.shape
-        z = torch.empty((n, h, ww, c["cout"]), dtype=self.dtype, device=x.device)
-        for a, b, wp, _ in (c["parts"] or [(0, c["cout"], c["w"], None)]):
-            wsel, layout = wp.conv_operand()
-            ops.conv2d(x, wsel, 1, 1, 1, (0, 0), z[..., a:b], None, ops.ACT_NONE, split=self.f32_split, w_layout=layout)
+        if z is None:   # (else: the raw 1x1 output came out of the block's stacked-heads contraction)
+            z = torch.empty((n, h, ww, c["cout"]), dtype=self.dtype, device=x.device)
+            for a, b, wp, _ in (c["parts"] or [(0, c["cout"], c["w"], None)]):
+                wsel, layout = wp.conv_operand()
+                ops.conv2d(x, wsel, 1, 1, 1, (0, 0), z[..., a:b], None, ops.ACT_NONE, split=self.f32_split, w_layout=layout)
         return ops.pool2d(z, "avg", 3, 1, 1, out, c["b"], ops.ACT_RELU, code=self.ecode)
 
     def _pool(self, x, mode, k, s, p, out=None):
@@ -787,11 +800,11 @@ class InceptionV3Runner:
 
     def _block_a(self, w, p, x, pf):
         buf, (o1, o5, o3, op) = self._cat_buffer(x, [64, 64, 96, pf])
-        t5, t3 = self._heads(w, p, x, "branch1x1", ["branch5x5_1", "branch3x3dbl_1"], o1)
+        t5, t3, zp = self._heads(w, p, x, "branch1x1", ["branch5x5_1", "branch3x3dbl_1"], o1, pool="branch_pool")
         self._conv(w, p + ".branch5x5_2", t5, o5)
         t = self._conv(w, p + ".branch3x3dbl_2", t3)
         self._conv(w, p + ".branch3x3dbl_3", t, o3)
-        self._pool_branch(w, p + ".branch_pool", x, op)
+        self._pool_branch(w, p + ".branch_pool", x, op, zp)
         return buf
 
     def _block_b(self, w, p, x):
@@ -804,19 +817,19 @@ class InceptionV3Runner:
 
     def _block_c(self, w, p, x):
         buf, (o1, o7, od, op) = self._cat_buffer(x, [192, 192, 192, 192])
-        t7, td = self._heads(w, p, x, "branch1x1", ["branch7x7_1", "branch7x7dbl_1"], o1)
+        t7, td, zp = self._heads(w, p, x, "branch1x1", ["branch7x7_1", "branch7x7dbl_1"], o1, pool="branch_pool")
         t = self._conv(w, p + ".branch7x7_2", t7)
         self._conv(w, p + ".branch7x7_3", t, o7)
         t = td
         for i in (2, 3, 4):
             t = self._conv(w, f"{p}.branch7x7dbl_{i}", t)
         self._conv(w, p + ".branch7x7dbl_5", t, od)
-        self._pool_branch(w, p + ".branch_pool", x, op)
+        self._pool_branch(w, p + ".branch_pool", x, op, zp)
         return buf
 
     def _block_d(self, w, p, x):
         buf, (o3, o7, op) = self._cat_buffer(x, [320, 192, x.shape[3]], stride=2)
-        t3, t7 = self._heads(w, p, x, None, ["branch3x3_1", "branch7x7x3_1"], None)
+        t3, t7, _ = self._heads(w, p, x, None, ["branch3x3_1", "branch7x7x3_1"], None)
         self._conv(w, p + ".branch3x3_2", t3, o3)
         t = self._conv(w, p + ".branch7x7x3_2", t7)
         t = self._conv(w, p + ".branch7x7x3_3", t)
@@ -826,13 +839,13 @@ class InceptionV3Runner:
 
     def _block_e(self, w, p, x):
         buf, (o1, o3a, o3b, oda, odb, op) = self._cat_buffer(x, [320, 384, 384, 384, 384, 192])
-        t, td = self._heads(w, p, x, "branch1x1", ["branch3x3_1", "branch3x3dbl_1"], o1)
+        t, td, zp = self._heads(w, p, x, "branch1x1", ["branch3x3_1", "branch3x3dbl_1"], o1, pool="branch_pool")
         self._conv(w, p + ".branch3x3_2a", t, o3a)
         self._conv(w, p + ".branch3x3_2b", t, o3b)
         t = self._conv(w, p + ".branch3x3dbl_2", td)
         self._conv(w, p + ".branch3x3dbl_3a", t, oda)
         self._conv(w, p + ".branch3x3dbl_3b", t, odb)
-        self._pool_branch(w, p + ".branch_pool", x, op)
+        self._pool_branch(w, p + ".branch_pool", x, op, zp)
         return buf
 
     def forward(self, frames_u8, out=None):

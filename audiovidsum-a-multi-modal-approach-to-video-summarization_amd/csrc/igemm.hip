@@ -918,6 +918,8 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
     const int col8 = n0 + wc * WCOLS + grp * 8;
     const int row_lim = (EPI == EPI_BNLOCAL ? m0 + used : p.M);   // rows at or past this one do not exist
     const bool col_ok = col8 < p.N;
+    // avs_conv2d_nhwc_split: columns >= relu_cols (> 0) skip the ReLU (a stacked head whose activation follows a pooling)
+    const bool relu_l = relu && (p.relu_cols <= 0 || col8 < p.relu_cols);
     // AVS_F16P8 (output / residual of the given-affine form): byte offset of this lane's run of 8 columns inside a row -
     // 48 bytes per 16 columns: hi halves of columns 0-7 | of columns 8-15 | the 16 remainder bytes - and from its hi
     // halves to its remainder bytes
@@ -1181,7 +1183,7 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += rv[j];
           }
-          if (relu) {
+          if (relu_l) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
           }
@@ -1985,7 +1987,8 @@ extern "C" int avs_conv2d_nhwc(const avs_conv_desc* d, const void* d_x, const vo
 // columns [0, n_split) to d_y and [n_split, cout) to d_y2 - e.g. an Inception block's 1x1 heads, of which one writes its
 // slice of the block's concatenated output and the others feed further convolutions (features/extractors.py:26,73-90).
 extern "C" int avs_conv2d_nhwc_split(const avs_conv_desc* d, const void* d_x, const void* d_w, const float* d_bias,
-                                     void* d_y, int n_split, void* d_y2, int64_t y2_px_stride, avs_stream_t stream) {
+                                     void* d_y, int n_split, void* d_y2, int64_t y2_px_stride, int relu_cols,
+                                     avs_stream_t stream) {
   const char* who = "avs_conv2d_nhwc_split";
   IgemmParams p{};
   int st = conv_fill_params(d, d_x, d_w, d_bias, d_y, p, who);
@@ -1998,6 +2001,8 @@ extern "C" int avs_conv2d_nhwc_split(const avs_conv_desc* d, const void* d_x, co
   p.y2 = (char*)d_y2;
   p.ldc2 = y2_px_stride;
   p.nsplit = n_split;
+  AVS_REQUIRE(relu_cols >= 0 && relu_cols % 8 == 0 && relu_cols <= p.N, AVS_E_SHAPE, "%s: relu_cols in multiples of 8, at most cout", who);
+  p.relu_cols = relu_cols;
   return igemm_launch(d->dtype, p, 1, (hipStream_t)stream, who);
 }
 

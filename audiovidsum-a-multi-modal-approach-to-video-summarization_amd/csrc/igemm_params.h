@@ -52,6 +52,7 @@ struct IgemmParams {
   char* y2;
   long long ldc2;
   int nsplit;
+  int relu_cols;     // > 0: only the columns below it take the ReLU of a bias + ReLU epilogue
   // clustered tile-local BatchNorm (local224.hip): a group = `cluster` consecutive tiles of tile_rows rows; every wave
   // publishes its tile's (mean, centred sum of squares) per column as 8-byte {value, epoch} granules in xchg
   // [tiles_m][tiles_n][4 waves][64] and reads its partners' - one exchange, merged by Chan's update in tile order

@@ -657,10 +657,11 @@ def conv2d(x, wt, kh, kw, stride, pad, out, bias=None, act=ACT_NONE, bnstats=Non
     return out if bnstats is None else r
 
 
-def conv2d_split(x, wt, out, n_split, out2, bias=None, act=ACT_NONE, w_layout=0):
+def conv2d_split(x, wt, out, n_split, out2, bias=None, act=ACT_NONE, w_layout=0, relu_cols=0):
     """A 1x1 / stride-1 convolution over STACKED filters with two destinations (avs_conv2d_nhwc_split, AVS_F16X2): x NHWC
     view [n,h,w,cin]; wt f16x2 [cout, cin]; output columns [0, n_split) -> out [n,h,w,n_split] (an NHWC view, e.g. a channel
-    slice of a concatenation buffer), columns [n_split, cout) -> out2 [n,h,w,cout - n_split]."""
+    slice of a concatenation buffer), columns [n_split, cout) -> out2 [n,h,w,cout - n_split].  relu_cols > 0: with act =
+    ReLU only the columns below it are rectified."""
     n, h, w, cin = x.shape
     cout = wt.shape[0]
     for o, c in ((out, n_split), (out2, cout - n_split)):
@@ -677,7 +678,7 @@ def conv2d_split(x, wt, out, n_split, out2, bias=None, act=ACT_NONE, w_layout=0)
     nbytes = 4.0 * n * h * w * (cin + cout)
     _timed("conv", AVS_F16X2, flops, lambda: check(
         lib().avs_conv2d_nhwc_split(ctypes.byref(d), _p(x), _p(wt), _p(bias), _p(out), int(n_split), _p(out2),
-                                    out2.stride(2), _stream()), "avs_conv2d_nhwc_split"), nbytes,
+                                    out2.stride(2), int(relu_cols), _stream()), "avs_conv2d_nhwc_split"), nbytes,
            form="plain / bias+ReLU 1x1 (stacked heads)")
     return out, out2
 

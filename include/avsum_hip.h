@@ -150,9 +150,11 @@ int avs_conv2d_nhwc(const avs_conv_desc* desc, const void* d_x, const void* d_w,
  * [n_split, cout) to d_y2 (row stride y2_px_stride, column c at c - n_split).  Convolutions that read the same input - an
  * Inception block's 1x1 heads (features/extractors.py:26,73-90) - run as ONE contraction over their stacked filters: the
  * input is fetched once, and the head that belongs to the block's concatenated output still lands in its channel slice.
- * n_split, both strides in multiples of 8 slots.                                                                       */
+ * n_split, both strides in multiples of 8 slots.  relu_cols > 0 (a multiple of 8): with desc->act = ReLU only the columns
+ * below it are rectified - a stacked head whose bias + ReLU follow a pooling of its output (Inception's branch_pool, run as
+ * convolution -> average pooling -> bias -> ReLU) keeps its raw values.                                                  */
 int avs_conv2d_nhwc_split(const avs_conv_desc* desc, const void* d_x, const void* d_w, const float* d_bias, void* d_y,
-                          int n_split, void* d_y2, int64_t y2_px_stride, avs_stream_t stream);
+                          int n_split, void* d_y2, int64_t y2_px_stride, int relu_cols, avs_stream_t stream);
 
 /* The same convolution (no bias, no activation) that also produces the BatchNorm batch statistics of its output
  * in its epilogue and folds them into the affine of avs_bn_batch_stats: for every group g = output_row /

@@ -28,8 +28,8 @@ def main():
     ref = None
     for name, kw in (("baseline", dict(split_tail_columns=False, stack_heads=False)),
                      ("tail columns split", dict(split_tail_columns=True, stack_heads=False)),
-                     ("stacked heads", dict(split_tail_columns=False, stack_heads=True)),
-                     ("both", dict(split_tail_columns=True, stack_heads=True))):
+                     ("stacked heads", dict(split_tail_columns=False, stack_heads=True, stack_pool_head=False)),
+                     ("stacked heads + pool", dict(split_tail_columns=False, stack_heads=True, stack_pool_head=True))):
         r = InceptionV3Runner(net, torch.float32, f32_split="f16x2")
         for k, v in kw.items():
             if not hasattr(r, k):
