@@ -38,19 +38,29 @@ class _HostStager:
         self.filled = [torch.cuda.Event(), torch.cuda.Event()]
         self.freed = [None, None]
         self.counts = [0, 0]
+        self.base = 0     # pass i lives in buffer (i + base) % 2 (base = the buffer a prefetched first pass sits in)
 
-    def upload(self, i, one_pass):
+    def adopt(self, k, event, count):
+        """Pass 0 of this call was uploaded by the PREVIOUS call (embed(..., next_batch=)) into buffer k."""
+        self.base = k
+        self.filled[k] = event
+        self.counts[k] = count
+
+    def upload(self, i, one_pass, host=None):
+        """host: another pinned tensor to read from (the next call's frames, prefetched into the buffer this call's pass i
+        would take)."""
         _, where, contiguous = one_pass
-        k = i % 2
+        k = (i + self.base) % 2
+        src_all = self.host if host is None else host
         with torch.cuda.stream(self.copy_stream):
             if self.freed[k] is not None:
                 self.copy_stream.wait_event(self.freed[k])    # the pass that used this buffer has finished
             if contiguous:
                 cnt = where[1] - where[0]
                 if self.pull_workgroups > 0:
-                    ops.pull_copy(self.host[where[0]:where[1]], self.bufs[k][:cnt], self.pull_workgroups)
+                    ops.pull_copy(src_all[where[0]:where[1]], self.bufs[k][:cnt], self.pull_workgroups)
                 else:
-                    self.bufs[k][:cnt].copy_(self.host[where[0]:where[1]], non_blocking=True)
+                    self.bufs[k][:cnt].copy_(src_all[where[0]:where[1]], non_blocking=True)
             else:
                 # an index set: runs of consecutive frames (whole videos minus their tails, or the tails themselves), one
                 # transfer per run
@@ -60,7 +70,7 @@ class _HostStager:
                 starts = np.concatenate([[0], cuts])
                 ends = np.concatenate([cuts, [cnt]])
                 for a, b in zip(starts.tolist(), ends.tolist()):
-                    src = self.host[int(idx[a]):int(idx[a]) + (b - a)]
+                    src = src_all[int(idx[a]):int(idx[a]) + (b - a)]
                     if self.pull_workgroups > 0:
                         ops.pull_copy(src, self.bufs[k][a:b], self.pull_workgroups)
                     else:
@@ -69,12 +79,12 @@ class _HostStager:
         self.counts[k] = cnt
 
     def ready(self, i):
-        k = i % 2
+        k = (i + self.base) % 2
         torch.cuda.current_stream().wait_event(self.filled[k])
         return self.bufs[k][:self.counts[k]]
 
     def release(self, i):
-        k = i % 2
+        k = (i + self.base) % 2
         self.freed[k] = torch.cuda.Event()
         self.freed[k].record(torch.cuda.current_stream())
 
@@ -151,24 +161,15 @@ class FrameScoringPipeline:
         npass = max(1, -(-count // cap))
         return min(cap, max(gsz, -(-(-(-count // npass)) // gsz) * gsz))
 
-    def embed(self, frames_u8, video_offsets):
-        """uint8 [N,224,224,3] -> fp32 [N,4096] on the device (ResNet-50 | Inception-v3 halves).
-        frames_u8 on the device: read in place.  frames_u8 in PINNED host memory: every pass's frames are uploaded
-        by a copy stream into one of two staging buffers while the previous pass computes (PCIe-inclusive path)."""
-        n = frames_u8.shape[0]
-        host = not frames_u8.is_cuda
-        if host and not frames_u8.is_pinned():
-            raise ValueError("host frames must be in pinned memory (tensor.pin_memory()) for the overlapped upload")
-        dev = self.visual._resnet_runner.trunk[0].weight.device if host else frames_u8.device
-        visual = torch.zeros((n, 4096), dtype=torch.float32, device=dev)
-        passes = []   # (group size, frame slice | index array, contiguous)
+    def _build_passes(self, video_offsets, lead_ok):
+        """[(group size, frame slice | index array, contiguous)]: per uniform set, equal passes of at most chunk_frames frames
+        (whole groups); lead_ok: a short first pass in front (host frames whose first upload has nothing to hide behind)."""
+        passes = []
         for gsz, where in self._uniform_sets(video_offsets):
             contiguous = isinstance(where, tuple)
             lo, hi = where if contiguous else (0, len(where))
-            # passes of equal size (a short last pass runs the same launches on a fraction of the chip's worth of
-            # work): at most chunk_frames frames each, whole groups
             lead = 0
-            if host and not passes and self.host_lead_frames > 0:
+            if lead_ok and not passes and self.host_lead_frames > 0:
                 lead = max(gsz, self.host_lead_frames // gsz * gsz)
                 if lead * 2 >= hi - lo:
                     lead = 0                       # too few frames for a lead pass to be worth a launch sequence
@@ -179,10 +180,40 @@ class FrameScoringPipeline:
             for a in range(lo, hi, per_pass):
                 b = min(a + per_pass, hi)
                 passes.append((gsz, (a, b) if contiguous else where[a:b], contiguous))
-        stage = _HostStager(frames_u8, max((p[1][1] - p[1][0]) if p[2] else len(p[1]) for p in passes), dev,
-                            self.host_pull_workgroups, self._stager_cache) if host and passes else None
+        return passes
+
+    def embed(self, frames_u8, video_offsets, next_batch=None):
+        """uint8 [N,224,224,3] -> fp32 [N,4096] on the device (ResNet-50 | Inception-v3 halves).
+        frames_u8 on the device: read in place.  frames_u8 in PINNED host memory: every pass's frames are uploaded
+        on a copy stream into one of two staging buffers while the previous pass computes (PCIe-inclusive path).
+        next_batch = (pinned frames, offsets) of the batch the NEXT call will be given (a stream of batches): its first
+        pass is uploaded while this call's last pass computes, so that no upload of the next call is exposed and it needs no
+        short lead pass.  The caller must leave that tensor alone until the next call has consumed it."""
+        n = frames_u8.shape[0]
+        host = not frames_u8.is_cuda
+        if host and not frames_u8.is_pinned():
+            raise ValueError("host frames must be in pinned memory (tensor.pin_memory()) for the overlapped upload")
+        dev = self.visual._resnet_runner.trunk[0].weight.device if host else frames_u8.device
+        visual = torch.zeros((n, 4096), dtype=torch.float32, device=dev)
+        pref = self._stager_cache.get("prefetched") if host else None
+        if pref is not None and pref["key"] != (frames_u8.data_ptr(), n, tuple(video_offsets)):
+            pref = None                            # another batch than the one announced: its first pass is uploaded afresh
+        self._stager_cache.pop("prefetched", None)
+        passes = self._build_passes(video_offsets, lead_ok=host and pref is None)
+        next_first = None
+        if host and next_batch is not None and next_batch[0].shape[0] > 0:
+            if next_batch[0].is_cuda or not next_batch[0].is_pinned():
+                raise ValueError("next_batch frames must be in pinned host memory")
+            next_first = self._build_passes([int(v) for v in next_batch[1]], lead_ok=False)[0]
+        sizes = [(p[1][1] - p[1][0]) if p[2] else len(p[1]) for p in passes + ([next_first] if next_first else [])]
+        stage = _HostStager(frames_u8, max(sizes), dev, self.host_pull_workgroups, self._stager_cache) if host and passes else None
         if stage is not None:
-            stage.upload(0, passes[0])
+            if pref is not None and stage.bufs is pref["bufs"]:
+                stage.adopt(pref["k"], pref["event"], pref["count"])
+            else:
+                if pref is not None:               # the staging buffers were re-allocated meanwhile: start over with a lead pass
+                    passes = self._build_passes(video_offsets, lead_ok=True)
+                stage.upload(0, passes[0])
         # two-stream overlap: device-resident contiguous passes of the ResNet-only path (the common case)
         overlap = (self.streams == 2 and stage is None and not self.use_inception and len(passes) > 1
                    and all(p[2] for p in passes))
@@ -195,6 +226,13 @@ class FrameScoringPipeline:
             if stage is not None:
                 if i + 1 < len(passes):
                     stage.upload(i + 1, passes[i + 1])     # overlaps with this pass's kernels
+                elif next_first is not None:
+                    # the NEXT call's first pass, into the buffer this call's (non-existent) pass i + 1 would take
+                    stage.upload(i + 1, next_first, host=next_batch[0])
+                    k = (i + 1 + stage.base) % 2
+                    self._stager_cache["prefetched"] = {
+                        "key": (next_batch[0].data_ptr(), next_batch[0].shape[0], tuple(int(v) for v in next_batch[1])),
+                        "k": k, "event": stage.filled[k], "count": stage.counts[k], "bufs": stage.bufs}
                 chunk = stage.ready(i)
                 cnt = chunk.shape[0]
                 if contiguous:
@@ -240,10 +278,10 @@ class FrameScoringPipeline:
         return visual
 
     @torch.no_grad()
-    def score(self, frames_u8, video_offsets, audio_rows=None):
-        """Per-frame importance scores fp32 [N] for videos given as frame offsets [V+1]."""
+    def score(self, frames_u8, video_offsets, audio_rows=None, next_batch=None):
+        """Per-frame importance scores fp32 [N] for videos given as frame offsets [V+1].  next_batch: see embed()."""
         video_offsets = [int(v) for v in video_offsets]
-        visual = self.embed(frames_u8, video_offsets)
+        visual = self.embed(frames_u8, video_offsets, next_batch=next_batch)
         if audio_rows is None:
             # AudioFeatureExtractor.forward literally returns zeros(296) (SURVEY Q5)
             audio_rows = torch.zeros((visual.shape[0], self.scorer.audio_fc[0].in_features), dtype=torch.float32,

@@ -629,11 +629,13 @@ def main():
             subs = {}
             dev_samples = torch.from_numpy(np.concatenate(s_frames)).to(dev) if s_frames is not None else None
 
-            def run_sub(name, pipe_, frames_, offsets_, note, steps_=2, roof=None, acc=False):
+            def run_sub(name, pipe_, frames_, offsets_, note, steps_=2, roof=None, acc=False, stream_of_batches=False):
                 """roof = (torch dtype, split): also bracket the contraction launches with HIP events -> own roofline
                 block; acc: this mode's accuracy against the oracle on the cpu_baseline samples."""
                 def s_step():
-                    sc = pipe_.score(frames_, offsets_)
+                    # stream_of_batches: the next batch (synthetic: the same pinned tensor) is announced to the call, which
+                    # uploads its first pass under its own last pass - steady state of a stream of host-resident batches
+                    sc = pipe_.score(frames_, offsets_, next_batch=(frames_, offsets_) if stream_of_batches else None)
                     return pipe_.select(sc, offsets_)
                 dt, sel, prof_ = timed_steps(s_step, steps_, 1, torch.cuda.synchronize, 1 if roof else None)
                 n = offsets_[-1]
@@ -693,8 +695,9 @@ def main():
             torch.cuda.synchronize()
             run_sub("h2d_inclusive", pipe, host_frames, offsets, base + args.dtype + " headline step with the uint8 "
                     "frames in PINNED HOST memory: every pass pulled over PCIe by a 16-workgroup kernel on a copy "
-                    "stream into one of two staging buffers while the previous pass computes (a short lead pass first)",
-                    steps_=3)
+                    "stream into one of two staging buffers while the previous pass computes; a stream of batches: the next "
+                    "batch's first pass is pulled under this batch's last pass (the warm-up step pays the one exposed upload)",
+                    steps_=3, stream_of_batches=True)
             subs["h2d_inclusive"]["fraction_of_resident"] = round(subs["h2d_inclusive"]["value"] * t_max / (frames_all * args.steps), 4)
             del host_frames
             # exact fp32 MFMA

@@ -189,6 +189,14 @@ def test_pinned_host_frames_are_uploaded_pass_by_pass(dev):
     g2 = pipe.embed(p2, offsets)
     g3 = pipe.embed(p1, offsets)
     assert torch.equal(g1, want) and torch.equal(g2, want2) and torch.equal(g3, want)
+    # a stream of batches: the call is told the NEXT batch and uploads its first pass under its own last pass; the next call
+    # finds it staged (no lead pass), a call with ANOTHER batch than announced uploads afresh - same features every time
+    g4 = pipe.embed(p1, offsets, next_batch=(p2, offsets))
+    assert "prefetched" in pipe._stager_cache
+    g5 = pipe.embed(p2, offsets, next_batch=(p1, offsets))      # consumes the staged pass, announces p1
+    g6 = pipe.embed(p2, offsets)                                  # not the announced batch: staged pass discarded
+    assert "prefetched" not in pipe._stager_cache
+    assert torch.equal(g4, want) and torch.equal(g5, want2) and torch.equal(g6, want2)
     with pytest.raises(ValueError, match="pinned"):
         pipe.embed(host, offsets)
 

@@ -37,12 +37,13 @@ def main():
     torch.cuda.synchronize()
     pipe = FrameScoringPipeline(ext, scorer, use_inception=False, chunk_frames=12288, frames_per_group=1)
 
-    def timed(src):
-        pipe.score(src, offsets)
+    def timed(src, stream=False):
+        nb = (src, offsets) if stream else None
+        pipe.score(src, offsets, next_batch=nb)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            s = pipe.score(src, offsets)
+            s = pipe.score(src, offsets, next_batch=nb)
         torch.cuda.synchronize()
         return total * args.steps / (time.perf_counter() - t0), s
 
@@ -67,6 +68,9 @@ def main():
             dt = time.perf_counter() - t0
             print(f"pull kernel, {pull} workgroups: one 12288-frame upload alone {dt * 1e3:.1f} ms = "
                   f"{12288 * 150528 / dt / 1e9:.1f} GB/s; equal: {torch.equal(buf, frames[:12288])}")
+        rate, s_host = timed(host, stream=True)
+        print(f"pinned host, {'pull kernel x' + str(pull) if pull else 'copy engine'}, stream of batches (next first pass prefetched): "
+              f"{rate:9.1f} frames/s = {rate / base:.4f} of resident; scores identical: {torch.equal(s_host, s_dev)}")
         for lead in [int(v) for v in args.leads.split(",")]:
             pipe.host_lead_frames = lead
             rate, s_host = timed(host)
