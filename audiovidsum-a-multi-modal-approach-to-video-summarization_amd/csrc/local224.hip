@@ -55,12 +55,23 @@ __global__ __launch_bounds__(256, 2) void igemm_h2_local224_kernel(IgemmParams p
   int tm = wg / p.tiles_n;
   if (p.cluster > 1) {
     // clustered form: the tiles of a group wait for each other, so they take CONSECUTIVE block ids (dispatched together);
-    // a unit = cluster x tiles_n blocks, member j = l % cluster of column tile l / cluster: a frame's column tiles then
-    // sit on the XCDs j, j + cluster, ... (round-robin placement: speed only, never correctness)
-    const unsigned unit = (unsigned)p.cluster * (unsigned)p.tiles_n;
-    const unsigned u = orig / unit, l = orig - u * unit;
-    tn = (int)(l / (unsigned)p.cluster);
-    tm = (int)(u * (unsigned)p.cluster + l % (unsigned)p.cluster);
+    // XCD placement (round-robin over block ids: speed only, never correctness) keeps a row tile's column tiles together
+    const unsigned c = (unsigned)p.cluster, tnn = (unsigned)p.tiles_n;
+    const unsigned tiles_m = nwg / tnn;
+    const unsigned full = (8u % c == 0u) ? (tiles_m / 8u) * 8u : 0u;   // row tiles covered by whole super-units of 8
+    if (orig < full * tnn) {
+      // super-unit = 8 row tiles x all column tiles, block = column tile * 8 + row tile: a row tile's column tiles all sit on
+      // XCD (row tile % 8) and share its L2 copy of the A rows; the tiles of a cluster (c | 8) are c consecutive blocks
+      const unsigned su = orig / (8u * tnn), l = orig - su * (8u * tnn);
+      tn = (int)(l >> 3);
+      tm = (int)(su * 8u + (l & 7u));
+    } else {
+      // (cluster sizes that do not divide 8, and the last row tiles of a launch) unit = cluster x column tiles
+      const unsigned o2 = orig - full * tnn, unit = c * tnn;
+      const unsigned u = o2 / unit, l = o2 - u * unit;
+      tn = (int)(l / c);
+      tm = (int)(full + u * c + l % c);
+    }
   }
   const int m0 = tm * p.tile_rows;
   const int n0 = tn * L_BN;
