@@ -316,29 +316,41 @@ __global__ __launch_bounds__(256, 2) void igemm_h2_local224_kernel(IgemmParams p
                        __HIP_MEMORY_SCOPE_AGENT);
     const float nt = (float)p.tile_rows;
     float n = 0.f, mu = 0.f, m2 = 0.f;
-    for (int j = 0; j < p.cluster; ++j) {
-      float mj = mean, qj = s2;
-      if (j != cj) {
-        const unsigned long long* src = p.xchg + (((long long)(t0 + j) * p.tiles_n + tn) * 4 + wave) * 64 + lane;
-        unsigned long long g = 0;
-        bool ok = false;
-        for (int spin = 0; spin < (1 << 20); ++spin) {
-          g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = (unsigned)(g >> 32) == p.epoch;
-          if (__builtin_amdgcn_read_exec() == __builtin_amdgcn_ballot_w64(ok)) break;
-          __builtin_amdgcn_s_sleep(8);
-        }
-        if (__builtin_amdgcn_read_exec() != __builtin_amdgcn_ballot_w64(ok) && lane == 0) atomicAdd(p.xerr, 1u);
-        const float v = __uint_as_float((unsigned)g);
-        const float o = __shfl_xor(v, 32, 64);
-        mj = lh ? o : v;
-        qj = lh ? v : o;
+    const unsigned long long* const gbase = p.xchg + (((long long)t0 * p.tiles_n + tn) * 4 + wave) * 64 + lane;
+    const long long gstride = (long long)p.tiles_n * 4 * 64;      // granules between consecutive row tiles
+    for (int j0 = 0; j0 < p.cluster; j0 += 4) {
+      // four partners' granules in flight at once (one latency for the usual cluster of four), then each is verified and -
+      // only if its tag is not this launch's yet - polled on
+      unsigned long long g[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = j0 + u < p.cluster ? j0 + u : cj;           // (past the cluster / own tile: a valid address, unused)
+        g[u] = __hip_atomic_load(gbase + j * gstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      // Chan's update in tile order: the same operands in the same order on every tile of the group -> the same bits
-      const float tot = n + nt, delta = mj - mu;
-      mu += delta * (nt / tot);
-      m2 += qj + delta * delta * (n * nt / tot);
-      n = tot;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = j0 + u;
+        if (j >= p.cluster) break;
+        float mj = mean, qj = s2;
+        if (j != cj) {
+          bool ok = (unsigned)(g[u] >> 32) == p.epoch;
+          for (int spin = 0; spin < (1 << 20) && __builtin_amdgcn_read_exec() != __builtin_amdgcn_ballot_w64(ok); ++spin) {
+            __builtin_amdgcn_s_sleep(8);
+            g[u] = __hip_atomic_load(gbase + j * gstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = (unsigned)(g[u] >> 32) == p.epoch;
+          }
+          if (__builtin_amdgcn_read_exec() != __builtin_amdgcn_ballot_w64(ok) && lane == 0) atomicAdd(p.xerr, 1u);
+          const float v = __uint_as_float((unsigned)g[u]);
+          const float o = __shfl_xor(v, 32, 64);
+          mj = lh ? o : v;
+          qj = lh ? v : o;
+        }
+        // Chan's update in tile order: the same operands in the same order on every tile of the group -> the same bits
+        const float tot = n + nt, delta = mj - mu;
+        mu += delta * (nt / tot);
+        m2 += qj + delta * delta * (n * nt / tot);
+        n = tot;
+      }
     }
     g_mean = mu;
     g_var = m2 / n;
