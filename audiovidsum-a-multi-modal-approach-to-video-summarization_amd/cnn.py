@@ -236,13 +236,18 @@ class ResNet50Runner:
                 rows = gsz * ho * wo
                 if rows <= 256:
                     plan.append(ops.conv_bnlocal_tile_rows(dcode, *geom, *xs, wrs, cout, rows) is not None)
-                elif (self.h2 and self.bn_cluster and gsz >= 2 and 192 < ho * wo <= 224
-                      and ops.conv_bncluster_ok(dcode, *geom, *xs, wrs, cout, rows, gsz)):
-                    # a group of gsz frames whose maps fill one 224-row tile each (layer 3 with the reference's 4-frame
-                    # micro-batches): the clustered tile-local form - the tiles of a group exchange their statistics
-                    plan.append(gsz)
                 else:
-                    plan.append(False)
+                    # a group larger than a tile: the clustered tile-local form where the map splits into k tiles of 193..224
+                    # rows (14 x 14: k = 1, layer 3 with the reference's 4-frame micro-batches; 28 x 28: k = 4) and the group
+                    # into gsz * k <= 16 of them - the tiles of a group exchange their statistics
+                    cl = False
+                    if self.h2 and self.bn_cluster:
+                        for k in (1, 2, 4, 8, 16):
+                            if (ho * wo) % k == 0 and 192 < (ho * wo) // k <= 224 and 2 <= gsz * k <= 16:
+                                if ops.conv_bncluster_ok(dcode, *geom, *xs, wrs, cout, rows, gsz * k):
+                                    cl = gsz * k
+                                break
+                    plan.append(cl)
             if len(self._plans) > 64:
                 self._plans.clear()
             self._plans[key] = plan

@@ -286,6 +286,8 @@ _CLUSTER_CASES = [   # frames, hw (in), cin, cout, k, stride, frames per group, 
     (6, 14, 256, 256, 1, 1, 2, True, True, 40.0),     # two-frame groups (a video's tail), mean >> spread
     (9, 14, 128, 128, 3, 1, 3, False, True, 0.3),     # three-frame groups
     (70, 14, 256, 256, 1, 1, 7, True, True, 0.3),     # more tiles than one round of the chip's slots would order trivially
+    (8, 28, 512, 256, 1, 1, 16, False, True, 0.3),    # 28 x 28 maps: a frame = 4 tiles of 196 rows, 4-frame groups = clusters of 16
+    (6, 28, 128, 128, 3, 1, 4, False, True, 0.3),     # ... one-frame groups of 4 tiles, 3x3 taps across the tile borders
 ]
 
 
@@ -302,7 +304,10 @@ def test_conv_bncluster_f16x2(dev, cfg):
     xp, wp, xv, wv = _conv_operands(frames, hw, hw, cin, cout, k, k, sum(cfg[:6]), offset)
     raw = _conv_ref(xv, wv, s, pad)
     ho = raw.shape[1]
-    rpg = gf * ho * ho
+    # gf = tiles per group: 14 x 14 maps are one tile each (gf frames per group), 28 x 28 maps four tiles of 196 rows
+    tiles_per_frame = (ho * ho) // 196
+    rpg = gf * 196
+    assert rpg % (ho * ho) == 0 or (ho * ho) % rpg == 0
     raw = raw.reshape(-1, cout)
     g = torch.Generator().manual_seed(2)
     gamma, beta = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
@@ -311,8 +316,10 @@ def test_conv_bncluster_f16x2(dev, cfg):
     geom = (frames, hw, hw, cin, k, k, s, s, pad, pad, ho, ho, cout)
     xs = (hw * hw * cin, hw * cin, cin)
     code = ops.dtype_code(torch.float32, "f16x2")
+    assert tiles_per_frame in (1, 4)
     assert ops.conv_bncluster_ok(code, *geom, *xs, wp.shape[1], cout, rpg, gf)
-    assert not ops.conv_bncluster_ok(code, *geom, *xs, wp.shape[1], cout, rpg, gf + 1)      # not whole tiles
+    if gf < 16:
+        assert not ops.conv_bncluster_ok(code, *geom, *xs, wp.shape[1], cout, rpg, gf + 1)      # not whole tiles
     xd, wd = xp.to(dev), wp.to(dev)
     amp = max(1.0, (1.0 / torch.sqrt(raw.reshape(-1, rpg, cout).var(1, unbiased=False) + 1e-5)).max().item() *
               raw.abs().max().item())
@@ -331,7 +338,7 @@ def test_conv_bncluster_f16x2(dev, cfg):
     y2 = torch.empty((frames, ho, ho, cout), device=dev)
     aff = ops.conv2d_raw(code, *geom, xd, *xs, wd, wd.stride(0), y2, cout, bnstats=(rpg, gamma.to(dev), beta.to(dev), 1e-5))
     assert aff is not None
-    rows = torch.arange(0, frames // gf + 1, dtype=torch.int64, device=dev) * rpg
+    rows = torch.arange(0, raw.shape[0] // rpg + 1, dtype=torch.int64, device=dev) * rpg
     y2d = y2.view(-1, cout)
     ops.bn_apply(y2d, aff[0], aff[1], rows, rpg, resp.to(dev) if with_res else None, ops.ACT_RELU if relu else ops.ACT_NONE,
                  y2d, code=code)
