@@ -242,7 +242,13 @@ class ResNet50Runner:
                     # into gsz * k <= 16 of them - the tiles of a group exchange their statistics
                     cl = False
                     if self.h2 and self.bn_cluster:
+                        cin_l, kh_l = geom[3], geom[4]
                         for k in (1, 2, 4, 8, 16):
+                            # (maps of several tiles: only the wide 1x1 layer that would otherwise take convolution +
+                            #  statistics + an apply pass - layer 3's first conv1, 512 -> 256 at 28 x 28; measured: layer 2's
+                            #  narrow layers are no faster clustered than on their Gram / nine-tap / 3-byte forms)
+                            if k > 1 and not (kh_l == 1 and cin_l >= 512 and cout >= 256):
+                                continue
                             if (ho * wo) % k == 0 and 192 < (ho * wo) // k <= 224 and 2 <= gsz * k <= 16:
                                 if ops.conv_bncluster_ok(dcode, *geom, *xs, wrs, cout, rows, gsz * k):
                                     cl = gsz * k
