@@ -235,14 +235,6 @@ __global__ __launch_bounds__(THREADS, 2) void stem_h2_kernel(StemH2Params p) {
       if constexpr (POOLING) {
         if (s < 9) pool_tap(tile - 1, s);
         if (s == 9) pool_finish(tile - 1);
-        // the step's instruction mix, in issue order: 4 fragment reads + the tap's 2 reads, then per matrix instruction a
-        // slice of the vector work (an MFMA holds the vector issue for 8 of its 32 cycles: ~6 plain VALU fit beside it)
-        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);   // DS reads
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
-          __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);   // VALU
-        }
       }
     }
     if (tile == 0 && wave == PIVOT_ROW / 64 && lh == ((PIVOT_ROW % 32) >> 2 & 1)) {
