@@ -65,7 +65,8 @@ def timed_conv_bn(self, geom, xs, x, wt, bnp, groups, residual=None, **kw):
     flops = 2.0 * rows * kk * cout
     in_elems = n * h * h * cin if sh == 1 or kh > 1 else rows * cin
     byts = (in_elems + rows * cout * (2 if residual is not None else 1)) * es
-    form = ("local" if kw.get("local") else "gram/2pass" if (kw.get("in_affine") is not None or (
+    loc = kw.get("local")
+    form = ("cluster" if (loc and loc is not True and int(loc) > 1) else "local" if loc else "gram/2pass" if (kw.get("in_affine") is not None or (
         kh == 1 and cout >= 2 * cin and sh == 1)) else "split+defer" if kw.get("defer") else "split")
     records.append((f"{h}x{h} {kh}x{kh}/{sh} {cin}->{cout}" + (" +res" if residual is not None else ""), form,
                     flops, byts, e0, e1))
@@ -140,6 +141,21 @@ cnn.ResNet50Runner._conv_bn = timed_conv_bn_outer
 ops.bn_gram_affine_h2 = timed_h2(ops.bn_gram_affine_h2, "gram")
 ops.conv2d_affine = timed_h2(ops.conv2d_affine, "affine")
 ops.stem_conv_bn_pool = timed_stem
+orig_stem_h2 = ops.stem_conv_pool_h2
+
+
+def timed_stem_h2(frames_u8, *a, **kw):
+    e0, e1 = ev(), ev()
+    e0.record()
+    out = orig_stem_h2(frames_u8, *a, **kw)
+    e1.record()
+    n = frames_u8.shape[0]
+    records.append(("stem 7x7/2 3->64 + pool", "fused h2", 2.0 * n * 112 * 112 * 147 * 64,
+                    n * (224 * 224 * 3 + 56 * 56 * 64 * es), e0, e1))
+    return out
+
+
+ops.stem_conv_pool_h2 = timed_stem_h2
 ops.bn_gram_affine = timed_op(ops.bn_gram_affine, "gram")
 ops.conv1x1_affine = timed_op(ops.conv1x1_affine, "affine")
 for _ in range(2):
