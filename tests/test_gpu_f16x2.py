@@ -628,3 +628,41 @@ def test_fused_stem_f16x2(dev, n, fpg, kind):
     fu = ops.f16x2_unpack(yu)
     bar = (2e-5 if kind == "random" else 5e-4) * max(1.0, fu.abs().max().item())
     assert (fin - fu).abs().max().item() <= bar
+
+
+@pytest.mark.parametrize("n,h,cin,couts,pool_cout", [(3, 17, 768, (192, 160, 160), 192), (2, 35, 192, (64, 48, 64), 32),
+                                                     (2, 8, 1280, (320, 384, 448), 0)])
+def test_conv_split_two_destinations(dev, n, h, cin, couts, pool_cout):
+    """avs_conv2d_nhwc_split: several 1x1 convolutions that read one input as ONE contraction over their stacked filters - the
+    first head into its channel slice of a wider buffer, the others (and, with relu_cols, a head without bias / ReLU) into a
+    temporary - bit for bit the separate avs_conv2d_nhwc launches (an Inception block's heads, features/extractors.py:26,73-90)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(n + h + cin)
+    x = emu_pack(torch.randn(n, h, h, cin, generator=g)).to(dev)
+    ws = [emu_pack(torch.randn(c, cin, generator=g) / cin ** 0.5).to(dev) for c in couts + ((pool_cout,) if pool_cout else ())]
+    bs = [torch.randn(c, generator=g).to(dev) for c in couts]
+    cat = torch.full((n, h, h, couts[0] + 40), float("nan"), device=dev)        # the first head's slice of a concatenation
+    ref_tmp = []
+    ops.conv2d(x, ws[0], 1, 1, 1, 0, cat[..., :couts[0]], bs[0], ops.ACT_RELU, split="f16x2")
+    ref_first = cat[..., :couts[0]].clone()
+    for w_, b_ in zip(ws[1:len(couts)], bs[1:]):
+        y = torch.empty((n, h, h, w_.shape[0]), device=dev)
+        ops.conv2d(x, w_, 1, 1, 1, 0, y, b_, ops.ACT_RELU, split="f16x2")
+        ref_tmp.append(y)
+    if pool_cout:
+        y = torch.empty((n, h, h, pool_cout), device=dev)
+        ops.conv2d(x, ws[-1], 1, 1, 1, 0, y, None, ops.ACT_NONE, split="f16x2")   # raw: bias + ReLU follow a pooling
+        ref_tmp.append(y)
+    wst = torch.cat(ws).contiguous()                                            # packed rows stack as they are
+    bst = torch.cat(bs + ([torch.zeros(pool_cout, device=dev)] if pool_cout else [])).contiguous()
+    cat2 = torch.full_like(cat, float("nan"))
+    tmp = torch.full((n, h, h, sum(couts[1:]) + pool_cout), float("nan"), device=dev)
+    ops.conv2d_split(x, wst, cat2[..., :couts[0]], couts[0], tmp, bst, ops.ACT_RELU,
+                     relu_cols=(sum(couts) if pool_cout else 0))
+    assert torch.equal(cat2[..., :couts[0]].contiguous().view(torch.int32), ref_first.view(torch.int32))
+    assert torch.isnan(cat2[..., couts[0]:]).all()                              # nothing beyond the slice was touched
+    o = 0
+    for y in ref_tmp:
+        c = y.shape[3]
+        assert torch.equal(tmp[..., o:o + c].contiguous().view(torch.int32), y.view(torch.int32)), o
+        o += c
