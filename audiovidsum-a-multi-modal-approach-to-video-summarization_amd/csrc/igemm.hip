@@ -1825,7 +1825,13 @@ static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream
                   (p.x_px_stride * es) % (ce * es) == 0 && (p.ldb * es) % (ce * es) == 0 && (p.sA * es) % (ce * es) == 0 &&
                   (p.sB * es) % (ce * es) == 0,
               AVS_E_ALIGN, "%s: strides must be multiples of %d bytes", who, ce * es);
-  AVS_REQUIRE(p.ldc >= p.N, AVS_E_SHAPE, "%s: output row stride %lld < N=%d", who, p.ldc, p.N);
+  if (p.nsplit > 0) {                                             // two destinations: each row stride covers its own columns
+    AVS_REQUIRE(p.ldc >= p.nsplit && p.ldc2 >= p.N - p.nsplit, AVS_E_SHAPE,
+                "%s: output row strides %lld / %lld < the %d / %d columns of the two destinations", who, p.ldc, p.ldc2,
+                p.nsplit, p.N - p.nsplit);
+  } else {
+    AVS_REQUIRE(p.ldc >= p.N, AVS_E_SHAPE, "%s: output row stride %lld < N=%d", who, p.ldc, p.N);
+  }
   AVS_REQUIRE(batch <= 65535, AVS_E_SHAPE, "%s: batch %d > 65535", who, batch);
 
   const bool narrow = p.N <= 64 || dtype == AVS_F32_ACC64;

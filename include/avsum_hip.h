@@ -150,7 +150,8 @@ int avs_conv2d_nhwc(const avs_conv_desc* desc, const void* d_x, const void* d_w,
  * [n_split, cout) to d_y2 (row stride y2_px_stride, column c at c - n_split).  Convolutions that read the same input - an
  * Inception block's 1x1 heads (features/extractors.py:26,73-90) - run as ONE contraction over their stacked filters: the
  * input is fetched once, and the head that belongs to the block's concatenated output still lands in its channel slice.
- * n_split, both strides in multiples of 8 slots.  relu_cols > 0 (a multiple of 8): with desc->act = ReLU only the columns
+ * n_split, both strides in multiples of 8 slots; each row stride need only cover its OWN columns (y_px_stride >= n_split,
+ * y2_px_stride >= cout - n_split).  relu_cols > 0 (a multiple of 8): with desc->act = ReLU only the columns
  * below it are rectified - a stacked head whose bias + ReLU follow a pooling of its output (Inception's branch_pool, run as
  * convolution -> average pooling -> bias -> ReLU) keeps its raw values.                                                  */
 int avs_conv2d_nhwc_split(const avs_conv_desc* desc, const void* d_x, const void* d_w, const float* d_bias, void* d_y,
