@@ -149,9 +149,14 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
   constexpr int WCOLS = BN / WC;     // output columns per wave
   constexpr int A_ROWS = 64 * WR;
   constexpr int NA = A_ROWS / RPP;   // A rows staged per thread
-  constexpr int NB = BN / RPP;       // B rows staged per thread
+  constexpr int NB = (BN + RPP - 1) / RPP;   // B rows staged per thread (BN = 96: two passes, the second one half empty)
   constexpr int NT = WCOLS / 32;     // 32-wide column tiles per wave
-  constexpr int BUF = (A_ROWS + BN) * CPRR;  // uint4 slots per buffer
+  constexpr int BUF = (A_ROWS + NB * RPP) * CPRR;  // uint4 slots per buffer
+  // BN = 96: the column tile of the bias + ReLU convolutions whose cout is 96, 160, 192, 288 ... (Inception-v3): a 128-wide
+  // tile spends 25 - 37 % of such a layer's matrix work on columns that do not exist
+  static_assert(BN == 64 || BN == 128 || (BN == 96 && SPLIT == 2 && WR == 4 && PIPE && ROWB == 64 && EPI == EPI_BRELU),
+                "96-column tiles: the AVS_F16X2 bias + ReLU form on the pipelined 256-row tiles");
+  static_assert(WCOLS % 32 == 0, "a wave's columns are whole 32-wide MFMA tiles");
   constexpr int CT_PITCH = BN * 2 + 16;      // bf16 epilogue staging tile: row pitch in bytes (16 bytes of padding)
   constexpr int CT_SLOTS = ES == 2 ? (A_ROWS * CT_PITCH) / 16 : 0;
   constexpr int NBUF = PIPE ? 3 : 2;
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     const int n = n0 + rb + RPP * i;
-    b_base[i] = n < p.N ? w + (long long)n * p.ldb * ES : nullptr;
+    b_base[i] = (n < p.N && rb + RPP * i < BN) ? w + (long long)n * p.ldb * ES : nullptr;
   }
 
   if (AVS_DEBUG_BIT(p, 2)) {
@@ -898,8 +903,11 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
     int used = A_ROWS;                    // EPI_BNLOCAL: rows of this tile that exist
     if constexpr (EPI == EPI_BNLOCAL) used = (m0 + p.tile_rows <= p.M ? p.tile_rows : p.M - m0);
     constexpr int G = WCOLS / 8;            // runs of 8 columns per staged row
-    constexpr int NU = (32 * G) / 64;       // runs per lane and half
     constexpr int RSTEP = 64 / G;           // staged rows between a lane's consecutive runs
+    constexpr int NU = (32 + RSTEP - 1) / RSTEP;   // runs per lane and half
+    // G = 12 (96-column waves): 5 rows x 12 runs = 60 lanes work, the last round covers rows 30, 31 only
+    constexpr bool RAGGED = 64 % G != 0;
+    static_assert(!RAGGED || EPI == EPI_BRELU, "ragged run maps: the bias + ReLU form only (no residual rows)");
     constexpr bool NORM = EPI == EPI_BNLOCAL || EPI == EPI_AFFINE || EPI == EPI_BRELU;
     float* const wreg = fl + wave * (32 * H2_P);
     const bool relu = NORM && (EPI == EPI_BRELU || p.act == AVS_ACT_RELU);
@@ -917,7 +925,7 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
     const int rl0 = lane / G, grp = lane % G;
     const int col8 = n0 + wc * WCOLS + grp * 8;
     const int row_lim = (EPI == EPI_BNLOCAL ? m0 + used : p.M);   // rows at or past this one do not exist
-    const bool col_ok = col8 < p.N;
+    const bool col_ok = col8 < p.N && (!RAGGED || lane < RSTEP * G);
     // avs_conv2d_nhwc_split: columns >= relu_cols (> 0) skip the ReLU (a stacked head whose activation follows a pooling)
     const bool relu_l = relu && (p.relu_cols <= 0 || col8 < p.relu_cols);
     // AVS_F16P8 (output / residual of the given-affine form): byte offset of this lane's run of 8 columns inside a row -
@@ -1155,6 +1163,9 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
         const float4 f1 = *reinterpret_cast<const float4*>(src + 4);
         const long long row = row0 + it * RSTEP;
         if (!(col_ok && row < row_lim)) continue;
+        if constexpr (RAGGED) {
+          if (rl0 + it * RSTEP >= 32) continue;   // (the last round of a ragged map: past the staged half)
+        }
         float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
         if constexpr (NORM) {
           if (p.residual) {
@@ -1719,10 +1730,9 @@ static bool igemm_dispatch_epi4(int epi, dim3 grid, hipStream_t stream, const Ig
 }
 
 
-template <int ES, int BN, bool ACC64, bool SP, int ROWB, bool PIPE, int WR>
-static bool igemm_dispatch_epi3(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p) {
-  constexpr int BKE = ROWB / ES;
-  // the buffer window: a tile's rows (at most 256, spread over whole images) plus the tap walk must stay below 2 GiB
+// FASTK (the scalar tap walk over buffer_load ... lds): cin a whole number of reduction steps of bke elements, at most 32
+// taps, and the buffer window - a tile's rows (at most 256, spread over whole images) plus the tap walk - below 2 GiB
+static bool igemm_fastk_ok(const IgemmParams& p, int es, int bke, int bn) {
   const long long rows = 256;
   long long extent;
   if (p.lin_stride >= 0)
@@ -1730,12 +1740,32 @@ static bool igemm_dispatch_epi3(int epi, dim3 grid, hipStream_t stream, const Ig
   else
     extent = (rows / p.HoWo + 2) * p.x_img_stride + (long long)(p.K / (p.cin * p.KW) + p.ph) * p.x_row_stride +
              (long long)(p.KW + p.pw) * p.x_px_stride + p.cin;
-  const bool window_ok = extent * ES < (1ll << 31) && (long long)BN * p.ldb * ES + (long long)p.K * ES < (1ll << 31) &&
+  const bool window_ok = extent * es < (1ll << 31) && (long long)bn * p.ldb * es + (long long)p.K * es < (1ll << 31) &&
                          p.x_img_stride >= 0 && p.x_row_stride >= 0 && p.x_px_stride >= 0;
-  if (!(p.variant & AVS_STAGING_GENERIC) && window_ok && p.cin % BKE == 0 && p.K % BKE == 0 && p.K / p.cin <= 32 && p.K % p.cin == 0)
+  return !(p.variant & AVS_STAGING_GENERIC) && window_ok && p.cin % bke == 0 && p.K % bke == 0 && p.K / p.cin <= 32 &&
+         p.K % p.cin == 0;
+}
+
+template <int ES, int BN, bool ACC64, bool SP, int ROWB, bool PIPE, int WR>
+static bool igemm_dispatch_epi3(int epi, dim3 grid, hipStream_t stream, const IgemmParams& p) {
+  if (igemm_fastk_ok(p, ES, ROWB / ES, BN))
     return igemm_dispatch_epi4<ES, BN, ACC64, SP, ROWB, PIPE, WR, true>(epi, grid, stream, p);
   else
     return igemm_dispatch_epi4<ES, BN, ACC64, SP, ROWB, PIPE, WR, false>(epi, grid, stream, p);
+}
+
+// AVS_F16X2 bias + ReLU on 256 x 96 tiles (igemm_launch's rule: cout = 96, 160, 192, 288 ... with enough rows)
+static bool igemm_dispatch_brelu96(bool spatial, dim3 grid, hipStream_t stream, const IgemmParams& p) {
+#ifdef AVS_STUDY
+  const_cast<IgemmParams&>(p).debug = g_debug_flags;
+#endif
+  const bool fk = igemm_fastk_ok(p, 4, 16, 96);
+  if (spatial) {
+    if (fk) AVS_LAUNCH_RET((igemm_kernel<4, 96, false, true, 64, EPI_BRELU, true, 4, true, 2>));
+    AVS_LAUNCH_RET((igemm_kernel<4, 96, false, true, 64, EPI_BRELU, true, 4, false, 2>));
+  }
+  if (fk) AVS_LAUNCH_RET((igemm_kernel<4, 96, false, false, 64, EPI_BRELU, true, 4, true, 2>));
+  AVS_LAUNCH_RET((igemm_kernel<4, 96, false, false, 64, EPI_BRELU, true, 4, false, 2>));
 }
 
 template <int ES, int BN, bool ACC64, bool SP, int ROWB, bool PIPE>
@@ -1835,8 +1865,23 @@ static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream
   AVS_REQUIRE(batch <= 65535, AVS_E_SHAPE, "%s: batch %d > 65535", who, batch);
 
   const bool narrow = p.N <= 64 || dtype == AVS_F32_ACC64;
-  const int bn = narrow ? 64 : 128;
+  int bn = narrow ? 64 : 128;
   p.tiles_n = (p.N + bn - 1) / bn;
+  // AVS_F16X2 bias + ReLU (Inception-v3's folded-BatchNorm convolutions): cout = 96, 160, 192, 288 ... leave a 128-wide
+  // column tile 25 - 37 % empty; 96-wide tiles on the 256-row form when they save at least 15 % of the padded width and the
+  // 256-row rule below holds for them (a tuning choice: the outputs do not depend on it; AVS_TILE_128 keeps the 128-row tiles)
+  bool wide96 = false;
+  if (dtype == AVS_F16X2 && !narrow && p.alpha == 1.0f && p.bias_mode == AVS_BIAS_COL && p.act == AVS_ACT_RELU && !p.stat_part &&
+      !p.tile_rows && !p.affine && batch == 1 && g_pipe3 && (long long)p.K * 4 >= g_tall_min_k_bytes &&
+      ((p.variant & 3) == AVS_TILE_AUTO || (p.variant & 3) == AVS_TILE_256)) {
+    const int t96 = (p.N + 95) / 96;
+    const long long tall_tiles96 = ((long long)p.M + 255) / 256 * t96;
+    if (t96 * 96 * 100 <= p.tiles_n * 128 * 85 && ((p.variant & 3) == AVS_TILE_256 || tall_tiles96 >= g_tall_min_tiles)) {
+      wide96 = true;
+      bn = 96;
+      p.tiles_n = t96;
+    }
+  }
   // 256-row tiles (WR = 4): bf16, the compile-time epilogue forms, a reduction of at least three 64-byte steps (the
   // variants are built on the 3-buffer pipeline), and enough rows that the grid still fills the chip several times
   p.tall = 0;
@@ -1853,6 +1898,7 @@ static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream
     if (can && (tile_mode == AVS_TILE_256 || (tile_mode == AVS_TILE_AUTO && tall_tiles >= g_tall_min_tiles &&
                                               (narrow || (long long)p.K * es >= g_tall_min_k_bytes))))
       p.tall = 1;
+    if (wide96) p.tall = 1;
   }
   // EPI_BNLOCAL (validated by bnlocal_plan): 256-row tiles at a pitch of tile_rows; EPI_AFFINE: 256-row tiles, or 128-row
   // ones for wide outputs when the caller asks (AVS_TILE_128) or the reduction is short
@@ -1912,7 +1958,9 @@ static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream
     }
   }
   bool launched;
-  if (dtype == AVS_BF16) {
+  if (wide96) {
+    launched = igemm_dispatch_brelu96(spatial, grid, stream, p);
+  } else if (dtype == AVS_BF16) {
     launched = narrow ? igemm_dispatch<2, 64, false>(spatial, grid, stream, p) : igemm_dispatch<2, 128, false>(spatial, grid, stream, p);
   } else if (dtype == AVS_F32_ACC64) {
     launched = igemm_dispatch<4, 64, true>(spatial, grid, stream, p);

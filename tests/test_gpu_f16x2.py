@@ -666,3 +666,40 @@ def test_conv_split_two_destinations(dev, n, h, cin, couts, pool_cout):
         c = y.shape[3]
         assert torch.equal(tmp[..., o:o + c].contiguous().view(torch.int32), y.view(torch.int32)), o
         o += c
+
+
+@pytest.mark.parametrize("cfg", [
+    (3, 17, 17, 128, 192, 1, 7, 1, (0, 3)), (2, 17, 17, 160, 160, 7, 1, 1, (3, 0)), (5, 35, 35, 64, 96, 3, 3, 1, 1),
+    (2, 35, 35, 96, 96, 3, 3, 2, 0), (2, 19, 19, 80, 192, 3, 3, 1, 0), (2, 9, 9, 768, 288, 1, 1, 1, 0),
+    (1, 13, 13, 24, 104, 3, 3, 1, 1),
+])
+def test_conv_bias_relu_96_column_tiles(dev, cfg):
+    """The bias + ReLU convolutions whose cout leaves a 128-wide column tile mostly empty (96, 160, 192, 288: most of
+    Inception-v3, features/extractors.py:26,83) run on 256 x 96 tiles where the rows allow it (forced here per call with
+    AVS_TILE_256; AVS_TILE_128 keeps the 128 x 128 tiles): the same products in the same order - bit for bit the same
+    outputs, both weight layouts, ragged last tiles, a channel-slice destination - and the double-precision reference."""
+    ops = _ops()
+    n, h, w, cin, cout, kh, kw, stride, pad = cfg
+    xp, wp, xv, wv = _conv_operands(n, h, w, cin, cout, kh, kw, h * 7 + cout)
+    g = torch.Generator().manual_seed(cout)
+    bias = torch.randn(cout, generator=g)
+    ref = torch.relu(_conv_ref(xv, wv, stride, pad) + bias.double())
+    ho, wo = ref.shape[1], ref.shape[2]
+    scale = max(1.0, ref.abs().max().item())
+    outs = []
+    for variant in (1, 2):                       # AVS_TILE_128, AVS_TILE_256
+        for layout in (0, 1):
+            if layout == 1 and (kh * kw * cin) % 16:
+                continue
+            wd = wp.to(dev)
+            wsel = ops.weights_kstep32(wd) if layout else wd
+            buf = torch.full((n, ho, wo, cout + 24), float("nan"), device=dev)
+            out = buf[..., 8:8 + cout]
+            ops.conv2d(xp.to(dev), wsel, kh, kw, stride, pad, out, bias.to(dev), ops.ACT_RELU, split="f16x2", w_layout=layout,
+                       variant=variant)
+            assert torch.isnan(buf[..., :8]).all() and torch.isnan(buf[..., 8 + cout:]).all()
+            outs.append(out.contiguous())
+    got = ops.f16x2_unpack(outs[0]).cpu().double()
+    assert (got - ref).abs().max().item() <= TOL * scale
+    for o in outs[1:]:
+        assert torch.equal(o.view(torch.int32), outs[0].view(torch.int32))
