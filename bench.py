@@ -46,7 +46,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARC
 MFMA_F32_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
 PMC_TRAFFIC_FILES = {"bf16": ("r02_pmc_traffic.json", "r01_e_pmc_traffic.json"),   # newest first, under profiles/
-                     "f16x2": ("r04_f_pmc_traffic.json", "r04_e_pmc_traffic.json", "r03_e_pmc_traffic.json", "r03_c_pmc_traffic.json", "r03_b_pmc_traffic.json", "r03_a_pmc_traffic.json")}
+                     "f16x2": ("r04_g_pmc_traffic.json", "r04_f_pmc_traffic.json", "r04_e_pmc_traffic.json", "r03_e_pmc_traffic.json", "r03_c_pmc_traffic.json", "r03_b_pmc_traffic.json", "r03_a_pmc_traffic.json")}
 
 T_START = time.perf_counter()
 
