@@ -631,7 +631,10 @@ def test_fused_stem_f16x2(dev, n, fpg, kind):
 
 
 @pytest.mark.parametrize("n,h,cin,couts,pool_cout", [(3, 17, 768, (192, 160, 160), 192), (2, 35, 192, (64, 48, 64), 32),
-                                                     (2, 8, 1280, (320, 384, 448), 0)])
+                                                     (2, 8, 1280, (320, 384, 448), 0),
+                                                     # 288 stacked columns on enough rows for the 256 x 96 tiles, the split
+                                                     # inside the first of them
+                                                     (150, 35, 64, (64, 128, 96), 0)])
 def test_conv_split_two_destinations(dev, n, h, cin, couts, pool_cout):
     """avs_conv2d_nhwc_split: several 1x1 convolutions that read one input as ONE contraction over their stacked filters - the
     first head into its channel slice of a wider buffer, the others (and, with relu_cols, a head without bias / ReLU) into a
