@@ -46,6 +46,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARC
 MFMA_F32_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
 PMC_TRAFFIC_FILES = {"bf16": ("r02_pmc_traffic.json", "r01_e_pmc_traffic.json"),   # newest first, under profiles/
+                     "f16x2+inception3": ("r04_g_both_pmc_traffic.json",),   # the both-trunks configuration's own passes
                      "f16x2": ("r04_g_pmc_traffic.json", "r04_f_pmc_traffic.json", "r04_e_pmc_traffic.json", "r03_e_pmc_traffic.json", "r03_c_pmc_traffic.json", "r03_b_pmc_traffic.json", "r03_a_pmc_traffic.json")}
 
 T_START = time.perf_counter()
@@ -613,7 +614,8 @@ def main():
     frames_all = float(n_all.item())
 
     if rank == 0:
-        roofline = roofline_from(prof, dtype, elapsed, pmc_traffic(args.dtype), split) if prof is not None else None
+        roofline = roofline_from(prof, dtype, elapsed, pmc_traffic(args.dtype + ("+inception3" if use_inception else "")),
+                                 split) if prof is not None else None
         group_txt = "per-frame shots" if fpg == 1 else f"the reference's {fpg}-frame BatchNorm micro-batches inside each video"
 
         # ---- CPU baseline + accuracy of the benchmarked mode on the same samples (outside every timed region)
@@ -648,7 +650,8 @@ def main():
             subs = {}
             dev_samples = torch.from_numpy(np.concatenate(s_frames)).to(dev) if s_frames is not None else None
 
-            def run_sub(name, pipe_, frames_, offsets_, note, steps_=2, roof=None, acc=False, stream_of_batches=False):
+            def run_sub(name, pipe_, frames_, offsets_, note, steps_=2, roof=None, acc=False, stream_of_batches=False,
+                        traffic_mode=None):
                 """roof = (torch dtype, split): also bracket the contraction launches with HIP events -> own roofline
                 block; acc: this mode's accuracy against the oracle on the cpu_baseline samples."""
                 def s_step():
@@ -662,7 +665,8 @@ def main():
                               "steps": steps_, "ms_per_step": round(dt * 1e3 / steps_, 2),
                               "selected_frames": int(sum(len(s) for s in sel))}
                 if roof:
-                    subs[name]["roofline"] = roofline_from(prof_, roof[0], dt, (None, None), roof[1])
+                    subs[name]["roofline"] = roofline_from(prof_, roof[0], dt,
+                                                           pmc_traffic(traffic_mode) if traffic_mode else (None, None), roof[1])
                 if acc and dev_samples is not None:
                     a_ = accuracy_report(pipe_.score(dev_samples, s_off).cpu().numpy(), ref, s_off)
                     subs[name]["accuracy"] = {k: (round(v, 8) if isinstance(v, float) else v) for k, v in a_.items()}
@@ -692,7 +696,8 @@ def main():
             run_sub("resnet50+inception3", pipe_both, frames, offsets, base + args.dtype + ", both trunks of "
                     "VisualFeatureExtractor.forward in the headline arithmetic (Inception-v3: eval BatchNorm folded, bias + ReLU "
                     "epilogue, the 1x1 heads of a block as one contraction, 299x299 bilinear resize on the GPU): the 4096-d "
-                    "embedding with both halves live", roof=(dtype, split))
+                    "embedding with both halves live", roof=(dtype, split),
+                    traffic_mode=(args.dtype + "+inception3"))
             if sd_cpu is not None and args.cpu_sample > 0:
                 # its accuracy against the oracle with BOTH trunks on the CPU: two of the cpu_baseline's sample videos
                 log("both trunks: oracle scores of 2 sample videos (ResNet-50 + Inception-v3 on the CPU)")
