@@ -6,7 +6,7 @@ returns a non-zero status, this module raises.  Build with
 """
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_uint, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_uint, c_void_p
 
 # torch first: its HIP runtime (torch/lib/libamdhip64) must be the one this process initialises.  Loading
 # libavsum_hip.so before torch pulls in /opt/rocm's copy of the same SONAME instead, and the second runtime to come
@@ -29,6 +29,7 @@ AVS_W_ROWS, AVS_W_KSTEP32 = 0, 1
 TILE_AUTO, TILE_128, TILE_256, TILE_224, STAGING_GENERIC = 0, 1, 2, 3, 4      # avs_conv_desc.variant
 X_F16P8, Y_F16P8, RES_F16P8 = 1, 2, 4                                         # avs_conv_desc.formats
 LSTM_AUTO, LSTM_STREAM, LSTM_RESIDENT_20_8, LSTM_RESIDENT_16_8 = 0, 1, 2, 3
+LSTM_SPLIT4 = 4   # (host-side choice: the avs_lstm*_split_f32 entry points - one recurrence over four CUs)
 ACT_NONE, ACT_RELU = 0, 1
 BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
 E_UNSUPPORTED = -6
@@ -128,6 +129,9 @@ _SIGNATURES = {
     "avs_score_head_bwd_f32": (c_int, [P, P, P, c_int64, c_int, c_int64, P, P, P, P]),
     "avs_lstm_train_fwd_f32": (c_int, [P, P, c_int, c_int, c_uint, P, c_int, P, c_int64, c_int, P, P, c_int, P]),
     "avs_lstm_bwd_f32": (c_int, [P, c_int64, c_int, P, P, P, c_int, c_int, c_uint, P, c_int, P, c_int, P]),
+    "avs_lstm_split_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "avs_lstm_split_f32": (c_int, [P, P, c_int, c_int, c_uint, P, c_int, P, c_int64, c_int, P, P, P, c_size_t, c_uint, P]),
+    "avs_lstm_bwd_split_f32": (c_int, [P, c_int64, c_int, P, P, P, c_int, c_int, c_uint, P, c_int, P, P, c_size_t, c_uint, P]),
     "avs_cdist_f64": (c_int, [P, c_int, P, c_int, c_int, P, P]),
     "avs_dtw_workspace_bytes": (c_int64, [c_int, c_int]),
     "avs_dtw_path_f64": (c_int, [P, c_int, c_int, P, c_int64, P, P, P, P]),
@@ -168,8 +172,8 @@ def lib():
         fn = getattr(handle, name)
         fn.restype = res
         fn.argtypes = args
-    if handle.avs_abi_version() != 4:
-        raise AvsError(f"ABI version mismatch: library reports {handle.avs_abi_version()}, binding expects 4")
+    if handle.avs_abi_version() != 5:
+        raise AvsError(f"ABI version mismatch: library reports {handle.avs_abi_version()}, binding expects 5")
     if STUDY and os.environ.get("AVS_TUNE_CONVBN_NARROW") is not None:
         handle.avs_tune_convbn_narrow(int(os.environ["AVS_TUNE_CONVBN_NARROW"]))
     if STUDY and os.environ.get("AVS_TUNE_PIPELINE") is not None:  # kernel-study override of the library default

@@ -1078,6 +1078,50 @@ def resample(x, taps, up, down, width, out_len):
 
 
 # --------------------------------------------------------------------------- scorer
+# ---- the split recurrence (avs_lstm_split_f32 / avs_lstm_bwd_split_f32): workspace + tag ranges per (device, stream)
+LSTM_SPLIT_MAX_RECURRENCES = 64     # AUTO takes the four-CU form up to this many recurrences per launch (4 workgroups each:
+#                                     all of them resident at once); beyond it one recurrence per CU is the better use of the chip
+
+
+class _LstmExchange:
+    """Granule workspace of the split recurrence on one (device, stream): zeroed once; `epoch` = tags handed out so far."""
+
+    def __init__(self):
+        self.buf, self.epoch = None, 0
+
+    def get(self, device, nbytes, steps):
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = torch.zeros(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            self.epoch = 0
+        if self.epoch + steps + 2 >= 0xFFFFFFF0:      # (32-bit tags: start over on a cleared buffer)
+            self.buf.zero_()
+            self.epoch = 0
+        e = self.epoch
+        self.epoch += int(steps) + 1
+        return self.buf, e
+
+
+_lstm_exchanges = {}
+
+
+def _lstm_split_ws(device, ndir, nseq, rows):
+    ex = _lstm_exchanges.setdefault(_ws_key(device), _LstmExchange())
+    return ex.get(device, lib().avs_lstm_split_workspace_bytes(ndir, nseq), rows)
+
+
+def lstm_split_errors(device):
+    """Workgroups whose bounded partner wait ran out in the split-recurrence launches on this device's current stream so far
+    (0 after healthy launches); reads the counter back (a host sync)."""
+    ex = _lstm_exchanges.get(_ws_key(device))
+    return 0 if ex is None or ex.buf is None else int(ex.buf[:4].view(torch.int32).item())
+
+
+def _lstm_takes_split(variant, hidden, ndir, nseq):
+    if variant == _abi.LSTM_SPLIT4:
+        return True
+    return variant == _abi.LSTM_AUTO and hidden == 256 and 0 < ndir * nseq <= LSTM_SPLIT_MAX_RECURRENCES
+
+
 def lstm(xproj, whh_t, hidden, ndir, reverse_mask, seq_rows, out, out_col0, variant=0):
     _f32(xproj, "xproj")
     _f32(whh_t, "whh_t")
@@ -1087,6 +1131,12 @@ def lstm(xproj, whh_t, hidden, ndir, reverse_mask, seq_rows, out, out_col0, vari
     if tuple(whh_t.shape) != (ndir, hidden, 4 * hidden):
         raise ValueError(f"whh_t shape {tuple(whh_t.shape)}")
     nseq = seq_rows.numel() - 1
+    if _lstm_takes_split(variant, hidden, ndir, nseq):
+        ws, epoch = _lstm_split_ws(xproj.device, ndir, nseq, xproj.shape[0])
+        check(lib().avs_lstm_split_f32(_p(xproj), _p(whh_t), hidden, ndir, reverse_mask, _p(seq_rows), nseq, _p(out),
+                                       out.stride(0), out_col0, None, None, _p(ws), ws.numel(), epoch, _stream()),
+              "avs_lstm_split_f32")
+        return out
     check(lib().avs_lstm_f32(_p(xproj), _p(whh_t), hidden, ndir, reverse_mask, _p(seq_rows), nseq, _p(out),
                              out.stride(0), out_col0, int(variant), _stream()), "avs_lstm_f32")
     return out
@@ -1203,6 +1253,14 @@ def lstm_train_fwd(xproj, whh_t, hidden, ndir, reverse_mask, seq_rows, out, out_
     gates = torch.empty((rows, ndir * 4 * hidden), dtype=torch.float32, device=xproj.device)
     cell = torch.empty((rows, ndir * hidden), dtype=torch.float32, device=xproj.device)
     nseq = seq_rows.numel() - 1
+    if _lstm_takes_split(variant, hidden, ndir, nseq):
+        ws, epoch = _lstm_split_ws(xproj.device, ndir, nseq, rows)
+        check(lib().avs_lstm_split_f32(_p(xproj), _p(whh_t), hidden, ndir, reverse_mask, _p(seq_rows), nseq, _p(out),
+                                       out.stride(0), out_col0, _p(gates), _p(cell), _p(ws), ws.numel(), epoch, _stream()),
+              "avs_lstm_split_f32")
+        return gates, cell
+    if variant == _abi.LSTM_RESIDENT_20_8:      # (the C entry's AUTO: the one-CU resident kernel)
+        variant = _abi.LSTM_AUTO
     check(lib().avs_lstm_train_fwd_f32(_p(xproj), _p(whh_t), hidden, ndir, reverse_mask, _p(seq_rows), nseq, _p(out),
                                        out.stride(0), out_col0, _p(gates), _p(cell), int(variant), _stream()),
           "avs_lstm_train_fwd_f32")
@@ -1213,6 +1271,14 @@ def lstm_bwd(dout, out_col0, gates, cell, whh, hidden, ndir, reverse_mask, seq_r
     rows = gates.shape[0]
     dxproj = torch.empty((rows, ndir * 4 * hidden), dtype=torch.float32, device=gates.device)
     nseq = seq_rows.numel() - 1
+    if _lstm_takes_split(variant, hidden, ndir, nseq):
+        ws, epoch = _lstm_split_ws(gates.device, ndir, nseq, rows)
+        check(lib().avs_lstm_bwd_split_f32(_p(dout), dout.stride(0), out_col0, _p(gates), _p(cell), _p(whh), hidden, ndir,
+                                           reverse_mask, _p(seq_rows), nseq, _p(dxproj), _p(ws), ws.numel(), epoch, _stream()),
+              "avs_lstm_bwd_split_f32")
+        return dxproj
+    if variant == _abi.LSTM_RESIDENT_20_8:
+        variant = _abi.LSTM_AUTO
     check(lib().avs_lstm_bwd_f32(_p(dout), dout.stride(0), out_col0, _p(gates), _p(cell), _p(whh), hidden, ndir,
                                  reverse_mask, _p(seq_rows), nseq, _p(dxproj), int(variant), _stream()), "avs_lstm_bwd_f32")
     return dxproj

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define AVS_ABI_VERSION 4
+#define AVS_ABI_VERSION 5
 
 enum {
   AVS_OK = 0,
@@ -609,6 +609,28 @@ int avs_lstm_train_fwd_f32(const float* d_xproj, const float* d_whh_t, int hidde
 int avs_lstm_bwd_f32(const float* d_dout, int64_t ldo, int out_col0, const float* d_gates,
                      const float* d_cell, const float* d_whh, int hidden, int ndir, unsigned reverse_mask,
                      const int64_t* d_seq_rows, int nseq, float* d_dxproj, int variant, avs_stream_t stream);
+
+/* The hidden = 256 recurrence with ONE recurrence split over FOUR CUs (models/av_model.py:39-40 forward,
+ * scripts/train_av_model.py:94-95 backward): each of the four workgroups of a recurrence owns 64 hidden units and keeps its
+ * quarter of W_hh in registers for the whole sequence; per time step the four exchange the step's vector (h_t forward, the
+ * gate gradients backward) through tagged 8-byte granules in the workspace.  Same arguments and bit-identical outputs as
+ * avs_lstm_f32 / avs_lstm_train_fwd_f32 (d_gates and d_cell given: both or neither) / avs_lstm_bwd_f32 with AVS_LSTM_AUTO;
+ * a time step costs ~1.5 us instead of 5.2: for FEW recurrences (one video per training step, a few dozen videos at
+ * inference: all 4 * ndir * nseq workgroups should be resident at once - with more than 64 recurrences prefer avs_lstm_f32,
+ * which runs one recurrence per CU).
+ * d_ws: avs_lstm_split_workspace_bytes(ndir, nseq) bytes, 8-byte aligned, ZEROED ONCE by the caller before its first use
+ * and then left alone; epoch: tags of a launch are epoch + 1 ... epoch + longest sequence - the caller passes values whose
+ * ranges do not overlap from launch to launch on the same workspace (e.g. a running sum of rows + 1; wrap-around after 2^32
+ * steps is harmless).  The FIRST 64 bytes of the workspace hold an error word (uint32, first of them): the number of
+ * workgroups whose bounded wait (~0.3 s) for a partner ran out - 0 after a healthy launch; such a launch ends, its
+ * outputs are incomplete.                                                                                            */
+size_t avs_lstm_split_workspace_bytes(int ndir, int nseq);
+int avs_lstm_split_f32(const float* d_xproj, const float* d_whh_t, int hidden, int ndir, unsigned reverse_mask,
+                       const int64_t* d_seq_rows, int nseq, float* d_out, int64_t ldo, int out_col0, float* d_gates,
+                       float* d_cell, void* d_ws, size_t ws_bytes, unsigned epoch, avs_stream_t stream);
+int avs_lstm_bwd_split_f32(const float* d_dout, int64_t ldo, int out_col0, const float* d_gates, const float* d_cell,
+                           const float* d_whh, int hidden, int ndir, unsigned reverse_mask, const int64_t* d_seq_rows,
+                           int nseq, float* d_dxproj, void* d_ws, size_t ws_bytes, unsigned epoch, avs_stream_t stream);
 
 /* ---- fusion (K13-K15) --------------------------------------------------- */
 

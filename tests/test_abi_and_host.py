@@ -16,7 +16,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) == set(_abi._SIGNATURES)
-    assert lib.avs_abi_version() == 4
+    assert lib.avs_abi_version() == 5
     assert os.path.dirname(_abi.LIB_PATH).startswith(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 

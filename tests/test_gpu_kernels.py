@@ -566,10 +566,12 @@ def test_lstm_vs_oracle(dev):
             # the scorer's size keeps part of W_hh^T in registers / LDS (default); the generic streaming kernel and the
             # other resident split run the same fmaf chain in the same order: bit-identical
             from avsum_amd import _abi
-            for variant in (_abi.LSTM_STREAM, _abi.LSTM_RESIDENT_16_8):
+            # (the default at this few recurrences: one recurrence split over four CUs, W_hh in registers - the same chain)
+            for variant in (_abi.LSTM_STREAM, _abi.LSTM_RESIDENT_20_8, _abi.LSTM_RESIDENT_16_8, _abi.LSTM_SPLIT4):
                 alt = torch.zeros_like(out)
                 ops.lstm(xproj, whh_t, hid, 2, 0b10, seq, alt, 4, variant=variant)
                 assert torch.equal(alt, out)
+            assert ops.lstm_split_errors(dev) == 0
 
 
 def test_lstm_training_kernels_resident_vs_streaming(dev):
@@ -588,7 +590,7 @@ def test_lstm_training_kernels_resident_vs_streaming(dev):
     seq = torch.tensor(np.cumsum([0] + lens), dtype=torch.int64, device=dev)
     dout = torch.randn(rows, ndir * hid + 8, generator=g).to(dev)
     res = {}
-    for variant in (_abi.LSTM_AUTO, _abi.LSTM_STREAM):
+    for variant in (_abi.LSTM_AUTO, _abi.LSTM_STREAM, _abi.LSTM_RESIDENT_20_8, _abi.LSTM_SPLIT4):
         out = torch.zeros(rows, ndir * hid + 8, device=dev)
         gates, cell = ops.lstm_train_fwd(xproj, whh_t, hid, ndir, 0b1010, seq, out, 8, variant=variant)
         dx = ops.lstm_bwd(dout, 8, gates, cell, whh, hid, ndir, 0b1010, seq, variant=variant)
@@ -604,6 +606,42 @@ def test_lstm_training_kernels_resident_vs_streaming(dev):
     scale = b[3].abs().max().item()
     assert (a[3] - b[3]).abs().max().item() <= 2e-5 * scale   # 700-step chains of fp32 sums in two orders
     assert torch.isfinite(a[3]).all()
+    # the four-CU split (AUTO's choice at 12 recurrences) against the one-CU resident kernels: the same chains in the same
+    # order, forward and backward - every saved tensor and the gradient bit for bit
+    r, sp = res[_abi.LSTM_RESIDENT_20_8], res[_abi.LSTM_SPLIT4]
+    for x, y, z in zip(r, sp, a):
+        assert torch.equal(x, y) and torch.equal(y, z)
+    assert ops.lstm_split_errors(dev) == 0
+
+
+def test_lstm_split_many_recurrences_and_ragged_lengths(dev):
+    """The split recurrence with more workgroups than the chip holds at once (96 recurrences x 4 = 384 workgroups of 512
+    threads: partners are dispatched together, complete groups always finish) and ragged lengths down to 0 and 1 steps:
+    bit for bit the one-CU kernel, no bounded wait ran out; twice in a row on the same workspace (tag ranges move on)."""
+    ops = _ops()
+    from avsum_amd import _abi
+    hid, ndir = 256, 4
+    g = torch.Generator().manual_seed(33)
+    lens = [int(v) for v in torch.randint(0, 40, (24,), generator=g)]
+    lens[3], lens[7], lens[11] = 0, 1, 2
+    rows = sum(lens)
+    xproj = torch.randn(rows, ndir * 4 * hid, generator=g).to(dev)
+    whh = ((torch.rand(ndir, 4 * hid, hid, generator=g) - 0.5) * 2 / hid ** 0.5).to(dev)
+    whh_t = whh.transpose(1, 2).contiguous()
+    seq = torch.tensor(np.cumsum([0] + lens), dtype=torch.int64, device=dev)
+    dout = torch.randn(rows, ndir * hid, generator=g).to(dev)
+    ref_out = torch.zeros(rows, ndir * hid, device=dev)
+    g0, c0 = ops.lstm_train_fwd(xproj, whh_t, hid, ndir, 0b0110, seq, ref_out, 0, variant=_abi.LSTM_RESIDENT_20_8)
+    dx0 = ops.lstm_bwd(dout, 0, g0, c0, whh, hid, ndir, 0b0110, seq, variant=_abi.LSTM_RESIDENT_20_8)
+    for _ in range(2):
+        out = torch.zeros(rows, ndir * hid, device=dev)
+        g1, c1 = ops.lstm_train_fwd(xproj, whh_t, hid, ndir, 0b0110, seq, out, 0, variant=_abi.LSTM_SPLIT4)
+        dx1 = ops.lstm_bwd(dout, 0, g1, c1, whh, hid, ndir, 0b0110, seq, variant=_abi.LSTM_SPLIT4)
+        inf = torch.zeros(rows, ndir * hid, device=dev)
+        ops.lstm(xproj, whh_t, hid, ndir, 0b0110, seq, inf, 0, variant=_abi.LSTM_SPLIT4)
+        assert torch.equal(out, ref_out) and torch.equal(inf, ref_out)
+        assert torch.equal(g1, g0) and torch.equal(c1, c0) and torch.equal(dx1, dx0)
+    assert ops.lstm_split_errors(dev) == 0
 
 
 def test_softmax_score_head_mha(dev):
