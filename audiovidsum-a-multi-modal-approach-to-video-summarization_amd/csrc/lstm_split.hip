@@ -70,6 +70,7 @@ __global__ __launch_bounds__(512) void lstm_split_fwd_kernel(const float* __rest
 
   __shared__ float h_s[SP_H];
   __shared__ float part_s[4 * SP_H];   // [kq][gate * 64 + unit]
+  __shared__ float act_s[SP_H];        // [gate][unit]: the step's post-activation gates of this workgroup's units
   __shared__ int bail;
 
   const int tid = threadIdx.x;
@@ -80,7 +81,10 @@ __global__ __launch_bounds__(512) void lstm_split_fwd_kernel(const float* __rest
 #pragma unroll
   for (int i = 0; i < 64; ++i) w[i] = *reinterpret_cast<const float2*>(W + (long long)(64 * kq + i) * SP_G + c0);
 
-  const int unit = SP_UNITS * part + tid;   // threads < 64: the hidden unit this thread finishes
+  // the gate activations of a step run on FOUR waves at once (wave gw: gate gw of the 64 units), the cell update on one
+  const int gw = __builtin_amdgcn_readfirstlane(tid >> 6) & 3, gu = tid & 63;
+  const int gcol = gw * SP_H + SP_UNITS * part + gu;   // threads < 256: the gate column this thread activates
+  const int unit = SP_UNITS * part + tid;              // threads < 64: the hidden unit this thread finishes
   float c_state = 0.f;
   if (tid < SP_H) h_s[tid] = 0.f;
   if (tid == 0) bail = 0;
@@ -89,14 +93,8 @@ __global__ __launch_bounds__(512) void lstm_split_fwd_kernel(const float* __rest
 
   for (long long s = 0; s < T; ++s) {
     const long long row = rev ? (r1 - 1 - s) : (r0 + s);
-    float xi = 0.f, xf = 0.f, xg = 0.f, xo = 0.f;
-    if (tid < SP_UNITS) {
-      const float* xr = xp + row * ldx;
-      xi = xr[unit];
-      xf = xr[SP_H + unit];
-      xg = xr[2 * SP_H + unit];
-      xo = xr[3 * SP_H + unit];
-    }
+    float xv = 0.f;
+    if (tid < SP_H) xv = xp[row * ldx + gcol];
     float ax = 0.f, ay = 0.f;
     const float4* h4 = reinterpret_cast<const float4*>(h_s + 64 * kq);
 #pragma unroll
@@ -115,29 +113,22 @@ __global__ __launch_bounds__(512) void lstm_split_fwd_kernel(const float* __rest
     __syncthreads();
     const unsigned tag = epoch + (unsigned)s + 1u;
     unsigned long long* const slot = slots + (s & 1) * SP_SLOT;
-    if (tid < SP_UNITS) {
-      float gi = xi, gf = xf, gg = xg, go = xo;
+    if (tid < SP_H) {
+      float pre = xv;   // x + the four slices' partial sums, slices ascending (as lstm_kernel adds them)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float* pq = part_s + q * SP_H;
-        gi += pq[tid];
-        gf += pq[SP_UNITS + tid];
-        gg += pq[2 * SP_UNITS + tid];
-        go += pq[3 * SP_UNITS + tid];
-      }
-      const float ig = avs_sigmoid(gi), fg = avs_sigmoid(gf), cg = tanhf(gg), og = avs_sigmoid(go);
+      for (int q = 0; q < 4; ++q) pre += part_s[q * SP_H + gw * SP_UNITS + gu];
+      const float act = gw == 2 ? tanhf(pre) : avs_sigmoid(pre);
+      act_s[gw * SP_UNITS + gu] = act;
+      if constexpr (TRAIN) gates[row * ldx + (long long)dir * SP_G + gcol] = act;
+    }
+    __syncthreads();
+    if (tid < SP_UNITS) {
+      const float ig = act_s[tid], fg = act_s[SP_UNITS + tid], cg = act_s[2 * SP_UNITS + tid], og = act_s[3 * SP_UNITS + tid];
       c_state = fg * c_state + ig * cg;
       const float hv = og * tanhf(c_state);
       __hip_atomic_store(slot + unit, sp_pack(hv, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       out[row * ldo + out_col0 + dir * SP_H + unit] = hv;
-      if constexpr (TRAIN) {
-        float* gr = gates + row * ldx + (long long)dir * SP_G;
-        gr[unit] = ig;
-        gr[SP_H + unit] = fg;
-        gr[2 * SP_H + unit] = cg;
-        gr[3 * SP_H + unit] = og;
-        cell[row * ((long long)ndir * SP_H) + dir * SP_H + unit] = c_state;
-      }
+      if constexpr (TRAIN) cell[row * ((long long)ndir * SP_H) + dir * SP_H + unit] = c_state;
     }
     if (s + 1 < T && tid < SP_H) {   // the whole h_t, from the four owners (this workgroup's own 64 values included)
       float v;
@@ -237,9 +228,13 @@ __global__ __launch_bounds__(512) void lstm_split_bwd_kernel(const float* __rest
       }
     }
     if (s > 0) {   // (the last step's product would feed nothing)
-      float v0, v1;
-      const bool ok0 = sp_wait(slot + tid, tag, v0);
-      const bool ok1 = sp_wait(slot + 512 + tid, tag, v1);
+      // both granules of this thread in flight at once, then each is verified (and polled on if its tag is not there yet)
+      unsigned long long q0 = __hip_atomic_load(slot + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned long long q1 = __hip_atomic_load(slot + 512 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      float v0 = __uint_as_float((unsigned)q0), v1 = __uint_as_float((unsigned)q1);
+      bool ok0 = (unsigned)(q0 >> 32) == tag, ok1 = (unsigned)(q1 >> 32) == tag;
+      if (!ok0) ok0 = sp_wait(slot + tid, tag, v0);
+      if (!ok1) ok1 = sp_wait(slot + 512 + tid, tag, v1);
       if (!(ok0 && ok1)) bail = 1;
       da_s[tid] = v0;
       da_s[512 + tid] = v1;

@@ -12,7 +12,7 @@ from ._abi import (ACT_NONE, ACT_RELU, AVS_BF16, AVS_F16X2, AVS_F32, AVS_F32_SPL
                    lib)
 
 __all__ = [
-    "ACT_NONE", "ACT_RELU", "linear", "gemm_nt_batched", "conv2d", "conv2d_raw", "conv2d_split", "conv_bnlocal_tile_rows", "conv_bncluster_ok", "cluster_exchange_errors", "conv1x1_bn", "conv1x1_gram_bn", "bn_gram_affine", "gram_supported", "frames_normalize", "pull_copy", "stem_conv_bn_pool", "stem_h2_operands", "stem_conv_pool_h2", "resize_bilinear",
+    "ACT_NONE", "ACT_RELU", "linear", "gemm_nt_batched", "conv2d", "conv2d_raw", "conv2d_split", "conv_bnlocal_tile_rows", "conv_bncluster_ok", "cluster_exchange_errors", "lstm_split_errors", "conv1x1_bn", "conv1x1_gram_bn", "bn_gram_affine", "gram_supported", "frames_normalize", "pull_copy", "stem_conv_bn_pool", "stem_h2_operands", "stem_conv_pool_h2", "resize_bilinear",
     "bn_batch_stats", "bn_apply", "bn_maxpool", "pool2d", "global_avgpool", "segment_mean", "hsv_frame_diff", "reflect_pad", "stft_f64", "stft_mel_fused", "power_mel",
     "clamp_topdb", "stft_mel_max", "stft_mel_segmean", "stft_mel_segmean_batch", "fill", "quantize", "resample", "lstm", "mha_batchaxis", "score_head", "mhsa_flash", "softmax_rows", "cdist", "dtw_path",
     "gather_scale", "dtype_code", "f16x2_pack", "f16x2_unpack", "bn_gram_affine_h2", "conv2d_affine",

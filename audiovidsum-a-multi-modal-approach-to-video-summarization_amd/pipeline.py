@@ -295,6 +295,9 @@ class FrameScoringPipeline:
             bad = ops.cluster_exchange_errors(visual.device)
             if bad:
                 raise RuntimeError(f"clustered BatchNorm: {bad} wave(s) gave up waiting for a partner tile's statistics")
+            bad = ops.lstm_split_errors(visual.device)      # the scorer's recurrences split over four CUs, likewise
+            if bad:
+                raise RuntimeError(f"split LSTM recurrence: {bad} workgroup(s) gave up waiting for a partner's step vector")
         return scores
 
     @staticmethod

@@ -12,7 +12,7 @@ import torch
 import torch.nn.functional as F
 from torch.utils.data import DataLoader
 
-from .. import dist as avd
+from .. import dist as avd, ops
 from ..models.av_model import AVBiLSTMModel
 from ..utils.alignments import align_shots_to_annotations
 
@@ -57,6 +57,12 @@ def train_on_dataset(dataset, epochs=100, lr=1e-4, model=None, on_step=None, dev
             loss = train_step(model, optimizer, features, frame_scores, device)
             if on_step is not None:
                 on_step(loss)
+        # the recurrences run split over four CUs (ops.lstm*): no bounded wait may have run out during the epoch
+        dev = next(model.parameters()).device
+        if dev.type == "cuda":
+            bad = ops.lstm_split_errors(dev)
+            if bad:
+                raise RuntimeError(f"split LSTM recurrence: {bad} workgroup(s) gave up waiting for a partner's step vector")
     return model
 
 

@@ -332,13 +332,13 @@ def config4_leg(dev, steps=20, lengths=(300, 1800), oracle_steps=6, rank=0, worl
     steps per sequence length, every step through avsum_amd.scripts.train_av_model.train_step (forward and backward are
     libavsum_hip.so calls; loss / optimiser are the caller's torch, as in the reference).  Features resident on the
     device.  Also: the LSTM sweeps alone (us per time step, forward with saved gates and backward through time, all four
-    recurrences in one launch), and the first `oracle_steps` losses against the CPU restatement under the same Dropout
+    recurrences in one launch: split over four CUs each as the step runs them, and one CU per recurrence beside it), and the first `oracle_steps` losses against the CPU restatement under the same Dropout
     masks (<= 1e-4 relative).
     world > 1 (launched with torch.distributed.run, one rank per GPU): plain data parallelism as SURVEY 8 E1 states it - every
     rank takes its own video per step, train_step averages the gradients over the ranks (dist.allreduce_gradients: one RCCL
     all-reduce of the 38.7 MB bucket) before AdamW; videos per second = world x steps per second.  The loss trajectory against
     the oracle is a world-1 statement (the effective batch differs) and is skipped."""
-    from avsum_amd import ops
+    from avsum_amd import _abi, ops
     from avsum_amd.models.av_model import AVBiLSTMModel
     from avsum_amd.scripts.train_av_model import train_step
     from oracle import scorer as osc
@@ -388,24 +388,31 @@ def config4_leg(dev, steps=20, lengths=(300, 1800), oracle_steps=6, rank=0, worl
         fused = torch.empty(t_len, 4 * hid, device=dev)
         dfused = torch.randn(t_len, 4 * hid, generator=g).to(dev)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        f_ms, b_ms = [], []
-        for _ in range(6):
-            ev[0].record()
-            gates, cell = ops.lstm_train_fwd(xproj, whh_t, hid, 4, 0b1010, seq, fused, 0)
-            ev[1].record()
-            ops.lstm_bwd(dfused, 0, gates, cell, whh, hid, 4, 0b1010, seq)
-            ev[2].record()
-            torch.cuda.synchronize()
-            f_ms.append(ev[0].elapsed_time(ev[1]))
-            b_ms.append(ev[1].elapsed_time(ev[2]))
-        f_us, b_us = statistics.median(f_ms[1:]) * 1e3 / t_len, statistics.median(b_ms[1:]) * 1e3 / t_len
+
+        def sweeps(variant):
+            f_ms, b_ms = [], []
+            for _ in range(6):
+                ev[0].record()
+                gates, cell = ops.lstm_train_fwd(xproj, whh_t, hid, 4, 0b1010, seq, fused, 0, variant=variant)
+                ev[1].record()
+                ops.lstm_bwd(dfused, 0, gates, cell, whh, hid, 4, 0b1010, seq, variant=variant)
+                ev[2].record()
+                torch.cuda.synchronize()
+                f_ms.append(ev[0].elapsed_time(ev[1]))
+                b_ms.append(ev[1].elapsed_time(ev[2]))
+            return statistics.median(f_ms[1:]) * 1e3 / t_len, statistics.median(b_ms[1:]) * 1e3 / t_len
+        f_us, b_us = sweeps(_abi.LSTM_AUTO)                 # what the step runs: one recurrence split over four CUs
+        f1_us, b1_us = sweeps(_abi.LSTM_RESIDENT_20_8)      # beside it: one recurrence per CU (rounds 3-4's kernels)
+        if ops.lstm_split_errors(dev):
+            raise RuntimeError("split LSTM recurrence: a bounded wait ran out")
         out["lengths"][str(t_len)] = {
             "steps_per_s": round(steps / dt, 2), "ms_per_step": round(dt * 1e3 / steps, 3),
             "videos_per_s": round(world * steps / dt, 2), "frames_per_s": round(world * steps * t_len / dt, 1),
             "last_loss": round(loss, 6),
             "inference_forward_ms": round(dt_inf * 1e3 / steps, 3),
             "lstm_forward_us_per_time_step": round(f_us, 3), "lstm_backward_us_per_time_step": round(b_us, 3),
-            "lstm_backward_over_forward": round(b_us / f_us, 3)}
+            "lstm_backward_over_forward": round(b_us / f_us, 3),
+            "lstm_one_cu_per_recurrence_us_per_time_step": {"forward": round(f1_us, 3), "backward": round(b1_us, 3)}}
         log(f"configs[4] T={t_len}: {steps / dt:.1f} steps/s, LSTM {f_us:.2f} / {b_us:.2f} us per time step (fwd / bwd)")
     if world > 1:
         return out
