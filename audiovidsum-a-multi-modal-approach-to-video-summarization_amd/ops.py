@@ -1079,8 +1079,10 @@ def resample(x, taps, up, down, width, out_len):
 
 # --------------------------------------------------------------------------- scorer
 # ---- the split recurrence (avs_lstm_split_f32 / avs_lstm_bwd_split_f32): workspace + tag ranges per (device, stream)
-LSTM_SPLIT_MAX_RECURRENCES = 64     # AUTO takes the four-CU form up to this many recurrences per launch (4 workgroups each:
-#                                     all of them resident at once); beyond it one recurrence per CU is the better use of the chip
+LSTM_SPLIT_MAX_RECURRENCES = 128    # AUTO takes the four-CU form up to this many recurrences per launch: 4 workgroups of 512
+#                                     threads each, one per CU - up to 64 recurrences all resident at once, up to 128 in two
+#                                     rounds (2 x 1.6 us per step against 5.2 for one recurrence per CU); beyond that one
+#                                     recurrence per CU is the better use of the chip
 
 
 class _LstmExchange:

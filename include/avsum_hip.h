@@ -615,13 +615,14 @@ int avs_lstm_bwd_f32(const float* d_dout, int64_t ldo, int out_col0, const float
  * quarter of W_hh in registers for the whole sequence; per time step the four exchange the step's vector (h_t forward, the
  * gate gradients backward) through tagged 8-byte granules in the workspace.  Same arguments and bit-identical outputs as
  * avs_lstm_f32 / avs_lstm_train_fwd_f32 (d_gates and d_cell given: both or neither) / avs_lstm_bwd_f32 with AVS_LSTM_AUTO;
- * a time step costs ~1.5 us instead of 5.2: for FEW recurrences (one video per training step, a few dozen videos at
- * inference: all 4 * ndir * nseq workgroups should be resident at once - with more than 64 recurrences prefer avs_lstm_f32,
- * which runs one recurrence per CU).
+ * a time step costs ~1.6 us (forward) / 1.85 us (backward) instead of 5.2 / 5.3: for FEW recurrences (one video per
+ * training step, a few dozen videos at inference).  A launch runs 4 * ndir * nseq workgroups of 512 threads, one per CU: up
+ * to 64 recurrences are all resident at once; more run in rounds (partners are dispatched together: complete groups always
+ * finish) and past ~190 recurrences avs_lstm_f32's one recurrence per CU is the faster use of the chip.
  * d_ws: avs_lstm_split_workspace_bytes(ndir, nseq) bytes, 8-byte aligned, ZEROED ONCE by the caller before its first use
  * and then left alone; epoch: tags of a launch are epoch + 1 ... epoch + longest sequence - the caller passes values whose
- * ranges do not overlap from launch to launch on the same workspace (e.g. a running sum of rows + 1; wrap-around after 2^32
- * steps is harmless).  The FIRST 64 bytes of the workspace hold an error word (uint32, first of them): the number of
+ * ranges do not overlap from launch to launch on the same workspace (e.g. a running sum of rows + 1) and stay below 2^32
+ * (tag 0 is the zeroed workspace's: before the sum would wrap, zero the workspace again and start over).  The FIRST 64 bytes of the workspace hold an error word (uint32, first of them): the number of
  * workgroups whose bounded wait (~0.3 s) for a partner ran out - 0 after a healthy launch; such a launch ends, its
  * outputs are incomplete.                                                                                            */
 size_t avs_lstm_split_workspace_bytes(int ndir, int nseq);
