@@ -44,21 +44,38 @@ extern "C" int avs_transpose_f32(const float* d_src, int rows, int cols, int64_t
 }
 
 // ---------------------------------------------------------------------------
-// out[c] = sum_r x[r, c] * (w ? w[r] : 1): one block per 64 columns, 4 row-waves, fixed summation order
-// (deterministic).  Bias gradients and the weighted sum of the scoring head.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long long rows, int cols,
-                                                     long long ld, const float* __restrict__ w,
-                                                     float* __restrict__ out) {
-  __shared__ float red[4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
-  float a = 0.f;
-  if (c < cols)
-    for (long long r = wave; r < rows; r += 4) a = fmaf(x[r * ld + c], w ? w[r] : 1.f, a);
-  red[wave][lane] = a;
+// out[c] = sum_r x[r, c] * (w ? w[r] : 1).  Bias gradients and the weighted sum of the scoring head
+// (scripts/train_av_model.py:94: loss.backward()).  One block of 1024 threads per 16 columns: a thread = column c of the 16
+// and row phase ph of 64 (a wave's load = 4 rows x 64 bytes), four independent accumulators per thread (rows ph, ph + 64,
+// ph + 128, ph + 192 of every 256) - 128 blocks x 64 loads in flight for the 2048-column gate gradients, where one block
+// per 64 columns with 4 dependent row chains (round 3) ran at 53 us per call.  Fixed summation order: deterministic.
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ x, long long rows, int cols,
+                                                      long long ld, const float* __restrict__ w,
+                                                      float* __restrict__ out) {
+  __shared__ float red[64][16];
+  const int t = threadIdx.x;
+  const int cl = t & 15, ph = t >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < cols) {
+    long long r = ph;
+    for (; r + 192 < rows; r += 256) {
+      const float x0 = x[r * ld + c], x1 = x[(r + 64) * ld + c], x2 = x[(r + 128) * ld + c], x3 = x[(r + 192) * ld + c];
+      a0 = fmaf(x0, w ? w[r] : 1.f, a0);
+      a1 = fmaf(x1, w ? w[r + 64] : 1.f, a1);
+      a2 = fmaf(x2, w ? w[r + 128] : 1.f, a2);
+      a3 = fmaf(x3, w ? w[r + 192] : 1.f, a3);
+    }
+    for (; r < rows; r += 64) a0 = fmaf(x[r * ld + c], w ? w[r] : 1.f, a0);
+  }
+  red[ph][cl] = (a0 + a1) + (a2 + a3);
   __syncthreads();
-  if (wave == 0 && c < cols) out[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  if (t < 16 && c < cols) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int q = 0; q < 64; ++q) s += red[q][t];
+    out[c] = s;
+  }
 }
 
 extern "C" int avs_colsum_f32(const float* d_x, int64_t rows, int cols, int64_t ld, const float* d_row_weight,
@@ -66,7 +83,7 @@ extern "C" int avs_colsum_f32(const float* d_x, int64_t rows, int cols, int64_t 
   AVS_REQUIRE(rows >= 0 && cols > 0 && ld >= cols, AVS_E_SHAPE, "avs_colsum_f32: rows=%lld cols=%d ld=%lld",
               (long long)rows, cols, (long long)ld);
   AVS_REQUIRE(d_x && d_out, AVS_E_ARG, "avs_colsum_f32: null pointer");
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)avs_cdiv(cols, 64)), dim3(256), 0, (hipStream_t)stream, d_x,
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)avs_cdiv(cols, 16)), dim3(1024), 0, (hipStream_t)stream, d_x,
                      (long long)rows, cols, (long long)ld, d_row_weight, d_out);
   AVS_CHECK_LAUNCH("avs_colsum_f32");
   return AVS_OK;

@@ -809,3 +809,24 @@ def test_align_features_against_oracle(dev):
     assert a.shape == ra.shape == (1, 128) and b.shape == rb.shape
     z1, z2 = ext._align_features(np.zeros((0, 128)), rng.normal(size=(3, 128)), rng.normal(size=(3, 128)))
     assert np.array_equal(z1, np.zeros(128)) and np.array_equal(z2, np.zeros(128))
+
+
+@pytest.mark.parametrize("rows,cols,ld,weighted", [(1800, 2048, 2048, False), (333, 64, 64, True), (1, 1, 1, False),
+                                                   (257, 23, 40, True), (5000, 8, 8, False), (63, 1024, 1030, True)])
+def test_colsum_bias_gradient_kernel(dev, rows, cols, ld, weighted):
+    """avs_colsum_f32 (the bias gradients and the scoring head's weighted sum of loss.backward(),
+    scripts/train_av_model.py:94): ragged row / column counts, a row stride wider than the columns, row weights; against a
+    float64 sum; twice the same bits (fixed summation order)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(rows + cols)
+    buf = torch.randn(max(rows, 1), ld, generator=g)
+    x = buf[:rows, :cols]
+    w = torch.randn(rows, generator=g) if weighted else None
+    xd = buf.to(dev)[:rows, :cols]
+    wd = w.to(dev) if weighted else None
+    got = ops.colsum(xd, wd)
+    ref = (x.double() * (w.double()[:, None] if weighted else 1.0)).sum(0)
+    scale = max(1.0, (x.abs().double() * (w.abs().double()[:, None] if weighted else 1.0)).sum(0).max().item()) if rows else 1.0
+    assert got.shape == (cols,)
+    assert (got.cpu().double() - ref).abs().max().item() <= 2e-6 * scale
+    assert torch.equal(ops.colsum(xd, wd), got)
