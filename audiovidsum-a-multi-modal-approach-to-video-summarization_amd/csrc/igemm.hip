@@ -1864,7 +1864,11 @@ static int igemm_launch(int dtype, IgemmParams& p, int batch, hipStream_t stream
   }
   AVS_REQUIRE(batch <= 65535, AVS_E_SHAPE, "%s: batch %d > 65535", who, batch);
 
-  const bool narrow = p.N <= 64 || dtype == AVS_F32_ACC64;
+  // exact fp32 with few tiles (the scorer's linear layers and their gradients: 1800 rows x 512 .. 2048 columns = 16 .. 240
+  // tiles of 128 x 128 on 256 CUs x 3 workgroups): 64-wide column tiles double the workgroups; the same sums in the same order
+  const bool few_f32 = dtype == AVS_F32 && batch == 1 && !p.stat_part && !p.tile_rows && !p.affine &&
+                       (((long long)p.M + 127) / 128) * ((p.N + 127) / 128) < 256;
+  const bool narrow = p.N <= 64 || dtype == AVS_F32_ACC64 || few_f32;
   int bn = narrow ? 64 : 128;
   p.tiles_n = (p.N + bn - 1) / bn;
   // AVS_F16X2 bias + ReLU (Inception-v3's folded-BatchNorm convolutions): cout = 96, 160, 192, 288 ... leave a 128-wide
