@@ -57,6 +57,13 @@ def test_validation_before_launch_needs_no_gpu():
     assert lib.avs_dtw_workspace_bytes(10, 20) >= 200
     assert lib.avs_lstm_f32(None, None, 0, 2, 0, None, 1, None, 0, 0, 0, None) == -2
     assert lib.avs_cdist_f64(None, 4, None, 4, 0, None, None) == -2
+    # the split recurrence: 64 bytes of error word + two slots of 1024 granules per recurrence; built for hidden = 256;
+    # a workspace that is too small is refused
+    assert lib.avs_lstm_split_workspace_bytes(4, 25) == 64 + 4 * 25 * 2 * 1024 * 8 and lib.avs_lstm_split_workspace_bytes(0, 3) == 0
+    assert lib.avs_lstm_split_f32(None, None, 128, 2, 0, None, 1, None, 256, 0, None, None, None, 0, 0, None) == -6
+    assert lib.avs_lstm_split_f32(None, None, 256, 2, 0, None, 1, None, 512, 0, None, None, None, 0, 0, None) == -5
+    assert lib.avs_lstm_bwd_split_f32(None, 512, 0, None, None, None, 256, 2, 0, None, 1, None, None, 0, 0, None) == -5
+    assert b"workspace" in lib.avs_last_error()
 
 
 def test_missing_library_fails_loudly(monkeypatch):
