@@ -131,8 +131,9 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
   static_assert(!AP8 || (SPLIT == 2 && ES == 4 && PIPE && ROWB == 64 && FASTK && !SPATIAL && !TAP9 && EPI == EPI_STATS),
                 "AVS_F16P8 input: the AVS_F16X2 1x1 convolution + statistics on the pipelined tiles");
   static_assert(!TAP9 || (((SPLIT == 2 && ES == 4) || (SPLIT == 0 && ES == 2)) && PIPE && WR == 4 && ROWB == 64 && FASTK &&
-                          SPATIAL && (EPI == EPI_STATS || EPI == EPI_BNLOCAL)),
-                "the nine-tap form: AVS_F16X2 / bf16 convolution + statistics / tile-local BatchNorm on the pipelined 256-row tiles");
+                          SPATIAL && (EPI == EPI_STATS || EPI == EPI_BNLOCAL || (EPI == EPI_BRELU && SPLIT == 2))),
+                "the shifted-row form: AVS_F16X2 / bf16 convolution + statistics / tile-local BatchNorm (3x3), AVS_F16X2 bias + "
+                "ReLU (any stride-1 'same' filter) on the pipelined 256-row tiles");
   static_assert(SPLIT == 0 || (ES == 4 && !ACC64), "the split arithmetic is for 4-byte operands");
   static_assert(WR == 2 || (WR == 4 && !ACC64 && (ES == 2 || SPLIT != 0)),
                 "256-row tiles are built for the bf16 variants and the fp32-split arithmetic");
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
   // TAP9: two A buffers of 384 rows (+ 4 rows of zeros) and a ring of three weight tiles
   constexpr int T9_AROWS = 384;
   constexpr int T9_ABUF = (T9_AROWS + 4) * CPRR;
-  constexpr int T9_BBUF = BN * CPRR;
+  constexpr int T9_BBUF = NB * RPP * CPRR;
   constexpr int OPERAND_SLOTS = TAP9 ? 2 * T9_ABUF + 3 * T9_BBUF : NBUF * BUF;
   constexpr int LDS_BASE = OPERAND_SLOTS > CT_SLOTS + TAB_SLOTS ? OPERAND_SLOTS : CT_SLOTS + TAB_SLOTS;
   constexpr int LDS_SLOTS = LDS_BASE > H2_SLOTS ? LDS_BASE : H2_SLOTS;
@@ -418,11 +419,19 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
   const int steps = (p.K + BKE - 1) / BKE;
   if constexpr (TAP9) {
     constexpr int T9_NA = T9_AROWS / RPP;   // DMA instructions per wave and A block (6)
+    // TGEN (bias + ReLU: Inception-v3's 1x7 / 7x1 / 3x3 / 1x3 / 3x1 stride-1 "same" layers): any KH x KW with the filter's
+    // reach ph W + pw <= 64 rows, the input possibly a channel slice of a wider tensor (pixel stride > cin).  The 3x3 forms
+    // of the BatchNorm epilogues keep their constants (the same code as before).
+    constexpr bool TGEN = EPI == EPI_BRELU;
+    const int ntap = TGEN ? p.K / p.cin : 9;
+    const int tkw = TGEN ? p.KW : 3;
+    const int tph = TGEN ? p.ph : 1, tpw = TGEN ? p.pw : 1;
+    const long long pxs = TGEN ? p.x_px_stride : (long long)p.cin;   // elements between consecutive pixels
     const unsigned lds_base = (unsigned)(unsigned long long)((__attribute__((address_space(3))) char*)lds);
-    const int w1 = p.W + 1;
-    // buffer row a holds flat input row m0 - (W + 1) + a; the buffer window starts at the first row fetched
+    const int w1 = TGEN ? tph * p.W + tpw : p.W + 1;
+    // buffer row a holds flat input row m0 - w1 + a; the buffer window starts at the first row fetched
     const long long mbase = m0 > w1 ? m0 - w1 : 0;
-    const __amdgpu_buffer_rsrc_t a9 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(x) + mbase * p.cin * ES, 0,
+    const __amdgpu_buffer_rsrc_t a9 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(x) + mbase * pxs * ES, 0,
                                                                          (int)BUF_OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t b9 = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(w) + (p.w_kstep ? (long long)n0 * 64 : (long long)n0 * p.ldb * ES), 0, (int)BUF_OOB, 0x00020000);
@@ -430,13 +439,13 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
 #pragma unroll
     for (int i = 0; i < T9_NA; ++i) {
       const long long m = (long long)m0 - w1 + rb + RPP * i;
-      aoff9[i] = (m >= 0 && m < p.M) ? (unsigned)((m - mbase) * p.cin * ES) + cq * 16 : BUF_OOB;
+      aoff9[i] = (m >= 0 && m < p.M) ? (unsigned)((m - mbase) * pxs * ES) + cq * 16 : BUF_OOB;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i)
-      boff9[i] = n0 + rb + RPP * i >= p.N ? BUF_OOB
-                 : p.w_kstep              ? (unsigned)((rb + RPP * i) * 64) + (cq & 3) * 16
-                                          : (unsigned)((long long)(rb + RPP * i) * p.ldb * ES) + cq * 16;
+      boff9[i] = (n0 + rb + RPP * i >= p.N || rb + RPP * i >= BN) ? BUF_OOB
+                 : p.w_kstep                                      ? (unsigned)((rb + RPP * i) * 64) + (cq & 3) * 16
+                                                                  : (unsigned)((long long)(rb + RPP * i) * p.ldb * ES) + cq * 16;
     // bit tp of vm[mt]: tap tp of this lane's row of block mt lies inside its frame
     unsigned vm[2];
 #pragma unroll
@@ -448,9 +457,14 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
       if (live) {
         const int pix = m % p.HoWo;
         const int yy = pix / p.W, xx = pix - yy * p.W;
+        if constexpr (TGEN) {
+          for (int tp = 0; tp < ntap; ++tp)
+            if ((unsigned)(yy + tp / tkw - tph) < (unsigned)p.H && (unsigned)(xx + tp % tkw - tpw) < (unsigned)p.W) mk |= 1u << tp;
+        } else {
 #pragma unroll
-        for (int tp = 0; tp < 9; ++tp)
-          if ((unsigned)(yy + tp / 3 - 1) < (unsigned)p.H && (unsigned)(xx + tp % 3 - 1) < (unsigned)p.W) mk |= 1u << tp;
+          for (int tp = 0; tp < 9; ++tp)
+            if ((unsigned)(yy + tp / 3 - 1) < (unsigned)p.H && (unsigned)(xx + tp % 3 - 1) < (unsigned)p.W) mk |= 1u << tp;
+        }
       }
       vm[mt] = mk;
     }
@@ -484,7 +498,7 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
         __builtin_amdgcn_raw_ptr_buffer_load_lds(b9, (__attribute__((address_space(3))) void*)(bbuf + 256 * i), 16,
                                                  (int)boff9[i], kb, 0, 0);
       sb_slot = sb_slot == 2 ? 0 : sb_slot + 1;
-      if (++sb_tap == 9) {
+      if (++sb_tap == ntap) {
         sb_tap = 0;
         ++sb_blk;
       }
@@ -567,11 +581,11 @@ __global__ __launch_bounds__(256, (ROWB == 64 && !ACC64 && WR == 2) ? ((BN == 64
       __builtin_amdgcn_sched_barrier(0);
       slot = slot == 2 ? 0 : slot + 1;
       ++sig;   // next tap: one pixel to the right, or the next row's first
-      if (++tdx == 3) {
+      if (++tdx == tkw) {
         tdx = 0;
-        sig += p.W - 3;
+        sig += p.W - tkw;
       }
-      if (++tap == 9) {
+      if (++tap == ntap) {
         tap = 0;
         ++blk;
         sig = -w1;
@@ -1646,6 +1660,19 @@ static bool igemm_tap9_ok(const IgemmParams& p, int es) {
          (long long)(384 + 64) * p.cin * es < (1ll << 31);
 }
 
+// The shapes the shifted-row form takes under the bias + ReLU epilogue (AVS_F16X2, 256-row tiles): any KH x KW / stride 1 with
+// "same" padding (output = input geometry) whose reach ph W + pw fits the 64 halo rows either side of a tile - Inception-v3's
+// 1x7 / 7x1 at 17x17, 3x3 at 35x35 and 8x8, 1x3 / 3x1 at 8x8; the input dense in pixels (a channel slice of a wider NHWC
+// tensor is fine: pixel stride >= cin); at most 32 taps; the caller not forcing the classic walk (AVS_TILE_256 keeps it).
+static bool igemm_taps_ok(const IgemmParams& p) {
+  if ((p.variant & 3) == AVS_TILE_256 || p.cin <= 0 || p.KW <= 0 || p.K % (p.cin * p.KW) != 0) return false;
+  const int kh = p.K / (p.cin * p.KW);
+  return kh * p.KW > 1 && kh * p.KW <= 32 && p.sh == 1 && p.sw == 1 && 2 * p.ph + 1 == kh && 2 * p.pw + 1 == p.KW &&
+         p.HoWo == p.H * p.W && p.Wo == p.W && p.ph * p.W + p.pw <= 64 && p.x_px_stride >= p.cin &&
+         p.x_row_stride == (long long)p.W * p.x_px_stride && p.x_img_stride == (long long)p.HoWo * p.x_px_stride &&
+         p.cin % 16 == 0 && (long long)(384 + 64) * p.x_px_stride * 4 + (long long)p.cin * 4 < (1ll << 31);
+}
+
 // every dispatcher returns whether a kernel was launched: a (dtype, tile, epilogue) combination that has no instantiation
 // is an error of the launcher's rules, reported as AVS_E_UNSUPPORTED - never a silent AVS_OK with an untouched output
 #define AVS_LAUNCH_RET(K)                                     \
@@ -1684,9 +1711,14 @@ static bool igemm_dispatch_epi4(int epi, dim3 grid, hipStream_t stream, const Ig
           }
         }
         AVS_LAUNCH_RET((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_STATS, PIPE, WR, FK, 2>));
-      } else if (epi == EPI_BRELU)
+      } else if (epi == EPI_BRELU) {
+        if constexpr (SP && ROWB == 64 && PIPE && WR == 4 && FK) {
+          if (igemm_taps_ok(p)) {   // stride-1 "same" filters: one A fetch per channel block serves every tap
+            AVS_LAUNCH_RET((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BRELU, PIPE, WR, FK, 2, true>));
+          }
+        }
         AVS_LAUNCH_RET((igemm_kernel<ES, BN, ACC64, SP, ROWB, EPI_BRELU, PIPE, WR, FK, 2>));
-      else if constexpr (WR == 4) {
+      } else if constexpr (WR == 4) {
         if (epi == EPI_BNLOCAL) {
           if constexpr (SP && ROWB == 64 && PIPE && FK) {
             if (igemm_tap9_ok(p, ES)) {
@@ -1761,6 +1793,7 @@ static bool igemm_dispatch_brelu96(bool spatial, dim3 grid, hipStream_t stream, 
 #endif
   const bool fk = igemm_fastk_ok(p, 4, 16, 96);
   if (spatial) {
+    if (fk && igemm_taps_ok(p)) AVS_LAUNCH_RET((igemm_kernel<4, 96, false, true, 64, EPI_BRELU, true, 4, true, 2, true>));
     if (fk) AVS_LAUNCH_RET((igemm_kernel<4, 96, false, true, 64, EPI_BRELU, true, 4, true, 2>));
     AVS_LAUNCH_RET((igemm_kernel<4, 96, false, true, 64, EPI_BRELU, true, 4, false, 2>));
   }

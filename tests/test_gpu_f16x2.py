@@ -706,3 +706,38 @@ def test_conv_bias_relu_96_column_tiles(dev, cfg):
     assert (got - ref).abs().max().item() <= TOL * scale
     for o in outs[1:]:
         assert torch.equal(o.view(torch.int32), outs[0].view(torch.int32))
+
+
+@pytest.mark.parametrize("cfg", [
+    (1024, 17, 128, 192, 1, 7, 0), (1024, 17, 160, 160, 7, 1, 32), (512, 35, 64, 96, 3, 3, 48), (2048, 8, 384, 384, 1, 3, 0),
+    (2048, 8, 448, 384, 3, 3, 64), (900, 17, 192, 192, 7, 1, 0),
+])
+def test_conv_bias_relu_shifted_row_form(dev, cfg):
+    """Stride-1 'same' bias + ReLU convolutions (Inception-v3's 1x7 / 7x1 / 3x3 / 1x3 layers, features/extractors.py:26,83) on
+    enough rows for the 256-row tiles take the shifted-row form by rule: a channel block of the tile's pixels and its halo is
+    fetched once and serves every tap from shifted LDS rows (block-major / tap-minor reduction order).  Against the classic
+    tap walk (AVS_TILE_256 keeps it) to rounding on the whole tensor - frame borders, tiles that straddle frames, an input
+    that is a channel slice of a wider tensor - and against the float64 reference on the first frames; twice the same bits."""
+    ops = _ops()
+    n, h, cin, cout, kh, kw, xoff = cfg
+    g = torch.Generator().manual_seed(h * 31 + cin + kh)
+    wide = ops.f16x2_pack(torch.randn(n, h, h, cin + xoff, generator=g).to(dev))
+    x = wide[..., xoff // 2:xoff // 2 + cin] if xoff else wide
+    wt = torch.randn(cout, kh * kw * cin, generator=g) / (kh * kw * cin) ** 0.5
+    wp = ops.f16x2_pack(wt.to(dev))
+    bias = torch.randn(cout, generator=g).to(dev)
+    pad = (kh // 2, kw // 2)
+    outs = []
+    for variant in (0, 0, 2):
+        y = torch.empty((n, h, h, cout), device=dev)
+        ops.conv2d(x, ops.weights_kstep32(wp), kh, kw, 1, pad, y, bias, ops.ACT_RELU, split="f16x2", w_layout=1, variant=variant)
+        outs.append(y)
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
+    a, b = ops.f16x2_unpack(outs[0]), ops.f16x2_unpack(outs[2])
+    scale = max(1.0, b.abs().max().item())
+    assert (a - b).abs().max().item() <= 4e-6 * scale          # two fp32 summation orders of the same products
+    m = 3
+    xv = ops.f16x2_unpack(x[:m].contiguous()).cpu().double()
+    wv = ops.f16x2_unpack(wp).cpu().double().reshape(cout, kh, kw, cin)
+    ref = torch.relu(_conv_ref(xv, wv, 1, pad) + bias.cpu().double())
+    assert (a[:m].cpu().double() - ref).abs().max().item() <= TOL * max(1.0, ref.abs().max().item())
