@@ -131,7 +131,8 @@ typedef struct {
                              * output tiles; AVS_TILE_224 (avs_conv2d_nhwc_bnlocal, AVS_F16X2 only): the 224-row tile
                              * whose waves split the columns, for groups of 193..224 rows - what AVS_TILE_AUTO picks
                              * for such groups, AVS_TILE_256 keeps them on the 256-row tile (and keeps the AVS_F16X2
-                             * 3x3 / stride-1 layers on the tap-major walk instead of the nine-tap form);
+                             * stride-1 'same' layers - 3x3 under the BatchNorm epilogues, any KH x KW under bias + ReLU -
+                             * on the tap-major walk instead of the shifted-row form);
                              * AVS_STAGING_GENERIC (bit 2): the general per-lane gather staging even where
                              * the scalar tap walk applies.  Results do not depend on it beyond fp32 summation order. */
   int formats;              /* 0, or AVS_F16P8 operands of the AVS_F16X2 1x1 forms (bits): AVS_X_F16P8 - the INPUT of
