@@ -47,7 +47,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
 PMC_TRAFFIC_FILES = {"bf16": ("r02_pmc_traffic.json", "r01_e_pmc_traffic.json"),   # newest first, under profiles/
                      "f16x2+inception3": ("r04_g_both_pmc_traffic.json",),   # the both-trunks configuration's own passes
-                     "f16x2": ("r04_h_pmc_traffic.json", "r04_g_pmc_traffic.json", "r04_f_pmc_traffic.json", "r04_e_pmc_traffic.json", "r03_e_pmc_traffic.json", "r03_c_pmc_traffic.json", "r03_b_pmc_traffic.json", "r03_a_pmc_traffic.json")}
+                     "f16x2": ("r04_j_pmc_traffic.json", "r04_h_pmc_traffic.json", "r04_g_pmc_traffic.json", "r04_f_pmc_traffic.json", "r04_e_pmc_traffic.json", "r03_e_pmc_traffic.json", "r03_c_pmc_traffic.json", "r03_b_pmc_traffic.json", "r03_a_pmc_traffic.json")}
 
 T_START = time.perf_counter()
 
