@@ -1,5 +1,5 @@
 # Round-4 evidence in one gpurun call (on the GPU box; everything lands in gpurun_out/):
-#   bash tools/collect_round4.sh            -> r04_e_* (headline: kernel stats, PMC traffic, SQ counters), the other
+#   bash tools/collect_round4.sh            -> ${TAG}_* (headline: kernel stats, PMC traffic, SQ counters), the other
 #   configurations' kernel stats (training leg, both trunks, configs[2], per-frame groups, bf16), the full bench line
 TAG=${TAG:-r04_j}; R=/root/repo; O=$R/gpurun_out; mkdir -p $O
 TAG=$TAG DTYPE=f16x2 bash $R/tools/collect_profiles.sh > $O/${TAG}_collect.txt 2>&1; tail -3 $O/${TAG}_collect.txt
