@@ -1079,9 +1079,10 @@ def resample(x, taps, up, down, width, out_len):
 
 # --------------------------------------------------------------------------- scorer
 # ---- the split recurrence (avs_lstm_split_f32 / avs_lstm_bwd_split_f32): workspace + tag ranges per (device, stream)
-LSTM_SPLIT_MAX_RECURRENCES = 128    # AUTO takes the four-CU form up to this many recurrences per launch: 4 workgroups of 512
-#                                     threads each, one per CU - up to 64 recurrences all resident at once, up to 128 in two
-#                                     rounds (2 x 1.6 us per step against 5.2 for one recurrence per CU); beyond that one
+LSTM_SPLIT_MAX_RECURRENCES = 208    # AUTO takes the four-CU form up to this many recurrences per launch: 4 workgroups of 512
+#                                     threads each, one per CU.  tools/lstm_study.py (profiles/r04_lstm_study.txt), sequences of
+#                                     ~1800 steps: 48 recurrences 3.4 ms against 11.0 for one recurrence per CU, 100 (two rounds
+#                                     on 256 CUs) 6.3 against 12.4, 200 (four rounds) 10.2 against 12.1; past ~250 one
 #                                     recurrence per CU is the better use of the chip
 
 
