@@ -619,7 +619,7 @@ int avs_lstm_bwd_f32(const float* d_dout, int64_t ldo, int out_col0, const float
  * a time step costs ~1.6 us (forward) / 1.85 us (backward) instead of 5.2 / 5.3: for FEW recurrences (one video per
  * training step, a few dozen videos at inference).  A launch runs 4 * ndir * nseq workgroups of 512 threads, one per CU: up
  * to 64 recurrences are all resident at once; more run in rounds (partners are dispatched together: complete groups always
- * finish) and past ~190 recurrences avs_lstm_f32's one recurrence per CU is the faster use of the chip.
+ * finish) and past ~250 recurrences avs_lstm_f32's one recurrence per CU is the faster use of the chip.
  * d_ws: avs_lstm_split_workspace_bytes(ndir, nseq) bytes, 8-byte aligned, ZEROED ONCE by the caller before its first use
  * and then left alone; epoch: tags of a launch are epoch + 1 ... epoch + longest sequence - the caller passes values whose
  * ranges do not overlap from launch to launch on the same workspace (e.g. a running sum of rows + 1) and stay below 2^32
