@@ -560,7 +560,10 @@ extern "C" int avs_bn_apply(int dtype, const void* d_x, int64_t rows, int c, int
 // ---------------------------------------------------------------------------
 // Pooling on NHWC
 // ---------------------------------------------------------------------------
-template <typename T, int V>
+// K3: the 3x3 window (every pooling of ResNet-50 and Inception-v3) with its nine loads issued together - coordinates
+// clamped into the image, taps outside it dropped when the window is combined (the same order as the general loop: the
+// same bits) - instead of nine dependent load -> combine rounds behind two `continue` branches.
+template <typename T, int V, bool K3 = false>
 __global__ __launch_bounds__(256) void pool2d_kernel(int mode, const T* __restrict__ x, int n, int h, int w, int c,
                                                      long long xps, int k, int s, int p, const float* __restrict__ bias,
                                                      int relu, T* __restrict__ y, int ho, int wo, long long yps) {
@@ -577,6 +580,23 @@ __global__ __launch_bounds__(256) void pool2d_kernel(int mode, const T* __restri
     float a[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) a[j] = mode == 0 ? -INFINITY : 0.f;
+    if constexpr (K3) {
+      float v[9][V];
+      bool ok[9];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int iy = oy * s - p + ky, ix = ox * s - p + kx;
+          ok[ky * 3 + kx] = (unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w;
+          const int cy = iy < 0 ? 0 : (iy >= h ? h - 1 : iy), cx = ix < 0 ? 0 : (ix >= w ? w - 1 : ix);
+          loadv<T, V>(x + ((img * h + cy) * (long long)w + cx) * xps + ch, v[ky * 3 + kx]);
+        }
+#pragma unroll
+      for (int q = 0; q < 9; ++q)
+#pragma unroll
+        for (int j = 0; j < V; ++j) a[j] = !ok[q] ? a[j] : (mode == 0 ? fmaxf(a[j], v[q][j]) : a[j] + v[q][j]);
+    } else {
     for (int ky = 0; ky < k; ++ky) {
       const int iy = oy * s - p + ky;
       if ((unsigned)iy >= (unsigned)h) continue;
@@ -588,6 +608,7 @@ __global__ __launch_bounds__(256) void pool2d_kernel(int mode, const T* __restri
 #pragma unroll
         for (int j = 0; j < V; ++j) a[j] = mode == 0 ? fmaxf(a[j], v[j]) : a[j] + v[j];
       }
+    }
     }
     if (mode == 1) {
       const float d = (float)(k * k);
@@ -628,7 +649,11 @@ extern "C" int avs_pool2d_nhwc(int dtype, int mode, const void* d_x, int n, int 
   const long long total = (long long)n * ho * wo * (c / ((wide || h2) ? 8 : 4));
   long long gx = avs_cdiv(total, 256);
   if (gx > 65536) gx = 65536;
-  if (h2)
+  if (h2 && k == 3)
+    hipLaunchKernelGGL((pool2d_kernel<avs_h2_tag, 8, true>), dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, mode,
+                       (const avs_h2_tag*)d_x, n, h, w, c, (long long)x_px_stride, k, s, p, d_bias, relu,
+                       (avs_h2_tag*)d_y, ho, wo, (long long)y_px_stride);
+  else if (h2)
     hipLaunchKernelGGL((pool2d_kernel<avs_h2_tag, 8>), dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, mode,
                        (const avs_h2_tag*)d_x, n, h, w, c, (long long)x_px_stride, k, s, p, d_bias, relu,
                        (avs_h2_tag*)d_y, ho, wo, (long long)y_px_stride);
