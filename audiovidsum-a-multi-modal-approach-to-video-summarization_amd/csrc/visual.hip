@@ -661,6 +661,10 @@ extern "C" int avs_pool2d_nhwc(int dtype, int mode, const void* d_x, int n, int 
     hipLaunchKernelGGL((pool2d_kernel<float, 4>), dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, mode,
                        (const float*)d_x, n, h, w, c, (long long)x_px_stride, k, s, p, d_bias, relu, (float*)d_y, ho,
                        wo, (long long)y_px_stride);
+  else if (wide && k == 3)
+    hipLaunchKernelGGL((pool2d_kernel<avs_bf16_tag, 8, true>), dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, mode,
+                       (const avs_bf16_tag*)d_x, n, h, w, c, (long long)x_px_stride, k, s, p, d_bias, relu,
+                       (avs_bf16_tag*)d_y, ho, wo, (long long)y_px_stride);
   else if (wide)
     hipLaunchKernelGGL((pool2d_kernel<avs_bf16_tag, 8>), dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, mode,
                        (const avs_bf16_tag*)d_x, n, h, w, c, (long long)x_px_stride, k, s, p, d_bias, relu,

@@ -830,3 +830,43 @@ def test_colsum_bias_gradient_kernel(dev, rows, cols, ld, weighted):
     assert got.shape == (cols,)
     assert (got.cpu().double() - ref).abs().max().item() <= 2e-6 * scale
     assert torch.equal(ops.colsum(xd, wd), got)
+
+
+@pytest.mark.parametrize("kind", ["f16x2", "bf16"])
+def test_pool2d_3x3_windows_packed_formats(dev, kind):
+    """avs_pool2d_nhwc on 3x3 windows in the storage formats of the two trunks (every pooling of ResNet-50 / Inception-v3,
+    features/extractors.py:29,83): the nine loads of a window issued together, outside taps dropped - max pooling exact
+    (a max of stored values is a stored value), average pooling to the format's rounding; odd sizes, both strides, padding,
+    channel-slice destination with bias + ReLU."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(77)
+    n, h, w, c = 3, 17, 13, 24
+    x32 = torch.randn(n, h, w, c, generator=g)
+    if kind == "f16x2":
+        xd = ops.f16x2_pack(x32.to(dev))
+        xv = ops.f16x2_unpack(xd).cpu()
+        mk = lambda shape: torch.zeros(shape, device=dev)
+        rd = lambda t: ops.f16x2_unpack(t.contiguous()).cpu()
+        code, tol = ops.dtype_code(torch.float32, "f16x2"), 5e-7
+    else:
+        xd = x32.to(dev).to(torch.bfloat16)
+        xv = xd.float().cpu()
+        mk = lambda shape: torch.zeros(shape, device=dev, dtype=torch.bfloat16)
+        rd = lambda t: t.float().cpu()
+        code, tol = None, 8e-3
+    xc = xv.permute(0, 3, 1, 2)
+    for mode, s, p in (("max", 2, 0), ("max", 2, 1), ("max", 1, 1), ("avg", 1, 1), ("avg", 2, 0)):
+        ref = (F.max_pool2d(xc, 3, s, p) if mode == "max" else F.avg_pool2d(xc, 3, s, p)).permute(0, 2, 3, 1)
+        out = mk((n, ref.shape[1], ref.shape[2], c))
+        ops.pool2d(xd, mode, 3, s, p, out, code=code)
+        got = rd(out)
+        if mode == "max":
+            assert torch.equal(got, ref)
+        else:
+            assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    bias = torch.randn(c, generator=g)
+    wide = mk((n, h, w, c + 16))
+    ops.pool2d(xd, "avg", 3, 1, 1, wide[..., 8:8 + c], bias.to(dev), ops.ACT_RELU, code=code)
+    ref = torch.relu(F.avg_pool2d(xc, 3, 1, 1).permute(0, 2, 3, 1) + bias)
+    assert (rd(wide[..., 8:8 + c]) - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    assert rd(wide[..., :8]).abs().max().item() == 0 and rd(wide[..., 8 + c:]).abs().max().item() == 0
