@@ -188,6 +188,7 @@ __global__ __launch_bounds__(512) void lstm_split_bwd_kernel(const float* __rest
     p_d = dbase[row * ldo];
     if (T > 1) p_cprev = cbase[row_of(T - 2) * ldc];
   }
+  float p_tc = tanhf(p_c);   // tanh of the step's cell state: computed a step ahead, under the exchange's wait
   if (tid == 0) bail = 0;
   __syncthreads();
   unsigned long long* const slots = xchg + (long long)rec * 2 * SP_SLOT;
@@ -198,8 +199,8 @@ __global__ __launch_bounds__(512) void lstm_split_bwd_kernel(const float* __rest
     const unsigned tag = epoch + (unsigned)n;
     unsigned long long* const slot = slots + (n & 1) * SP_SLOT;
     if (tid < SP_UNITS) {
-      const float ig = p_i, fg = p_f, cg = p_g, og = p_o, c = p_c, c_prev = s > 0 ? p_cprev : 0.f;
-      const float tc = tanhf(c);
+      const float ig = p_i, fg = p_f, cg = p_g, og = p_o, c_prev = s > 0 ? p_cprev : 0.f;
+      const float tc = p_tc;   // tanh(cell state of this step)
       const float dh = p_d + dh_next;
       const float d_o = dh * tc;
       const float dc = dh * og * (1.f - tc * tc) + dc_next;
@@ -225,6 +226,7 @@ __global__ __launch_bounds__(512) void lstm_split_bwd_kernel(const float* __rest
         p_d = dbase[nrow * ldo];
         p_c = p_cprev;
         if (s > 1) p_cprev = cbase[row_of(s - 2) * ldc];
+        p_tc = tanhf(p_c);   // (p_c arrived a step ago: no memory wait here)
       }
     }
     if (s > 0) {   // (the last step's product would feed nothing)
