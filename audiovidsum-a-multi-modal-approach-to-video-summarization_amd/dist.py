@@ -28,6 +28,12 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # REHEARSAL on a box with fewer GPUs than ranks (tests only): AVS_DIST_REHEARSAL=1 maps every rank onto the devices that
+    # exist (local % device_count) and runs the collectives on gloo (RCCL refuses two ranks on one GPU) - the multi-rank
+    # program flow on real kernels, not a measurement
+    if os.environ.get("AVS_DIST_REHEARSAL") == "1" and torch.cuda.is_available():
+        local = local % max(1, torch.cuda.device_count())
+        backend = backend or "gloo"
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"

@@ -554,11 +554,12 @@ def main():
 
     if args.config == 4:
         # the configs[4] training leg on its own (what sub_results.config4_training runs at N = 1); N > 1: data-parallel
-        leg = config4_leg(dev, steps=args.steps if args.steps != 5 else 20, rank=rank, world=world)
+        c4_steps = args.steps if args.steps != 5 else 20
+        leg = config4_leg(dev, steps=c4_steps, rank=rank, world=world)
         if rank == 0:
             best = leg["lengths"]["1800"]
             print(json.dumps({"metric": "training videos/sec (scripts/train_av_model.py loop, T = 1800, data-parallel over the ranks)",
-                              "value": best["videos_per_s"], "unit": "videos/s", "n_gpus": world, "steps": 20, "warmup": 2,
+                              "value": best["videos_per_s"], "unit": "videos/s", "n_gpus": world, "steps": c4_steps, "warmup": 2,
                               "ms_per_step": best["ms_per_step"], "higher_is_better": True, "scaling": "weak",
                               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                               "config": {"workload": leg["workload"], "parallelism": f"data-parallel x{world}: one video per rank "

@@ -374,3 +374,28 @@ print("RCCL_OK", torch.cuda.get_device_name(0))
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0 and "RCCL_OK" in out.stdout, out.stderr[-1500:]
+
+
+def test_two_rank_rehearsal_of_the_bench_on_one_gpu(tmp_path):
+    """The multi-rank program flow on real kernels: two ranks of `bench.py --gpus 2` share this box's GPU (AVS_DIST_REHEARSAL=1:
+    ranks map onto the devices that exist, collectives on gloo - RCCL refuses two ranks on one GPU), started the way the
+    driver starts N > 1 (torch.distributed.run).  Weights broadcast from rank 0, each rank its own batch, scores gathered under
+    global ids, the slowest rank's time, ONE JSON line from rank 0 with n_gpus = 2 - for the headline path and the configs[4]
+    training leg (gradients averaged over the ranks before AdamW).  Not a measurement."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AVS_DIST_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for port, extra, unit in ((29521, ["--steps", "1", "--warmup", "1", "--videos", "4", "--mean-frames", "400", "--cpu-sample", "0"],
+                               "frames/s"),
+                              (29522, ["--config", "4", "--steps", "3"], "videos/s")):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2"] + extra
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["unit"] == unit and d["value"] > 0 and d["scaling"] == "weak"
