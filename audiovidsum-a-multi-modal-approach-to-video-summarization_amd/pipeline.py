@@ -114,6 +114,12 @@ class FrameScoringPipeline:
         # half (layers 3-4) of the other.  Passes are independent (disjoint frames, disjoint rows of the output).
         self.streams = int(streams)
         self._side = None
+        if self.streams == 2:
+            # kernels whose workgroups WAIT for each other (the clustered BatchNorm) rely on one queue's in-order dispatch: a
+            # group's workgroups are dispatched together, complete groups always finish.  Two queues feeding the chip at once can
+            # each hold partial groups that fill the CUs and wait for partners the other queue's partial groups keep out - the
+            # bounded waits would end it and score() would raise.  Two-stream passes therefore keep to the unclustered forms
+            visual_extractor._resnet_runner.bn_cluster = False
 
     def _group_offsets(self, video_offsets):
         """BatchNorm groups never straddle a video: per video, groups of frames_per_group (+ remainder)."""

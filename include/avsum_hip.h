@@ -197,6 +197,10 @@ int avs_conv2d_nhwc_bnlocal(const avs_conv_desc* desc, const void* d_x, const vo
  * statistics / apply passes, deterministic.  The tiles of a group take consecutive block ids (they are dispatched together);
  * the wait for a partner is bounded: the first word of d_xchg counts the waves whose wait ran out (0 after a healthy
  * launch; check it where results are validated).
+ * ASSUMES that this launch's workgroups reach the CUs in block order from ONE queue (what a process that owns its GPU gets):
+ * complete groups then always finish and free the CUs the next groups need.  When several queues feed the chip at once with
+ * kernels of this kind - two streams, or processes time-sharing one GPU - each can hold partial groups that keep the other's
+ * partners out; the bounded waits then end the launch and the counter says so (observed with 4 processes on one GPU).
  * d_xchg: avs_conv2d_bncluster_workspace_bytes(...) bytes, 64-byte aligned, ZEROED ONCE by the caller when allocated and
  * then left alone; epoch: a value that is new for this buffer on every call (1, 2, 3, ...; never 0) - granules of earlier
  * calls are then recognisably stale, nothing needs clearing between calls.
@@ -625,7 +629,8 @@ int avs_lstm_bwd_f32(const float* d_dout, int64_t ldo, int out_col0, const float
  * ranges do not overlap from launch to launch on the same workspace (e.g. a running sum of rows + 1) and stay below 2^32
  * (tag 0 is the zeroed workspace's: before the sum would wrap, zero the workspace again and start over).  The FIRST 64 bytes of the workspace hold an error word (uint32, first of them): the number of
  * workgroups whose bounded wait (~0.3 s) for a partner ran out - 0 after a healthy launch; such a launch ends, its
- * outputs are incomplete.                                                                                            */
+ * outputs are incomplete.  The same single-queue assumption as avs_conv2d_nhwc_bncluster: not for GPUs time-shared between
+ * processes, nor for two streams running such kernels at once.                                                                                            */
 size_t avs_lstm_split_workspace_bytes(int ndir, int nseq);
 int avs_lstm_split_f32(const float* d_xproj, const float* d_whh_t, int hidden, int ndir, unsigned reverse_mask,
                        const int64_t* d_seq_rows, int nseq, float* d_out, int64_t ldo, int out_col0, float* d_gates,
