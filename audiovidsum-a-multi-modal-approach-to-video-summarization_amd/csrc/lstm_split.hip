@@ -24,7 +24,7 @@
 namespace {
 constexpr int SP_H = 256, SP_G = 1024, SP_PARTS = 4, SP_UNITS = SP_H / SP_PARTS;   // 64 hidden units per workgroup
 constexpr int SP_SLOT = 1024;               // granules per step parity (forward uses the first 256)
-constexpr int SP_SPIN = 1 << 20;            // bounded wait: ~0.3 s
+constexpr int SP_SPIN = 1 << 20;            // bounded wait: 2^20 polls, of the order of a second
 
 __device__ __forceinline__ void sp_map(int b, int& rec, int& part) {
   // 32 consecutive blocks = 8 recurrences x 4 parts; a recurrence's parts are 8 ids apart

@@ -627,10 +627,11 @@ int avs_lstm_bwd_f32(const float* d_dout, int64_t ldo, int out_col0, const float
  * d_ws: avs_lstm_split_workspace_bytes(ndir, nseq) bytes, 8-byte aligned, ZEROED ONCE by the caller before its first use
  * and then left alone; epoch: tags of a launch are epoch + 1 ... epoch + longest sequence - the caller passes values whose
  * ranges do not overlap from launch to launch on the same workspace (e.g. a running sum of rows + 1) and stay below 2^32
- * (tag 0 is the zeroed workspace's: before the sum would wrap, zero the workspace again and start over).  The FIRST 64 bytes of the workspace hold an error word (uint32, first of them): the number of
- * workgroups whose bounded wait (~0.3 s) for a partner ran out - 0 after a healthy launch; such a launch ends, its
+ * (tag 0 is the zeroed workspace's: before the sum would wrap, zero the workspace again and start over).
+ * The FIRST 64 bytes of the workspace hold an error word (uint32, first of them): the number of workgroups whose bounded
+ * wait (2^20 polls: of the order of a second) for a partner ran out - 0 after a healthy launch; such a launch ends, its
  * outputs are incomplete.  The same single-queue assumption as avs_conv2d_nhwc_bncluster: not for GPUs time-shared between
- * processes, nor for two streams running such kernels at once.                                                                                            */
+ * processes, nor for two streams running such kernels at once.                                                       */
 size_t avs_lstm_split_workspace_bytes(int ndir, int nseq);
 int avs_lstm_split_f32(const float* d_xproj, const float* d_whh_t, int hidden, int ndir, unsigned reverse_mask,
                        const int64_t* d_seq_rows, int nseq, float* d_out, int64_t ldo, int out_col0, float* d_gates,
