@@ -513,7 +513,10 @@ def main():
     from avsum_amd.pipeline import FrameScoringPipeline
 
     if args.chunk is None:
-        args.chunk = 24576 if args.dtype == "bf16" else 12288
+        # frames per pass of the trunk.  4-byte modes, ResNet-50 only: 16 384 (three passes of 15 048 for configs[1]; measured on
+        # one box, back to back: 12 288 -> 26 624, 16 384 -> 26 750, 24 576 -> 26 779 frames/s; layer 1's 72 GB tensors at
+        # 24 576 leave too little of the 288 GB); with Inception-v3 (its 147 x 147 maps are 5.5 MB per frame) 12 288
+        args.chunk = 24576 if args.dtype == "bf16" else (16384 if args.extractor == "resnet50" else 12288)
     rank, world, local = avd.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
